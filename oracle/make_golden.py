@@ -1,0 +1,429 @@
+"""Generate golden vectors by RUNNING THE REFERENCE ITSELF (build container only).
+
+TEST INFRASTRUCTURE ONLY.  Usage (from the repo root, in the container that has
+/root/reference):
+
+    python -m oracle.make_golden small        # ops / layers / tiny-FLUX / TeaCache  (~1 min)
+    python -m oracle.make_golden c3 [--blocks 19 38]   # full-width FLUX @ 1024x2048 (tens of minutes)
+
+The reference is imported from /root/reference with two stub modules
+(`fastdm.kernel.cuda`, `fastdm.kernel.triton`: their real versions need the CUDA
+extension / triton kernels) and KERNEL_BACKEND=torch, QLinear forced to the CPU
+(SURVEY.md §8c).  `fp8_matmul` has no CPU implementation upstream
+(torch._scaled_mm row-wise is CUDA-only), so an extra backend is registered for that one
+op: the reference's own primitive `torch._scaled_mm` with unit per-tensor scales yields
+the fp32 accumulator, to which the row/column scales and bias are applied in fp32 exactly
+as csrc/gemm/hopper_w8a8_fp8.cu:95-142 does.  Nothing here travels to the GPU box except
+the vectors it writes under tests/golden/.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+# ------------------------------------------------------------------ reference import
+def import_reference():
+    os.environ["KERNEL_BACKEND"] = "torch"
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for m in ("fastdm.kernel.cuda", "fastdm.kernel.triton"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    import fastdm.kernel  # noqa: F401
+    from fastdm.kernel.registry import kernel_registry
+    from fastdm.layer import qlinear as ref_qlinear
+
+    reg = kernel_registry._registry
+    if "cpu_fp8" not in reg["fp8_matmul"]:
+        def fp8_matmul_cpu(a, b, scale_a, scale_b, out_dtype, bias=None):
+            one = torch.tensor(1.0)
+            outs = []
+            for s in range(0, a.shape[0], 2048):
+                acc = torch._scaled_mm(a[s:s + 2048], b, one, one, None, out_dtype=torch.float32)
+                r = acc * scale_a[s:s + 2048] * scale_b.reshape(1, -1)
+                if bias is not None:
+                    r = r + bias.float()
+                outs.append(r.to(out_dtype))
+            return torch.cat(outs, 0)
+        reg["fp8_matmul"]["cpu_fp8"] = fp8_matmul_cpu
+    # gelu_and_mul is force-dispatched to triton (operators_set.py:54): alias the torch impl.
+    reg["gelu_and_mul"].setdefault("triton", reg["gelu_and_mul"]["torch"])
+
+    if not getattr(ref_qlinear.QLinear, "_cpu_patched", False):
+        orig_init = ref_qlinear.QLinear.__init__
+
+        def cpu_init(self, in_features, out_features, bias=True, data_type=torch.bfloat16, device_type="cpu"):
+            orig_init(self, in_features, out_features, bias=bias, data_type=data_type, device_type="cpu")
+        ref_qlinear.QLinear.__init__ = cpu_init
+        ref_qlinear.QLinear._cpu_patched = True
+    return kernel_registry
+
+
+def use_backend(name):
+    """'torch' for everything; 'cpu_fp8' makes fp8_matmul use the CPU restatement (other ops
+    fall back to torch, registry.py:31)."""
+    os.environ["KERNEL_BACKEND"] = name
+
+
+# ------------------------------------------------------------------ npz packing
+def pack(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().contiguous()
+            if v.dtype == torch.bfloat16:
+                out[k + "__bf16"] = v.view(torch.int16).numpy().view(np.uint16)
+            elif v.dtype == torch.float8_e4m3fn:
+                out[k + "__fp8"] = v.view(torch.uint8).numpy()
+            else:
+                out[k] = v.numpy()
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+def unpack(npz):
+    out = {}
+    for k in npz.files:
+        a = npz[k]
+        if k.endswith("__bf16"):
+            out[k[:-6]] = torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16)
+        elif k.endswith("__fp8"):
+            out[k[:-5]] = torch.from_numpy(a.copy()).view(torch.float8_e4m3fn)
+        else:
+            out[k] = torch.from_numpy(a.copy()) if a.shape != () else a.item()
+    return out
+
+
+def load(name):
+    return unpack(np.load(os.path.join(GOLD, name)))
+
+
+def save(name, d):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name)
+    np.savez_compressed(path, **pack(d))
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def randn_bf16(gen, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=gen) * scale).to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------ small fixtures
+def gen_ops():
+    import_reference()
+    use_backend("torch")
+    from fastdm.kernel import operators_set as R
+    g = torch.Generator().manual_seed(1234)
+    d = {}
+    # rms_norm: 4-D FLUX q/k-norm layout, 3-D Wan layout, odd row count (tests/test_rmsnorm.py:5-14 shapes, reduced)
+    for tag, shape in (("rms4d", (1, 37, 4, 128)), ("rms3d", (2, 9, 320)), ("rms64", (3, 5, 2, 64))):
+        x = randn_bf16(g, *shape, scale=3.0)
+        w = (1 + 0.1 * torch.randn(shape[-1], generator=g)).to(torch.bfloat16)
+        d[f"{tag}_x"], d[f"{tag}_w"] = x, w
+        d[f"{tag}_out"] = R.rms_norm(x, w, 1e-6)
+    # rope GPT-J (tests/test_rope.py:5-7 layout, reduced) and NeoX
+    for tag, (B, S, H, hd, neox) in (("ropej", (2, 33, 4, 64, False)), ("ropej128", (1, 70, 3, 128, False)),
+                                      ("ropen", (1, 17, 2, 64, True))):
+        q = randn_bf16(g, B, S, H * hd)
+        k = randn_bf16(g, B, S, H * hd)
+        ang = torch.rand(S, hd // 2, generator=g) * 6.28
+        cache = torch.cat((ang.cos(), ang.sin()), dim=-1).to(torch.bfloat16)
+        d[f"{tag}_q"], d[f"{tag}_k"], d[f"{tag}_cache"] = q.clone(), k.clone(), cache
+        R.rotary_pos_embedding(q, k, hd, cache, is_neox=neox)
+        d[f"{tag}_qout"], d[f"{tag}_kout"] = q, k
+    # per-token quant incl. constant / all-negative / zero / huge rows (tests/test_quant.py shapes, reduced)
+    x = randn_bf16(g, 19, 256, scale=2.0)
+    x[3] = 0.75
+    x[5] = -x[5].abs() - 0.5
+    x[7] = 0.0
+    x[9] *= 1000.0
+    x[11, 17] = 300.0
+    d["quant_x"] = x
+    q8, s8 = R.quantize_to_fp8(x)
+    d["quant_fp8_q"], d["quant_fp8_s"] = q8, s8
+    xi = x.clone()
+    xi[7, 0] = 1.0  # an all-zero row is 0/0 in the reference's int8 path; keep it finite
+    xi[3, 1] = 0.5  # constant rows give scale 0 in the asymmetric path
+    d["quant_xi"] = xi
+    qi, si, zi = R.quantize_to_int8(xi, symmetric=False)
+    d["quant_i8a_q"], d["quant_i8a_s"], d["quant_i8a_zp"] = qi, si, zi
+    qs, ss, _ = R.quantize_to_int8(xi, symmetric=True)
+    d["quant_i8s_q"], d["quant_i8s_s"] = qs, ss
+    # W8A8 GEMMs (tests/test_matmul.py:48-71,104-123 recipe at reduced shapes)
+    for tag, (M, K, N) in (("mm14", (14, 256, 192)), ("mm130", (130, 384, 320))):
+        a = torch.randint(-128, 128, (M, K), generator=g).to(torch.int8)
+        b = torch.randint(-128, 128, (K, N), generator=g).to(torch.int8).t().contiguous().t()
+        sa = torch.randn(M, 1, generator=g)
+        sb = torch.randn(N, 1, generator=g)
+        adj = torch.randint(-128, 127, (1, N), generator=g).to(torch.int32)
+        azp = torch.randint(-128, 127, (M, 1), generator=g).to(torch.int32)
+        bias = randn_bf16(g, N)
+        d.update({f"{tag}_i8_a": a, f"{tag}_i8_b": b, f"{tag}_sa": sa, f"{tag}_sb": sb, f"{tag}_adj": adj,
+                  f"{tag}_azp": azp, f"{tag}_bias": bias})
+        d[f"{tag}_i8_out_bias"] = R.int8_matmul(a, b, sa, sb, torch.bfloat16, adj, azp, bias)
+        d[f"{tag}_i8_out"] = R.int8_matmul(a, b, sa, sb, torch.bfloat16, adj, azp, None)
+        fa = torch.randn(M, K, generator=g).to(torch.float8_e4m3fn)
+        fb = torch.randn(K, N, generator=g).to(torch.float8_e4m3fn).t().contiguous().t()
+        d[f"{tag}_f8_a"], d[f"{tag}_f8_b"] = fa, fb
+        use_backend("cpu_fp8")
+        d[f"{tag}_f8_out_bias"] = R.fp8_matmul(fa, fb, sa, sb, torch.bfloat16, bias)
+        d[f"{tag}_f8_out"] = R.fp8_matmul(fa, fb, sa, sb, torch.bfloat16, None)
+        use_backend("torch")
+    # attention (tests/test_attention.py:7-21 families: hd 128 self, hd 64 self, hd 64 cross Sq != Skv)
+    torch.manual_seed(0)
+    for tag, (B, Sq, Sk, H, hd) in (("att128", (1, 200, 200, 3, 128)), ("att64", (2, 130, 130, 2, 64)),
+                                    ("attx64", (2, 96, 77, 2, 64))):
+        q = randn_bf16(g, B, Sq, H * hd)
+        k = randn_bf16(g, B, Sk, H * hd)
+        v = randn_bf16(g, B, Sk, H * hd)
+        d[f"{tag}_q"], d[f"{tag}_k"], d[f"{tag}_v"] = q, k, v
+        d[f"{tag}_out"] = R.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5)
+    # gelu_and_mul (tests/test_gelu_and_mul.py:5-8, reduced)
+    x = randn_bf16(g, 21, 2 * 160, scale=2.0)
+    d["gm_x"] = x
+    d["gm_out"] = R.gelu_and_mul(x)
+    save("ops.npz", d)
+
+
+def gen_layers():
+    import_reference()
+    use_backend("torch")
+    from fastdm.utils.quantization import fp8_quantization, int8_quantization
+    from fastdm.layer.embeddings import FluxPosEmbed, get_timestep_embedding
+    from fastdm.layer.qlinear import QLinear
+    g = torch.Generator().manual_seed(4321)
+    d = {}
+    # weight quantisation exactly as QLinear.weight_loading_and_quant does it (qlinear.py:18-54)
+    w_list = [randn_bf16(g, 96, 128, scale=0.1) for _ in range(3)]      # three [out,in] weights fused along N
+    b_list = [randn_bf16(g, 96, scale=0.02) for _ in range(3)]
+    for i in range(3):
+        d[f"w{i}"], d[f"b{i}"] = w_list[i], b_list[i]
+    for tag, qt in (("fp8", torch.float8_e4m3fn), ("int8", torch.int8)):
+        ql = QLinear(128, 288)
+        ql.weight_loading_and_quant([w.transpose(0, 1) for w in w_list], list(b_list), quant_type=qt)
+        d[f"ql_{tag}_w_nk"] = ql.weight.t().contiguous()        # stored [K,N] col-major == [N,K] row-major
+        d[f"ql_{tag}_scale"] = ql.weight_quant_scale
+        d[f"ql_{tag}_bias"] = ql.bias
+        if qt == torch.int8:
+            d["ql_int8_colsum"] = ql.weight_asym_sumcol
+        x = randn_bf16(g, 2, 11, 128)
+        d[f"ql_{tag}_x"] = x
+        if qt == torch.float8_e4m3fn:
+            use_backend("cpu_fp8")
+        d[f"ql_{tag}_y"] = ql.forward(x)
+        use_backend("torch")
+    # RoPE table for a small grid + text tokens, FLUX axes (embeddings.py:527-549, flux.py:425-428)
+    ids = torch.zeros(5 + 6 * 7, 3)
+    ids[5:, 1] = torch.arange(6).repeat_interleave(7).float()
+    ids[5:, 2] = torch.arange(7).repeat(6).float()
+    cos, sin = FluxPosEmbed(theta=10000, axes_dim=[16, 56, 56]).forward(ids)
+    d["rope_ids"] = ids
+    d["rope_cos"], d["rope_sin"] = cos, sin
+    d["rope_cache"] = torch.cat((cos[:, 0::2], sin[:, 1::2]), dim=-1).to(torch.bfloat16)
+    # timestep embedding on the bf16-rounded timestep*1000 (flux.py:399-401)
+    ts = torch.tensor([1.0, 0.75, 0.0361, 3.5]).to(torch.bfloat16) * 1000
+    d["ts_in"] = ts
+    d["ts_emb"] = get_timestep_embedding(ts, 256, flip_sin_to_cos=True, downscale_freq_shift=0)
+    save("layers.npz", d)
+
+
+def ref_flux_core(cfg, quant, sd, cache=None):
+    from fastdm.model.flux import FluxTransformer2DModelCore
+    core = FluxTransformer2DModelCore(
+        in_channels=cfg.in_channels, out_channels=cfg.out_channels, num_layers=cfg.num_layers,
+        num_single_layers=cfg.num_single_layers, attention_head_dim=cfg.attention_head_dim,
+        num_attention_heads=cfg.num_attention_heads, joint_attention_dim=cfg.joint_attention_dim,
+        pooled_projection_dim=cfg.pooled_projection_dim, guidance_embeds=True,
+        axes_dims_rope=cfg.axes_dims_rope, data_type=torch.bfloat16, quant_dtype=quant, cache=cache)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        core.weight_loading(dict(sd), device_type="cpu")
+    return core
+
+
+def gen_tiny_flux():
+    import_reference()
+    from oracle import flux as OF
+    cfg = OF.TINY
+    sd = OF.synth_state_dict(cfg, seed=7)
+    inp = OF.synth_inputs(cfg, batch=2, img_h=4, img_w=6, n_txt=8, seed=7)
+    d = {"seed": 7, "batch": 2, "img_h": 4, "img_w": 6, "n_txt": 8}
+    for tag, qt in (("bf16", None), ("int8", torch.int8), ("fp8", torch.float8_e4m3fn)):
+        use_backend("cpu_fp8" if qt == torch.float8_e4m3fn else "torch")
+        core = ref_flux_core(cfg, qt, sd)
+        for ti, t in enumerate((1.0, 0.75)):
+            out = core.forward(timestep=torch.tensor([t, t]), guidance=torch.tensor([3.5, 3.5]), **inp)[0]
+            d[f"out_{tag}_t{ti}"] = out
+    use_backend("torch")
+    save("tiny_flux.npz", d)
+
+
+def gen_teacache():
+    """TeaCache decision + tensors on the tiny core over a 12-step synthetic trajectory
+    (xcaching.py:187-276 driven exactly as model_entry.py:635-637 does, via a step callback)."""
+    import_reference()
+    use_backend("torch")
+    from fastdm.caching.xcaching import AutoCache
+    from oracle import flux as OF
+    cfg = OF.TINY
+    sd = OF.synth_state_dict(cfg, seed=7)
+    inp = OF.synth_inputs(cfg, batch=1, img_h=4, img_w=6, n_txt=8, seed=9)
+    coeffs = json.load(open(os.path.join(REF, "examples/xcaching/configs/teacache_flux.json")))
+    # the shipped threshold never skips on this tiny random net; a loose one exercises both branches
+    state = {"step": 0}
+    trace = []
+    for thr_tag, thr in (("shipped", coeffs["threshold"]), ("loose", 2.0)):
+        cfgd = dict(coeffs)
+        cfgd["threshold"] = thr
+        cache = AutoCache.from_dict(cfgd)
+        cache.config.current_steps_callback = lambda: state["step"]
+        core = ref_flux_core(cfg, None, sd, cache=cache)
+        lat = inp["hidden_states"].clone()
+        outs, decisions = [], []
+        sig = torch.linspace(1.0, 1.0 / 12, 12)
+        import contextlib
+        import io
+        for i in range(12):
+            state["step"] = i
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                out = core.forward(hidden_states=lat, encoder_hidden_states=inp["encoder_hidden_states"],
+                                   pooled_projections=inp["pooled_projections"], timestep=sig[i:i + 1],
+                                   img_ids=inp["img_ids"], txt_ids=inp["txt_ids"], guidance=torch.tensor([3.5]))[0]
+            decisions.append(0 if "Skipping" in buf.getvalue() else 1)
+            outs.append(out)
+            dt = (sig[i + 1] - sig[i]) if i + 1 < 12 else -sig[i]
+            lat = (lat.float() + dt * out.float()).to(torch.bfloat16)     # flow-match Euler step
+        trace.append((thr_tag, thr, decisions, torch.stack(outs), lat))
+    d = {"seed_w": 7, "seed_in": 9, "coefficients": np.array(coeffs["coefficients"])}
+    for thr_tag, thr, decisions, outs, lat in trace:
+        d[f"{thr_tag}_threshold"] = thr
+        d[f"{thr_tag}_should_calc"] = np.array(decisions, dtype=np.int8)
+        d[f"{thr_tag}_outs"] = outs
+        d[f"{thr_tag}_final"] = lat
+    # decision rule on its own: polynomial rescale of a rel-L1 sequence (np.poly1d, xcaching.py:212-216)
+    rels = np.array([0.0, 0.02, 0.05, 0.11, 0.23, 0.4, 0.31, 0.07, 0.01, 0.6], dtype=np.float64)
+    d["poly_in"] = rels
+    d["poly_out"] = np.poly1d(coeffs["coefficients"])(rels)
+    save("teacache.npz", d)
+
+
+# ------------------------------------------------------------------ full-width C3 fixture
+def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=0, sub=64):
+    """Full-width FLUX.1-dev at 1024x2048 (S = 8192 + 512) through the reference's own block
+    classes, streamed one block at a time so RSS stays small.  The block objects,
+    their weight loading/quantisation and forward are the reference's; only the loop over blocks
+    (flux.py:445-485) is spelled out here so that each block's weights can be freed."""
+    import_reference()
+    from oracle import flux as OF
+    from fastdm.model.flux import FluxTransformer2DModelCore
+    import contextlib
+    import io
+    cfg = OF.FluxConfig(num_layers=n_double, num_single_layers=n_single)
+    inp = OF.synth_inputs(cfg, 1, img_h, img_w, n_txt, seed)
+    t0 = time.time()
+
+    def specs_with_prefix(prefix):
+        full = OF.FluxConfig()
+        return [(n, s, k) for n, s, k in OF.param_specs(full) if n.startswith(prefix)]
+
+    def load_part(core, names_map, loader):
+        sd = {}
+        for name, shape, kind in names_map:
+            sd[name[1]] = OF.synth_tensor(name[0], shape, kind, seed)
+        core.origin_tensor_dict = sd
+        core.unmatched_tensors = list(sd.keys())
+        core.device, core.dtype = "cpu", torch.bfloat16
+        with contextlib.redirect_stdout(io.StringIO()):
+            loader()
+        assert len(core.unmatched_tensors) == 0, core.unmatched_tensors
+        core.origin_tensor_dict = {}
+
+    results = {}
+    for tag in quant_tags:
+        qt = {"bf16": None, "fp8": torch.float8_e4m3fn, "int8": torch.int8}[tag]
+        use_backend("cpu_fp8" if tag == "fp8" else "torch")
+        core = FluxTransformer2DModelCore(num_layers=1, num_single_layers=1, quant_dtype=qt)
+        # pre/post parts (never quantised)
+        pre = [((n, n), s, k) for n, s, k in OF.param_specs(OF.FluxConfig())
+               if n.startswith(("time_text_embed", "context_embedder", "x_embedder"))]
+        post = [((n, n), s, k) for n, s, k in OF.param_specs(OF.FluxConfig()) if n.startswith(("norm_out", "proj_out"))]
+        load_part(core, pre, core._pre_part_loading)
+        load_part(core, post, core._post_part_loading)
+        d = {}
+        with torch.no_grad():
+            hidden = core.x_embedder.forward(inp["hidden_states"])
+            ts = torch.tensor([1.0]).to(hidden.dtype) * 1000
+            gd = torch.tensor([3.5]).to(hidden.dtype) * 1000
+            temb = core.time_text_embed.forward(ts, gd, inp["pooled_projections"])
+            encoder = core.context_embedder.forward(inp["encoder_hidden_states"])
+            ids = torch.cat((inp["txt_ids"], inp["img_ids"]), dim=0)
+            rc, rs = core.pos_embed.forward(ids)
+            rope = torch.cat((rc[:, 0::2], rs[:, 1::2]), dim=-1).to(hidden.dtype)
+            d["temb"] = temb
+            d["hidden_in_sub"] = hidden[:, ::sub].clone()
+            d["encoder_in_sub"] = encoder[:, ::sub].clone()
+            for i in range(n_double):
+                names = [((n, n.replace(f"transformer_blocks.{i}.", "transformer_blocks.0.")), s, k)
+                         for n, s, k in specs_with_prefix(f"transformer_blocks.{i}.")]
+                load_part(core, names, core._FluxTransformer2DModelCore__transformer_block_loading)
+                encoder, hidden = core.transformer_blocks[0].forward(
+                    hidden_states=hidden, encoder_hidden_states=encoder, temb=temb, image_rotary_emb=rope)
+                print(f"[{tag}] double {i} done  t={time.time() - t0:.0f}s  |h|={hidden.float().abs().mean():.4f}", flush=True)
+                if i in (0, n_double - 1):
+                    d[f"hidden_d{i}_sub"] = hidden[:, ::sub].clone()
+                    d[f"encoder_d{i}_sub"] = encoder[:, ::sub].clone()
+            x = torch.cat([encoder, hidden], dim=1)
+            for i in range(n_single):
+                names = [((n, n.replace(f"single_transformer_blocks.{i}.", "single_transformer_blocks.0.")), s, k)
+                         for n, s, k in specs_with_prefix(f"single_transformer_blocks.{i}.")]
+                load_part(core, names, core._FluxTransformer2DModelCore__single_trans_block_loading)
+                x = core.single_transformer_blocks[0].forward(hidden_states=x, temb=temb, image_rotary_emb=rope)
+                print(f"[{tag}] single {i} done  t={time.time() - t0:.0f}s  |x|={x.float().abs().mean():.4f}", flush=True)
+                if i in (0, n_single - 1):
+                    d[f"x_s{i}_sub"] = x[:, ::sub].clone()
+            hidden = x[:, n_txt:]
+            hidden = core.norm_out.forward(hidden, temb)
+            out = core.proj_out.forward(hidden)
+            d["out"] = out
+        results[tag] = d
+        meta = {"seed": seed, "img_h": img_h, "img_w": img_w, "n_txt": n_txt, "sub": sub, "n_double": n_double,
+                "n_single": n_single, "timestep": 1.0, "guidance": 3.5}
+        d.update({f"meta_{k}": v for k, v in meta.items()})
+        save(f"flux_c3_{tag}_{n_double}x{n_single}.npz", d)
+    use_backend("torch")
+    return results
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "c3"])
+    ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
+    ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
+    args = ap.parse_args()
+    torch.set_grad_enabled(False)
+    if args.what in ("small", "ops"):
+        gen_ops()
+    if args.what in ("small", "layers"):
+        gen_layers()
+    if args.what in ("small", "tiny"):
+        gen_tiny_flux()
+    if args.what in ("small", "teacache"):
+        gen_teacache()
+    if args.what == "c3":
+        gen_c3(args.blocks[0], args.blocks[1], args.quant)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+"""The oracle (CPU restatement) against vectors produced by the reference itself
+(tests/golden/*.npz, written by oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops, layers as L, flux as OF, teacache as TC
+from oracle.make_golden import load
+
+
+def same(a, b):
+    assert a.dtype == b.dtype and a.shape == b.shape
+    if a.dtype in (torch.float8_e4m3fn,):
+        a, b = a.view(torch.uint8), b.view(torch.uint8)
+    assert torch.equal(a, b), f"max|d|={(a.float() - b.float()).abs().max().item()}"
+
+
+@pytest.mark.parametrize("tag", ["rms4d", "rms3d", "rms64"])
+def test_rms_norm_bit_exact(ops_golden, tag):
+    g = ops_golden
+    same(ops.rms_norm(g[f"{tag}_x"], g[f"{tag}_w"], 1e-6), g[f"{tag}_out"])
+
+
+@pytest.mark.parametrize("tag,hd,neox", [("ropej", 64, False), ("ropej128", 128, False), ("ropen", 64, True)])
+def test_rope_bit_exact(ops_golden, tag, hd, neox):
+    g = ops_golden
+    q, k = g[f"{tag}_q"].clone(), g[f"{tag}_k"].clone()
+    assert ops.rotary_pos_embedding(q, k, hd, g[f"{tag}_cache"], is_neox=neox) is None
+    same(q, g[f"{tag}_qout"])
+    same(k, g[f"{tag}_kout"])
+
+
+def test_quant_fp8_bit_exact(ops_golden):
+    g = ops_golden
+    q, s = ops.quantize_to_fp8(g["quant_x"])
+    same(q, g["quant_fp8_q"])
+    same(s, g["quant_fp8_s"])
+
+
+def test_quant_int8_bit_exact(ops_golden):
+    g = ops_golden
+    q, s, zp = ops.quantize_to_int8(g["quant_xi"], symmetric=False)
+    same(q, g["quant_i8a_q"]); same(s, g["quant_i8a_s"]); same(zp, g["quant_i8a_zp"])
+    q, s, zp = ops.quantize_to_int8(g["quant_xi"], symmetric=True)
+    assert zp is None
+    same(q, g["quant_i8s_q"]); same(s, g["quant_i8s_s"])
+
+
+@pytest.mark.parametrize("tag", ["mm14", "mm130"])
+def test_int8_matmul(ops_golden, tag):
+    g = ops_golden
+    args = (g[f"{tag}_i8_a"], g[f"{tag}_i8_b"], g[f"{tag}_sa"], g[f"{tag}_sb"], torch.bfloat16, g[f"{tag}_adj"], g[f"{tag}_azp"])
+    # the reference accumulates the int8 products in fp32 (torch/matrixmul.py:67); exact integer
+    # accumulation can differ from it by an fp32 rounding of the accumulator -> <= 1 bf16 ulp
+    for out, bias in ((g[f"{tag}_i8_out"], None), (g[f"{tag}_i8_out_bias"], g[f"{tag}_bias"])):
+        got = ops.int8_matmul(*args, bias)
+        torch.testing.assert_close(got, out, rtol=2 ** -7, atol=1e-5)
+        assert (got != out).float().mean() < 0.02
+
+
+@pytest.mark.parametrize("tag", ["mm14", "mm130"])
+def test_fp8_matmul_bit_exact(ops_golden, tag):
+    g = ops_golden
+    for out, bias in ((g[f"{tag}_f8_out"], None), (g[f"{tag}_f8_out_bias"], g[f"{tag}_bias"])):
+        same(ops.fp8_matmul(g[f"{tag}_f8_a"], g[f"{tag}_f8_b"], g[f"{tag}_sa"], g[f"{tag}_sb"], torch.bfloat16, bias), out)
+
+
+@pytest.mark.parametrize("tag,H,hd", [("att128", 3, 128), ("att64", 2, 64), ("attx64", 2, 64)])
+def test_attention_within_reference_tolerance(ops_golden, tag, H, hd):
+    g = ops_golden
+    got = ops.scaled_dot_product_attention(g[f"{tag}_q"], g[f"{tag}_k"], g[f"{tag}_v"], H, H, hd, scale=hd ** -0.5)
+    # /root/reference/tests/test_attention.py:94: atol 1.8e-2, rtol 0 (third-party SDPA arithmetic)
+    torch.testing.assert_close(got, g[f"{tag}_out"], rtol=0.0, atol=1.8e-2)
+    assert (got.float() - g[f"{tag}_out"].float()).abs().mean() < 1e-3
+
+
+def test_gelu_and_mul_bit_exact(ops_golden):
+    same(ops.gelu_and_mul(ops_golden["gm_x"]), ops_golden["gm_out"])
+
+
+def test_block_sparse_all_ones_equals_dense(ops_golden):
+    g = ops_golden
+    q, k, v = g["att128_q"], g["att128_k"], g["att128_v"]
+    mask = torch.ones(1, 3, 2, 4, dtype=torch.int8)
+    a = ops.scaled_dot_product_attention(q, k, v, 3, 3, 128, scale=128 ** -0.5, block_mask=mask)
+    b = ops.scaled_dot_product_attention(q, k, v, 3, 3, 128, scale=128 ** -0.5)
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ layers
+@pytest.mark.parametrize("tag,qt", [("fp8", torch.float8_e4m3fn), ("int8", torch.int8)])
+def test_qlinear_weight_quant_and_forward(layers_golden, tag, qt):
+    g = layers_golden
+    ql = L.QLinear([g[f"w{i}"] for i in range(3)], [g[f"b{i}"] for i in range(3)], qt)
+    same(ql.w_kn.t().contiguous(), g[f"ql_{tag}_w_nk"])
+    same(ql.w_scale, g[f"ql_{tag}_scale"])
+    same(ql.bias, g[f"ql_{tag}_bias"])
+    if qt == torch.int8:
+        same(ql.colsum, g["ql_int8_colsum"])
+        torch.testing.assert_close(ql(g[f"ql_{tag}_x"]), g[f"ql_{tag}_y"], rtol=2 ** -7, atol=1e-5)
+    else:
+        same(ql(g[f"ql_{tag}_x"]), g[f"ql_{tag}_y"])
+
+
+def test_rope_table_and_timestep_embedding(layers_golden):
+    g = layers_golden
+    cos, sin = L.flux_pos_embed(g["rope_ids"])
+    same(cos, g["rope_cos"]); same(sin, g["rope_sin"])
+    same(L.flux_rope_cache(g["rope_ids"][:5], g["rope_ids"][5:]), g["rope_cache"])
+    same(L.timestep_embedding(g["ts_in"]), g["ts_emb"])
+    # bf16 'timestep*1000' is systematic, not noise (SURVEY §8c'): 0.75 -> 752, 3.5 -> 3504
+    assert g["ts_in"].tolist() == [1000.0, 752.0, 36.25, 3504.0]
+
+
+# ------------------------------------------------------------------ tiny FLUX core
+@pytest.mark.parametrize("tag,qt", [("bf16", None), ("int8", torch.int8), ("fp8", torch.float8_e4m3fn)])
+def test_tiny_flux_core(tag, qt):
+    g = load("tiny_flux.npz")
+    cfg = OF.TINY
+    sd = OF.synth_state_dict(cfg, seed=int(g["seed"]))
+    inp = OF.synth_inputs(cfg, int(g["batch"]), int(g["img_h"]), int(g["img_w"]), int(g["n_txt"]), seed=int(g["seed"]))
+    core = OF.FluxCore(sd, cfg, qt)
+    for ti, t in enumerate((1.0, 0.75)):
+        out = core.forward(timestep=torch.tensor([t, t]), guidance=torch.tensor([3.5, 3.5]), **inp)[0]
+        ref = g[f"out_{tag}_t{ti}"]
+        err = (out.float() - ref.float()).abs()
+        # attention is the only non-bit-pinned op (torch SDPA vs fp32-softmax restatement)
+        assert err.max() < 3e-2 and err.mean() < 2e-3, (err.max().item(), err.mean().item())
+
+
+# ------------------------------------------------------------------ TeaCache
+def test_teacache_poly_and_trace():
+    g = load("teacache.npz")
+    coeffs = g["coefficients"].tolist()
+    assert coeffs == TC.FLUX_COEFFICIENTS
+    got = np.array([TC.poly(coeffs, float(x)) for x in g["poly_in"]])
+    np.testing.assert_allclose(got, g["poly_out"].numpy(), rtol=1e-12)
+    cfg = OF.TINY
+    sd = OF.synth_state_dict(cfg, seed=int(g["seed_w"]))
+    inp = OF.synth_inputs(cfg, 1, 4, 6, 8, seed=int(g["seed_in"]))
+    for tag in ("shipped", "loose"):
+        state = {"step": 0}
+        cache = TC.TeaCache(TC.TeaCacheConfig(threshold=float(g[f"{tag}_threshold"]), current_steps_callback=lambda: state["step"]))
+        core = OF.FluxCore(sd, cfg, None, cache=cache)
+        lat = inp["hidden_states"].clone()
+        sig = torch.linspace(1.0, 1.0 / 12, 12)
+        for i in range(12):
+            state["step"] = i
+            out = core.forward(hidden_states=lat, encoder_hidden_states=inp["encoder_hidden_states"],
+                               pooled_projections=inp["pooled_projections"], timestep=sig[i:i + 1],
+                               img_ids=inp["img_ids"], txt_ids=inp["txt_ids"], guidance=torch.tensor([3.5]))[0]
+            dt = (sig[i + 1] - sig[i]) if i + 1 < 12 else -sig[i]
+            lat = (lat.float() + dt * out.float()).to(torch.bfloat16)
+        decisions = [int(t[3]) for t in cache.trace]
+        assert decisions == g[f"{tag}_should_calc"].tolist(), (tag, decisions)
+        err = (lat.float() - g[f"{tag}_final"].float()).abs()
+        assert err.max() < 5e-2, err.max()
+    assert 0 in g["loose_should_calc"].tolist() and 1 in g["loose_should_calc"].tolist()[1:]
