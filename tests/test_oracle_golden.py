@@ -125,7 +125,7 @@ def test_tiny_flux_core(tag, qt):
         ref = g[f"out_{tag}_t{ti}"]
         err = (out.float() - ref.float()).abs()
         # attention is the only non-bit-pinned op (torch SDPA vs fp32-softmax restatement)
-        assert err.max() < 3e-2 and err.mean() < 2e-3, (err.max().item(), err.mean().item())
+        assert err.max() < 3e-2 and err.mean() < 4e-3, (err.max().item(), err.mean().item())
 
 
 # ------------------------------------------------------------------ TeaCache
