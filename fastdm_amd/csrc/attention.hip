@@ -1,0 +1,327 @@
+// Dense / block-sparse flash-attention forward for gfx950 (bf16, head_dim 64 or 128, non-causal).
+//
+//   block     512 threads = 8 waves; one 256-row Q block of one (batch, head); wave w owns rows
+//             [32w, 32w+32).  KV tile = 64 keys, K and V staged global -> VGPR -> LDS (split
+//             issue-early / write-late), double buffered: 2 x (K + V) = 64 KiB at D = 128.
+//   QK^T      swapped: S^T[key][q] = K . Q^T on v_mfma_f32_32x32x16_bf16, so lane (q = lane&31,
+//             h = lane>>5) holds 16 of each 32 keys of ITS query row: row max / sum are in-lane plus
+//             one cross-half exchange (lane ^ 32).
+//   PV        O^T[d][q] += V^T[d][key] . P^T[key][q].  The S^T accumulator, converted pairwise to
+//             bf16, IS the B operand (no lane movement); the matching (permuted-k) A operand comes
+//             from the row-major V tile with ds_read_b64_tr_b16 (hardware transpose).
+//   LDS       K rows: chunk c of key r at slot c ^ (r & 15) (D=128) -> conflict-free ds_read_b128;
+//             V rows: chunk c of key r at slot c ^ ((r & 3) << 2)  -> conflict-free transposed reads.
+//   softmax   fp32 running max / sum in the exp2 domain (scale * log2 e folded into one FMA).
+//   grid      block id -> (xcd = id % 8): every q-block of a (batch, head) runs on one XCD so that
+//             K/V (4.4 MB per head at S = 8704) is fetched from HBM once and re-read from that L2.
+//   mask      optional int8 block mask [B, H, ceil(Sq/bq), ceil(Sk/bk)] (1 = compute): tiles masked
+//             for both 128-row halves of the Q block are skipped entirely (no loads, no barrier).
+#include "common.h"
+
+namespace fdm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ATT_THREADS = 512;
+constexpr int QB = 256;  // query rows per block
+constexpr int KT = 64;   // keys per tile
+
+struct AttnParams {
+  bf16_t* o;
+  const bf16_t* q;
+  const bf16_t* k;
+  const bf16_t* v;
+  const int8_t* mask;
+  int64_t sq, sk;
+  int64_t q_ts, k_ts, v_ts, o_ts;  // token strides (elements)
+  int batch, heads, kv_heads;
+  int n_qblocks;
+  int mask_bq, mask_bk, mask_nq, mask_nk;
+  float scale_log2e;
+};
+
+template <int D>
+struct Swz {
+  static constexpr int CPR = D / 8;  // 16-byte chunks per row
+  // K image: conflict-free ds_read_b128 for 16-lane groups of distinct rows
+  static __device__ __forceinline__ int k(int row, int ch) {
+    if constexpr (D == 128) return ch ^ (row & 15);
+    else return ch ^ ((row >> 1) & 7);
+  }
+  // V image: conflict-free ds_read_b64_tr_b16 (4 consecutive keys x 64 B per 32-lane half)
+  static __device__ __forceinline__ int v(int row, int ch) {
+    if constexpr (D == 128) return ch ^ ((row & 3) << 2);
+    else return ch ^ (((row >> 1) & 1) << 2);
+  }
+};
+
+__device__ __forceinline__ i32x4 tr_pair(const uint8_t* p0, const uint8_t* p1) {
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  i32x2 lo = __builtin_bit_cast(i32x2, a), hi = __builtin_bit_cast(i32x2, b);
+  i32x4 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+  return r;
+}
+
+template <int D>
+__global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnParams p) {
+  constexpr int CPR = D / 8;
+  constexpr int TILE_BYTES = KT * D * 2;               // one K or V tile
+  constexpr int LD_PER_THREAD = KT * CPR / ATT_THREADS;  // 16-B chunks per thread per tile (2 @128, 1 @64)
+  constexpr int KSTEPS = D / 16;                        // QK^T k-steps
+  constexpr int DT = D / 32;                            // 32-wide d tiles of O^T
+  __shared__ __attribute__((aligned(1024))) uint8_t smem[4 * TILE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 31, h = lane >> 5;
+
+  // ---- block id -> (batch*head, q block), heads pinned to XCDs
+  const int BH = p.batch * p.heads;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int bh = xcd + 8 * (j / p.n_qblocks);
+  if (bh >= BH) return;
+  const int qb = j % p.n_qblocks;
+  const int b = bh / p.heads, head = bh % p.heads;
+  const int kvh = head / (p.heads / p.kv_heads);
+  const int64_t q0 = (int64_t)qb * QB;
+
+  const bf16_t* qbase = p.q + ((int64_t)b * p.sq) * p.q_ts + (int64_t)head * D;
+  const bf16_t* kbase = p.k + ((int64_t)b * p.sk) * p.k_ts + (int64_t)kvh * D;
+  const bf16_t* vbase = p.v + ((int64_t)b * p.sk) * p.v_ts + (int64_t)kvh * D;
+
+  // ---- Q fragments: B operand of the swapped QK^T: lane holds Q[q][16*ks + 8*h .. +8]
+  i32x4 qf[KSTEPS];
+  {
+    int64_t qrow = q0 + wave * 32 + lq;
+    if (qrow > p.sq - 1) qrow = p.sq - 1;
+    const bf16_t* qp = qbase + qrow * p.q_ts + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *reinterpret_cast<const i32x4*>(qp + 16 * ks);
+  }
+
+  // ---- mask bookkeeping (wave-uniform)
+  const int ntiles = (int)((p.sk + KT - 1) / KT);
+  const int8_t* mrow0 = nullptr;
+  const int8_t* mrow1 = nullptr;
+  const int8_t* mrow_w = nullptr;
+  if (p.mask != nullptr) {
+    const int64_t mb = ((int64_t)b * p.heads + head) * p.mask_nq;
+    int r0 = (int)(q0 / p.mask_bq), r1 = (int)((q0 + 128) / p.mask_bq);
+    if (r1 > p.mask_nq - 1) r1 = p.mask_nq - 1;
+    mrow0 = p.mask + (mb + r0) * p.mask_nk;
+    mrow1 = p.mask + (mb + r1) * p.mask_nk;
+    mrow_w = (wave < 4) ? mrow0 : mrow1;
+  }
+  auto tile_active = [&](int t) -> bool {
+    if (p.mask == nullptr) return true;
+    const int kb = (t * KT) / p.mask_bk;
+    return (mrow0[kb] | mrow1[kb]) != 0;
+  };
+  auto next_active = [&](int t) -> int {
+    while (t < ntiles && !tile_active(t)) ++t;
+    return t;
+  };
+
+  // ---- staging registers
+  i32x4 kreg[LD_PER_THREAD], vreg[LD_PER_THREAD];
+  auto issue_loads = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < LD_PER_THREAD; ++i) {
+      const int c = tid + i * ATT_THREADS;  // chunk id within the tile
+      const int row = c / CPR, ch = c % CPR;
+      int64_t key = (int64_t)t * KT + row;
+      if (key > p.sk - 1) key = p.sk - 1;
+      kreg[i] = *reinterpret_cast<const i32x4*>(kbase + key * p.k_ts + ch * 8);
+      vreg[i] = *reinterpret_cast<const i32x4*>(vbase + key * p.v_ts + ch * 8);
+    }
+  };
+  auto write_lds = [&](int buf) {
+    uint8_t* sk_ = smem + buf * 2 * TILE_BYTES;
+    uint8_t* sv_ = sk_ + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < LD_PER_THREAD; ++i) {
+      const int c = tid + i * ATT_THREADS;
+      const int row = c / CPR, ch = c % CPR;
+      *reinterpret_cast<i32x4*>(sk_ + row * (D * 2) + Swz<D>::k(row, ch) * 16) = kreg[i];
+      *reinterpret_cast<i32x4*>(sv_ + row * (D * 2) + Swz<D>::v(row, ch) * 16) = vreg[i];
+    }
+  };
+
+  // ---- accumulators
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  // tr-read lane geometry (see header): 16-lane group gi, lane-in-group li = 4*tq + tp
+  const int gi = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+
+  int t = next_active(0);
+  int cur = 0;
+  if (t < ntiles) {
+    issue_loads(t);
+    write_lds(0);
+  }
+  __syncthreads();
+
+  while (t < ntiles) {
+    const int tn = next_active(t + 1);
+    if (tn < ntiles) issue_loads(tn);
+
+    bool active = true;
+    if (p.mask != nullptr) active = mrow_w[(t * KT) / p.mask_bk] != 0;
+    if (active) {
+      const uint8_t* sk_ = smem + cur * 2 * TILE_BYTES;
+      const uint8_t* sv_ = sk_ + TILE_BYTES;
+      // ---- S^T = K . Q^T  (two 32-key tiles)
+      f32x16 sacc[2];
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[kt2][e] = 0.f;
+        const int row = kt2 * 32 + lq;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          i32x4 kf = *reinterpret_cast<const i32x4*>(sk_ + row * (D * 2) + Swz<D>::k(row, 2 * ks + h) * 16);
+          sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]),
+                                                              sacc[kt2], 0, 0, 0);
+        }
+      }
+      // ---- mask the key tail (keys >= sk)
+      const int64_t key0 = (int64_t)t * KT;
+      if (key0 + KT > p.sk) {
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t key = key0 + kt2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (key >= p.sk) sacc[kt2][e] = -INFINITY;
+          }
+      }
+      // ---- online softmax (exp2 domain)
+      float mx = sacc[0][0];
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt2][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx * p.scale_log2e);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.f;
+      i32x4 pf[2][2];
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt2][e], p.scale_log2e, -m_new));
+          sacc[kt2][e] = pv;
+          psum += pv;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int w2 = 0; w2 < 4; ++w2)
+            pf[kt2][s][w2] = (int)pack2bf(sacc[kt2][8 * s + 2 * w2], sacc[kt2][8 * s + 2 * w2 + 1]);
+      }
+      l_run = l_run * alpha + psum;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+      // ---- O^T += V^T . P^T
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int krow = kt2 * 32 + 16 * s + 4 * h + tq;  // first of the two 4-key groups (second = +8)
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            const int ch = d * 4 + 2 * (gi & 1) + (tp >> 1);
+            const uint8_t* a0 = sv_ + krow * (D * 2) + Swz<D>::v(krow, ch) * 16 + 8 * (tp & 1);
+            const uint8_t* a1 = a0 + 8 * (D * 2);  // key + 8: same (key & 3) and ((key>>1)&1)
+            i32x4 vf = tr_pair(a0, a1);
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[kt2][s]),
+                                                              oacc[d], 0, 0, 0);
+          }
+        }
+    }
+    if (tn < ntiles) write_lds(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+    t = tn;
+  }
+
+  // ---- finalize: l = own half + other half; O = O^T / l
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  const int64_t qrow = q0 + wave * 32 + lq;
+  if (qrow < p.sq) {
+    bf16_t* op = p.o + ((int64_t)b * p.sq + qrow) * p.o_ts + (int64_t)head * D;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        // registers 4*g4 .. 4*g4+3 hold d = 32*d + 8*g4 + 4*h + (0..3): 8 contiguous bytes
+        i32x2 w;
+        w[0] = (int)pack2bf(oacc[d][4 * g4] * inv, oacc[d][4 * g4 + 1] * inv);
+        w[1] = (int)pack2bf(oacc[d][4 * g4 + 2] * inv, oacc[d][4 * g4 + 3] * inv);
+        *reinterpret_cast<i32x2*>(op + 32 * d + 8 * g4 + 4 * h) = w;
+      }
+  }
+}
+
+}  // namespace fdm
+
+using namespace fdm;
+
+extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v, int64_t batch, int64_t sq, int64_t sk,
+                            int q_heads, int kv_heads, int head_dim, int64_t q_tok_stride, int64_t k_tok_stride,
+                            int64_t v_tok_stride, int64_t o_tok_stride, float scale, const int8_t* block_mask, int block_q,
+                            int block_k, fdm_stream_t stream) {
+  if (!o || !q || !k || !v || batch <= 0 || sq <= 0 || sk <= 0 || q_heads <= 0 || kv_heads <= 0 || q_heads % kv_heads)
+    return FDM_ERR_INVALID;
+  if (head_dim != 64 && head_dim != 128) return FDM_ERR_UNSUPPORTED;
+  if ((q_tok_stride & 7) || (k_tok_stride & 7) || (v_tok_stride & 7) || (o_tok_stride & 3)) return FDM_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(q) & 15) || (reinterpret_cast<uintptr_t>(k) & 15) || (reinterpret_cast<uintptr_t>(v) & 15) ||
+      (reinterpret_cast<uintptr_t>(o) & 7))
+    return FDM_ERR_INVALID;
+  AttnParams p;
+  p.o = (bf16_t*)o;
+  p.q = (const bf16_t*)q;
+  p.k = (const bf16_t*)k;
+  p.v = (const bf16_t*)v;
+  p.mask = block_mask;
+  p.sq = sq;
+  p.sk = sk;
+  p.q_ts = q_tok_stride;
+  p.k_ts = k_tok_stride;
+  p.v_ts = v_tok_stride;
+  p.o_ts = o_tok_stride;
+  p.batch = (int)batch;
+  p.heads = q_heads;
+  p.kv_heads = kv_heads;
+  p.n_qblocks = (int)((sq + QB - 1) / QB);
+  p.mask_bq = p.mask_bk = 1;
+  p.mask_nq = p.mask_nk = 0;
+  if (block_mask != nullptr) {
+    if (block_q <= 0 || block_k <= 0 || block_q % 128 || block_k % 64) return FDM_ERR_UNSUPPORTED;
+    p.mask_bq = block_q;
+    p.mask_bk = block_k;
+    p.mask_nq = (int)((sq + block_q - 1) / block_q);
+    p.mask_nk = (int)((sk + block_k - 1) / block_k);
+  }
+  p.scale_log2e = scale * 1.4426950408889634f;
+  const int64_t bh = batch * q_heads;
+  const int64_t grid = 8 * ((bh + 7) / 8) * p.n_qblocks;
+  hipStream_t s = to_stream(stream);
+  if (head_dim == 128) attn_fwd_kernel<128><<<(unsigned)grid, ATT_THREADS, 0, s>>>(p);
+  else attn_fwd_kernel<64><<<(unsigned)grid, ATT_THREADS, 0, s>>>(p);
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}

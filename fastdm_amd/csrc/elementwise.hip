@@ -1,0 +1,744 @@
+// HBM-bound row / element-wise kernels of the denoise step (bf16 I/O, fp32 math).
+// Every kernel streams 16-byte vectors per lane; rows are owned by one wave (hidden <= 4096) or
+// one 256-thread block, and a row's values stay in registers between the statistics pass and the
+// output pass so each byte is read from HBM once.
+#include "common.h"
+
+namespace fdm {
+
+bool g_fp8_sw_cvt = false;
+
+constexpr int MAXV = 8;  // 16-byte vectors held per thread
+
+// Load this thread's slice of a row: vectors t, t+THREADS, ...  (nvec = hidden/8)
+template <int THREADS>
+__device__ __forceinline__ void load_row(Vec8 (&x)[MAXV], const bf16_t* row, int nvec) {
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int v = threadIdx.x % THREADS + i * THREADS;
+    if (v < nvec) x[i] = load8(row + (size_t)v * 8);
+  }
+}
+
+// ------------------------------------------------------------------------------------ rms_norm
+// Small hidden (<= 512): LPR lanes per row, several rows per wave.
+template <int LPR>
+__global__ void __launch_bounds__(256) rms_norm_small_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ in,
+                                                             const bf16_t* __restrict__ w, float eps, int64_t rows,
+                                                             int hidden) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t row = wave * RPW + lane / LPR;
+  const int sub = lane % LPR;
+  const bool ok = row < rows;
+  Vec8 x;
+  if (ok) x = load8(in + row * hidden + sub * 8);
+  float ss = 0.f;
+  if (ok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += x.v[j] * x.v[j];
+  }
+#pragma unroll
+  for (int off = LPR / 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  if (!ok) return;
+  const float rs = rsqrtf(ss / (float)hidden + eps);
+  Vec8 wv = load8(w + sub * 8), o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o.v[j] = rbf(x.v[j] * rs) * wv.v[j];
+  store8(out + row * hidden + sub * 8, o);
+}
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) rms_norm_row_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ in,
+                                                               const bf16_t* __restrict__ w, float eps, int hidden) {
+  __shared__ float smem[THREADS / 64];
+  const int64_t row = blockIdx.x;
+  const int nvec = hidden >> 3;
+  const bf16_t* src = in + row * hidden;
+  Vec8 x[MAXV];
+  float ss = 0.f;
+  const bool cached = nvec <= MAXV * THREADS;
+  if (cached) {
+    load_row<THREADS>(x, src, nvec);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if ((int)threadIdx.x + i * THREADS < nvec)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += x[i].v[j] * x[i].v[j];
+  } else {
+    for (int v = threadIdx.x; v < nvec; v += THREADS) {
+      Vec8 t = load8(src + (size_t)v * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += t.v[j] * t.v[j];
+    }
+  }
+  ss = block_reduce<THREADS>(ss, OpSum(), smem);
+  const float rs = rsqrtf(ss / (float)hidden + eps);
+  bf16_t* dst = out + row * hidden;
+  if (cached) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      int v = threadIdx.x + i * THREADS;
+      if (v < nvec) {
+        Vec8 wv = load8(w + (size_t)v * 8), o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = rbf(x[i].v[j] * rs) * wv.v[j];
+        store8(dst + (size_t)v * 8, o);
+      }
+    }
+  } else {
+    for (int v = threadIdx.x; v < nvec; v += THREADS) {
+      Vec8 t = load8(src + (size_t)v * 8), wv = load8(w + (size_t)v * 8), o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = rbf(t.v[j] * rs) * wv.v[j];
+      store8(dst + (size_t)v * 8, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ rope
+// One thread per 8 consecutive elements (4 pairs GPT-J / 8 lows or highs NeoX) of q or k.
+template <bool NEOX>
+__global__ void __launch_bounds__(256) rope_kernel(bf16_t* __restrict__ q, bf16_t* __restrict__ k,
+                                                   const bf16_t* __restrict__ cache, int64_t tokens, int64_t seq_len,
+                                                   int q_heads, int k_heads, int head_size, int rot_dim,
+                                                   int64_t q_stride, int64_t k_stride) {
+  const int half = rot_dim >> 1;
+  // work items per token: NEOX: (heads * half/8) items each touching 8 lows + 8 highs; GPT-J: heads*rot_dim/8
+  const int per_head = NEOX ? (half >> 3) : (rot_dim >> 3);
+  const int per_tok = (q_heads + k_heads) * per_head;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= tokens * per_tok) return;
+  const int64_t tok = gid / per_tok;
+  int it = (int)(gid - tok * per_tok);
+  bf16_t* base;
+  if (it < q_heads * per_head) {
+    base = q + tok * q_stride;
+  } else {
+    it -= q_heads * per_head;
+    base = k + tok * k_stride;
+  }
+  const int head = it / per_head, c = it % per_head;
+  const bf16_t* crow = cache + (tok % seq_len) * rot_dim;
+  bf16_t* p = base + (size_t)head * head_size;
+  if constexpr (NEOX) {
+    Vec8 lo = load8(p + c * 8), hi = load8(p + half + c * 8);
+    Vec8 cs = load8(crow + c * 8), sn = load8(crow + half + c * 8), olo, ohi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      olo.v[j] = rbf(lo.v[j] * cs.v[j]) - rbf(hi.v[j] * sn.v[j]);
+      ohi.v[j] = rbf(hi.v[j] * cs.v[j]) + rbf(lo.v[j] * sn.v[j]);
+    }
+    store8(p + c * 8, olo);
+    store8(p + half + c * 8, ohi);
+  } else {
+    Vec8 x = load8(p + c * 8), o;
+    const i32x2 cr = *reinterpret_cast<const i32x2*>(crow + c * 4);
+    const i32x2 sr = *reinterpret_cast<const i32x2*>(crow + half + c * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t cw = (uint32_t)cr[j >> 1], sw = (uint32_t)sr[j >> 1];
+      float cs = (j & 1) ? __builtin_bit_cast(float, cw & 0xffff0000u) : __builtin_bit_cast(float, cw << 16);
+      float sn = (j & 1) ? __builtin_bit_cast(float, sw & 0xffff0000u) : __builtin_bit_cast(float, sw << 16);
+      float a = x.v[2 * j], b = x.v[2 * j + 1];
+      o.v[2 * j] = rbf(a * cs) - rbf(b * sn);
+      o.v[2 * j + 1] = rbf(b * cs) + rbf(a * sn);
+    }
+    store8(p + c * 8, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------ row quant
+// Shared body: given this thread's cached row slice x[], emit fp8 / int8 bytes + per-row params.
+// MODE 1: fp8 (torch/quantize.py:58-67)   MODE 2: int8 asymmetric (:36-41)   MODE 3: int8 symmetric (:31-35)
+template <int THREADS, int MODE, bool SW>
+__device__ __forceinline__ void quant_row_cached(const Vec8 (&x)[MAXV], int nvec, uint8_t* qdst, float* scale_out,
+                                                 int32_t* azp_out, int64_t row, float* smem) {
+  float amax = 0.f, mn = 3.0e38f, mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if ((int)(threadIdx.x % THREADS) + i * THREADS < nvec) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        amax = fmaxf(amax, fabsf(x[i].v[j]));
+        mn = fminf(mn, x[i].v[j]);
+        mx = fmaxf(mx, x[i].v[j]);
+      }
+    }
+  float scale, zpf = 0.f;
+  if constexpr (MODE == 1) {
+    amax = block_reduce<THREADS>(amax, OpMax(), smem);
+    amax = fmaxf(amax, 9.9920072216264089e-13f);  // bf16(1e-12): the clamp runs on the bf16 tensor
+    scale = amax / 448.0f;
+  } else if constexpr (MODE == 3) {
+    amax = block_reduce<THREADS>(amax, OpMax(), smem);
+    scale = amax / 127.0f;
+  } else {
+    mn = block_reduce<THREADS>(mn, OpMin(), smem);
+    mx = block_reduce<THREADS>(mx, OpMax(), smem);
+    scale = (mx - mn) / 255.0f;
+    zpf = -128.0f - __builtin_rintf(mn / scale);
+  }
+  if (threadIdx.x % THREADS == 0) {
+    scale_out[row] = scale;
+    if constexpr (MODE == 2) azp_out[row] = (int32_t)zpf;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int v = (int)(threadIdx.x % THREADS) + i * THREADS;
+    if (v < nvec) {
+      uint32_t w[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          float a = x[i].v[h * 4 + j], b = x[i].v[h * 4 + j + 1];
+          uint32_t two;
+          if constexpr (MODE == 1) {
+            two = cvt2_e4m3<SW>(clamp448(a / scale), clamp448(b / scale));
+          } else {
+            float ra = __builtin_rintf(a / scale + zpf), rb = __builtin_rintf(b / scale + zpf);
+            int ia = (int)fmaxf(-128.f, fminf(ra, 127.f)), ib = (int)fmaxf(-128.f, fminf(rb, 127.f));
+            two = ((uint32_t)ia & 0xffu) | (((uint32_t)ib & 0xffu) << 8);
+          }
+          acc |= two << (8 * j);
+        }
+        w[h] = acc;
+      }
+      i32x2 o;
+      o[0] = (int)w[0];
+      o[1] = (int)w[1];
+      *reinterpret_cast<i32x2*>(qdst + (size_t)v * 8) = o;
+    }
+  }
+}
+
+// Virtual concatenation of two sources so proj_out's K=15360 row never exists in bf16.
+template <int THREADS, int MODE, bool SW>
+__global__ void __launch_bounds__(THREADS) quant_rowwise_kernel(uint8_t* __restrict__ q, float* __restrict__ scale,
+                                                                int32_t* __restrict__ azp,
+                                                                const bf16_t* __restrict__ s0, int w0, int64_t st0,
+                                                                const bf16_t* __restrict__ s1, int w1, int64_t st1) {
+  __shared__ float smem[THREADS / 64 + 1];
+  const int64_t row = blockIdx.x;
+  const int nv0 = w0 >> 3, nvec = (w0 + w1) >> 3;
+  Vec8 x[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int v = threadIdx.x + i * THREADS;
+    if (v < nvec) x[i] = (v < nv0) ? load8(s0 + row * st0 + (size_t)v * 8) : load8(s1 + row * st1 + (size_t)(v - nv0) * 8);
+  }
+  quant_row_cached<THREADS, MODE, SW>(x, nvec, q + row * (int64_t)(w0 + w1), scale, azp, row, smem);
+}
+
+// Fallback for very wide rows (> MAXV*256*8 = 16384 elements): two passes, second read from L2.
+template <int MODE, bool SW>
+__global__ void __launch_bounds__(256) quant_rowwise_wide_kernel(uint8_t* __restrict__ q, float* __restrict__ scale,
+                                                                 int32_t* __restrict__ azp, const bf16_t* __restrict__ in,
+                                                                 int hidden, int64_t stride) {
+  __shared__ float smem[5];
+  const int64_t row = blockIdx.x;
+  const bf16_t* src = in + row * stride;
+  const int nvec = hidden >> 3;
+  float amax = 0.f, mn = 3.0e38f, mx = -3.0e38f;
+  for (int v = threadIdx.x; v < nvec; v += 256) {
+    Vec8 t = load8(src + (size_t)v * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      amax = fmaxf(amax, fabsf(t.v[j]));
+      mn = fminf(mn, t.v[j]);
+      mx = fmaxf(mx, t.v[j]);
+    }
+  }
+  float sc, zpf = 0.f;
+  if constexpr (MODE == 1) {
+    amax = fmaxf(block_reduce<256>(amax, OpMax(), smem), 9.9920072216264089e-13f);
+    sc = amax / 448.0f;
+  } else if constexpr (MODE == 3) {
+    sc = block_reduce<256>(amax, OpMax(), smem) / 127.0f;
+  } else {
+    mn = block_reduce<256>(mn, OpMin(), smem);
+    mx = block_reduce<256>(mx, OpMax(), smem);
+    sc = (mx - mn) / 255.0f;
+    zpf = -128.0f - __builtin_rintf(mn / sc);
+  }
+  if (threadIdx.x == 0) {
+    scale[row] = sc;
+    if constexpr (MODE == 2) azp[row] = (int32_t)zpf;
+  }
+  uint8_t* dst = q + row * (int64_t)hidden;
+  for (int v = threadIdx.x; v < nvec; v += 256) {
+    Vec8 t = load8(src + (size_t)v * 8);
+    uint32_t w[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      uint32_t two;
+      if constexpr (MODE == 1) {
+        two = cvt2_e4m3<SW>(clamp448(t.v[j] / sc), clamp448(t.v[j + 1] / sc));
+      } else {
+        float ra = __builtin_rintf(t.v[j] / sc + zpf), rb = __builtin_rintf(t.v[j + 1] / sc + zpf);
+        int ia = (int)fmaxf(-128.f, fminf(ra, 127.f)), ib = (int)fmaxf(-128.f, fminf(rb, 127.f));
+        two = ((uint32_t)ia & 0xffu) | (((uint32_t)ib & 0xffu) << 8);
+      }
+      w[j >> 2] |= two << (8 * (j & 3));
+    }
+    i32x2 o;
+    o[0] = (int)w[0];
+    o[1] = (int)w[1];
+    *reinterpret_cast<i32x2*>(dst + (size_t)v * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------ AdaLN modulate (+residual, +quant)
+// y = bf16(bf16(LN(x) * bf16(1+scale)) + shift); optional x := bf16(res + bf16(gate*x)) first.
+template <int THREADS, int QMODE, bool SW>
+__global__ void __launch_bounds__(THREADS) ln_modulate_kernel(
+    bf16_t* __restrict__ out_bf16, uint8_t* __restrict__ out_q, float* __restrict__ out_scale,
+    int32_t* __restrict__ out_azp, const bf16_t* __restrict__ xin, const bf16_t* __restrict__ scale,
+    const bf16_t* __restrict__ shift, int64_t mod_bstride, const bf16_t* __restrict__ res,
+    const bf16_t* __restrict__ gate, bf16_t* __restrict__ x_out, int hidden, int64_t rows_per_batch, float eps) {
+  __shared__ float smem[THREADS / 64 + 1];
+  const int64_t row = blockIdx.x;
+  const int64_t b = row / rows_per_batch;
+  const int nvec = hidden >> 3;
+  Vec8 x[MAXV];
+  load_row<THREADS>(x, xin + row * hidden, nvec);
+  if (res != nullptr) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      int v = threadIdx.x + i * THREADS;
+      if (v < nvec) {
+        Vec8 r = load8(res + row * hidden + (size_t)v * 8), g = load8(gate + b * mod_bstride + (size_t)v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[i].v[j] = rbf(r.v[j] + rbf(g.v[j] * x[i].v[j]));
+        if (x_out != nullptr) store8(x_out + row * hidden + (size_t)v * 8, x[i]);
+      }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if ((int)threadIdx.x + i * THREADS < nvec)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += x[i].v[j];
+  const float mean = block_reduce<THREADS>(s, OpSum(), smem) / (float)hidden;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if ((int)threadIdx.x + i * THREADS < nvec)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float d = x[i].v[j] - mean;
+        ss += d * d;
+      }
+  const float var = block_reduce<THREADS>(ss, OpSum(), smem) / (float)hidden;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int v = threadIdx.x + i * THREADS;
+    if (v < nvec) {
+      Vec8 sc = load8(scale + b * mod_bstride + (size_t)v * 8), sh = load8(shift + b * mod_bstride + (size_t)v * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float n = rbf((x[i].v[j] - mean) * rstd);
+        x[i].v[j] = rbf(rbf(n * rbf(1.0f + sc.v[j])) + sh.v[j]);
+      }
+      if (out_bf16 != nullptr) store8(out_bf16 + row * hidden + (size_t)v * 8, x[i]);
+    }
+  }
+  if constexpr (QMODE != 0) {
+    quant_row_cached<THREADS, QMODE, SW>(x, nvec, out_q + row * (int64_t)hidden, out_scale, out_azp, row, smem);
+  }
+}
+
+// ------------------------------------------------------------------------------------ simple element-wise
+__global__ void __launch_bounds__(256) gate_residual_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ res,
+                                                            const bf16_t* __restrict__ y, const bf16_t* __restrict__ gate,
+                                                            int64_t gate_bstride, int64_t nvec_total, int nvec_row,
+                                                            int64_t rows_per_batch) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec_total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nvec_row;
+    const int v = (int)(i - row * nvec_row);
+    const int64_t b = row / rows_per_batch;
+    Vec8 r = load8(res + i * 8), yy = load8(y + i * 8), g = load8(gate + b * gate_bstride + (size_t)v * 8), o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = r.v[j] + rbf(g.v[j] * yy.v[j]);
+    store8(out + i * 8, o);
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) gelu_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ in, int64_t nvec) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    Vec8 x = load8(in + i * 8), o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = (MODE == 1) ? gelu_tanh_f(x.v[j]) : gelu_erf_f(x.v[j]);
+    store8(out + i * 8, o);
+  }
+}
+
+__global__ void __launch_bounds__(256) gelu_and_mul_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ in,
+                                                           int64_t rows, int d) {
+  const int nv = d >> 3;
+  const int64_t total = rows * nv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nv;
+    const int v = (int)(i - row * nv);
+    Vec8 a = load8(in + row * 2 * d + (size_t)v * 8), g = load8(in + row * 2 * d + d + (size_t)v * 8), o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = a.v[j] * rbf(gelu_erf_f(g.v[j]));
+    store8(out + row * d + (size_t)v * 8, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------ q/k norm + rope + scatter
+// One wave handles one (token, head) pair-of-8-lanes... layout: 16 lanes x 8 elements = one 128-wide head
+// (8 lanes for hd 64).  Each wave covers 64/LPH heads of q, then k; v is copied.
+template <int HD>
+__global__ void __launch_bounds__(256) qk_norm_rope_kernel(bf16_t* __restrict__ qo, bf16_t* __restrict__ ko,
+                                                           bf16_t* __restrict__ vo, const bf16_t* __restrict__ qkv,
+                                                           const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk,
+                                                           const bf16_t* __restrict__ cache, int64_t rows,
+                                                           int64_t rows_per_batch, int64_t seq_total, int64_t seq_offset,
+                                                           int heads, float eps) {
+  constexpr int LPH = HD / 8;  // lanes per head
+  const int inner = heads * HD;
+  const int items_per_row = 3 * heads;  // (q|k|v, head)
+  const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPH;
+  const int sub = threadIdx.x % LPH;
+  const bool ok = gid < rows * items_per_row;
+  const int64_t row = ok ? gid / items_per_row : 0;
+  const int it = ok ? (int)(gid - row * items_per_row) : 0;
+  const int which = it / heads, head = it % heads;
+  const int64_t b = row / rows_per_batch, r = row - b * rows_per_batch;
+  const int64_t pos = seq_offset + r;
+  const int64_t orow = b * seq_total + pos;
+  Vec8 x;
+  if (ok) x = load8(qkv + row * 3 * inner + (size_t)which * inner + head * HD + sub * 8);
+  float ss = 0.f;
+  if (ok && which < 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += x.v[j] * x.v[j];
+  }
+#pragma unroll
+  for (int off = LPH / 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  if (!ok) return;
+  if (which == 2) {
+    store8(vo + orow * inner + head * HD + sub * 8, x);
+    return;
+  }
+  const float rs = rsqrtf(ss / (float)HD + eps);
+  Vec8 wv = load8((which == 0 ? wq : wk) + sub * 8), o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o.v[j] = rbf(rbf(x.v[j] * rs) * wv.v[j]);
+  if (cache != nullptr) {
+    const bf16_t* crow = cache + pos * HD;
+    const i32x2 cr = *reinterpret_cast<const i32x2*>(crow + sub * 4);
+    const i32x2 sr = *reinterpret_cast<const i32x2*>(crow + HD / 2 + sub * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t cw = (uint32_t)cr[j >> 1], sw = (uint32_t)sr[j >> 1];
+      float cs = (j & 1) ? __builtin_bit_cast(float, cw & 0xffff0000u) : __builtin_bit_cast(float, cw << 16);
+      float sn = (j & 1) ? __builtin_bit_cast(float, sw & 0xffff0000u) : __builtin_bit_cast(float, sw << 16);
+      float a = o.v[2 * j], bb = o.v[2 * j + 1];
+      o.v[2 * j] = rbf(a * cs) - rbf(bb * sn);
+      o.v[2 * j + 1] = rbf(bb * cs) + rbf(a * sn);
+    }
+  }
+  store8((which == 0 ? qo : ko) + orow * inner + head * HD + sub * 8, o);
+}
+
+// ------------------------------------------------------------------------------------ TeaCache metric
+__global__ void __launch_bounds__(256) absdiff_sums_kernel(float* __restrict__ out2, const bf16_t* __restrict__ a,
+                                                           const bf16_t* __restrict__ b, int64_t nvec) {
+  __shared__ float smem[5];
+  float sd = 0.f, sb = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    Vec8 x = load8(a + i * 8), y = load8(b + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sd += fabsf(rbf(x.v[j] - y.v[j]));  // (a-b) is a bf16 tensor in the reference before .abs()
+      sb += fabsf(y.v[j]);
+    }
+  }
+  sd = block_reduce<256>(sd, OpSum(), smem);
+  sb = block_reduce<256>(sb, OpSum(), smem);
+  if (threadIdx.x == 0) {
+    atomicAdd(out2, sd);
+    atomicAdd(out2 + 1, sb);
+  }
+}
+
+// ------------------------------------------------------------------------------------ synthetic data (twin of oracle/synth.py)
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ void __launch_bounds__(256) synth_fill_kernel(bf16_t* __restrict__ out, int64_t n, uint32_t seed, int kind,
+                                                         float scale, float offset) {
+  const uint64_t s0 = (uint64_t)seed * 0x9E3779B97F4A7C15ull;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t z = splitmix64(s0 + (uint64_t)i);
+    float v;
+    if (kind == 0) {
+      int tot = (int)(z & 0xffff) + (int)((z >> 16) & 0xffff) + (int)((z >> 32) & 0xffff) + (int)(z >> 48);
+      v = __fmul_rn((float)(tot - 131070), scale);
+      if (offset != 0.0f) v = __fadd_rn(v, offset);
+    } else {
+      v = __fmul_rn((float)(uint32_t)(z >> 40), 5.9604644775390625e-08f);
+    }
+    out[i] = f2bf(v);
+  }
+}
+
+template <bool SW>
+__global__ void debug_cvt_fp8_kernel(uint8_t* out, const float* in, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)(cvt2_e4m3<SW>(clamp448(in[i]), 0.f) & 0xff);
+}
+
+}  // namespace fdm
+
+using namespace fdm;
+
+static inline int grid_for(int64_t work, int threads, int cap = 256 * 8) {
+  int64_t g = (work + threads - 1) / threads;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int MODE>
+static int launch_quant(void* q, float* scale, int32_t* azp, const bf16_t* s0, int w0, int64_t st0, const bf16_t* s1, int w1,
+                        int64_t st1, int64_t rows, hipStream_t s) {
+  const int hidden = w0 + w1;
+  const bool sw = g_fp8_sw_cvt;
+  auto qq = (uint8_t*)q;
+  if (hidden <= 4096) {
+    if (sw) quant_rowwise_kernel<64, MODE, true><<<(unsigned)rows, 64, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1);
+    else quant_rowwise_kernel<64, MODE, false><<<(unsigned)rows, 64, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1);
+  } else if (hidden <= MAXV * 256 * 8) {
+    if (sw) quant_rowwise_kernel<256, MODE, true><<<(unsigned)rows, 256, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1);
+    else quant_rowwise_kernel<256, MODE, false><<<(unsigned)rows, 256, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1);
+  } else {
+    if (s1 != nullptr) return FDM_ERR_UNSUPPORTED;
+    if (sw) quant_rowwise_wide_kernel<MODE, true><<<(unsigned)rows, 256, 0, s>>>(qq, scale, azp, s0, hidden, st0);
+    else quant_rowwise_wide_kernel<MODE, false><<<(unsigned)rows, 256, 0, s>>>(qq, scale, azp, s0, hidden, st0);
+  }
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+template <int THREADS>
+static int launch_ln(void* out_bf16, void* out_q, float* out_scale, int32_t* out_azp, int qm, const void* x, const void* scale,
+                     const void* shift, int64_t mbs, const void* res, const void* gate, void* x_out, int64_t rows, int hidden,
+                     int64_t rpb, float eps, hipStream_t s) {
+  const bool sw = g_fp8_sw_cvt;
+#define FDM_LN(QM, SWV)                                                                                                  \
+  ln_modulate_kernel<THREADS, QM, SWV><<<(unsigned)rows, THREADS, 0, s>>>(                                               \
+      (bf16_t*)out_bf16, (uint8_t*)out_q, out_scale, out_azp, (const bf16_t*)x, (const bf16_t*)scale, (const bf16_t*)shift, \
+      mbs, (const bf16_t*)res, (const bf16_t*)gate, (bf16_t*)x_out, hidden, rpb, eps)
+  if (qm == 0) FDM_LN(0, false);
+  else if (qm == 1) { if (sw) FDM_LN(1, true); else FDM_LN(1, false); }
+  else if (qm == 2) FDM_LN(2, false);
+  else return FDM_ERR_UNSUPPORTED;
+#undef FDM_LN
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+extern "C" {
+
+int fdm_rms_norm(void* out, const void* in, const void* weight, float eps, int64_t rows, int hidden, fdm_stream_t stream) {
+  if (!out || !in || !weight || rows < 0 || hidden <= 0 || (hidden & 7) || !aligned16(out) || !aligned16(in) || !aligned16(weight))
+    return FDM_ERR_INVALID;
+  if (rows == 0) return FDM_OK;
+  hipStream_t s = to_stream(stream);
+  auto o = (bf16_t*)out;
+  auto i = (const bf16_t*)in;
+  auto w = (const bf16_t*)weight;
+  const int lpr = hidden / 8;
+  if (lpr <= 64 && (lpr & (lpr - 1)) == 0) {
+    const int rpw = 64 / lpr;
+    const int64_t waves = (rows + rpw - 1) / rpw;
+    const int grid = (int)((waves + 3) / 4);
+    switch (lpr) {
+      case 1: rms_norm_small_kernel<1><<<grid, 256, 0, s>>>(o, i, w, eps, rows, hidden); break;
+      case 2: rms_norm_small_kernel<2><<<grid, 256, 0, s>>>(o, i, w, eps, rows, hidden); break;
+      case 4: rms_norm_small_kernel<4><<<grid, 256, 0, s>>>(o, i, w, eps, rows, hidden); break;
+      case 8: rms_norm_small_kernel<8><<<grid, 256, 0, s>>>(o, i, w, eps, rows, hidden); break;
+      case 16: rms_norm_small_kernel<16><<<grid, 256, 0, s>>>(o, i, w, eps, rows, hidden); break;
+      case 32: rms_norm_small_kernel<32><<<grid, 256, 0, s>>>(o, i, w, eps, rows, hidden); break;
+      default: rms_norm_small_kernel<64><<<grid, 256, 0, s>>>(o, i, w, eps, rows, hidden); break;
+    }
+  } else if (hidden <= 4096) {
+    rms_norm_row_kernel<64><<<(int)rows, 64, 0, s>>>(o, i, w, eps, hidden);
+  } else {
+    rms_norm_row_kernel<256><<<(int)rows, 256, 0, s>>>(o, i, w, eps, hidden);
+  }
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+int fdm_rope_inplace(void* q, void* k, const void* cos_sin_cache, int64_t tokens, int64_t seq_len, int q_heads,
+                     int k_heads, int head_size, int rot_dim, int64_t q_row_stride, int64_t k_row_stride, int is_neox,
+                     fdm_stream_t stream) {
+  if (!q || !k || !cos_sin_cache || tokens < 0 || seq_len <= 0 || q_heads < 0 || k_heads < 0 || rot_dim > head_size)
+    return FDM_ERR_INVALID;
+  if ((head_size & 7) || (q_row_stride & 7) || (k_row_stride & 7) || !aligned16(q) || !aligned16(k)) return FDM_ERR_INVALID;
+  if (is_neox ? (rot_dim % 16) : (rot_dim % 8)) return FDM_ERR_UNSUPPORTED;
+  if (tokens == 0) return FDM_OK;
+  const int per_head = is_neox ? (rot_dim / 16) : (rot_dim / 8);
+  const int64_t work = tokens * (int64_t)(q_heads + k_heads) * per_head;
+  const int64_t grid = (work + 255) / 256;
+  hipStream_t s = to_stream(stream);
+  if (is_neox)
+    rope_kernel<true><<<(unsigned)grid, 256, 0, s>>>((bf16_t*)q, (bf16_t*)k, (const bf16_t*)cos_sin_cache, tokens, seq_len,
+                                                     q_heads, k_heads, head_size, rot_dim, q_row_stride, k_row_stride);
+  else
+    rope_kernel<false><<<(unsigned)grid, 256, 0, s>>>((bf16_t*)q, (bf16_t*)k, (const bf16_t*)cos_sin_cache, tokens, seq_len,
+                                                      q_heads, k_heads, head_size, rot_dim, q_row_stride, k_row_stride);
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+int fdm_quant_rowwise_cat2(void* q_out, float* scale_out, int32_t* azp_out, int quant_mode, const void* src0, int w0,
+                           int64_t stride0, const void* src1, int w1, int64_t stride1, int64_t rows, fdm_stream_t stream) {
+  if (!q_out || !scale_out || !src0 || w0 <= 0 || (w0 & 7) || (w1 & 7) || w1 < 0 || (stride0 & 7) || (stride1 & 7) || rows < 0)
+    return FDM_ERR_INVALID;
+  if ((w1 > 0) != (src1 != nullptr)) return FDM_ERR_INVALID;
+  if (!aligned16(src0) || !aligned16(src1) || (reinterpret_cast<uintptr_t>(q_out) & 7)) return FDM_ERR_INVALID;
+  if (quant_mode == 2 && !azp_out) return FDM_ERR_INVALID;
+  if (rows == 0) return FDM_OK;
+  hipStream_t s = to_stream(stream);
+  auto a = (const bf16_t*)src0;
+  auto b = (const bf16_t*)src1;
+  switch (quant_mode) {
+    case 1: return launch_quant<1>(q_out, scale_out, azp_out, a, w0, stride0, b, w1, stride1, rows, s);
+    case 2: return launch_quant<2>(q_out, scale_out, azp_out, a, w0, stride0, b, w1, stride1, rows, s);
+    case 3: return launch_quant<3>(q_out, scale_out, azp_out, a, w0, stride0, b, w1, stride1, rows, s);
+    default: return FDM_ERR_UNSUPPORTED;
+  }
+}
+
+int fdm_quant_fp8_rowwise(void* q_out, float* scale_out, const void* in, int64_t rows, int hidden, int64_t in_row_stride,
+                          fdm_stream_t stream) {
+  return fdm_quant_rowwise_cat2(q_out, scale_out, nullptr, 1, in, hidden, in_row_stride, nullptr, 0, 0, rows, stream);
+}
+
+int fdm_quant_int8_rowwise(void* q_out, float* scale_out, int32_t* azp_out, const void* in, int64_t rows, int hidden,
+                           int64_t in_row_stride, fdm_stream_t stream) {
+  return fdm_quant_rowwise_cat2(q_out, scale_out, azp_out, azp_out ? 2 : 3, in, hidden, in_row_stride, nullptr, 0, 0, rows,
+                                stream);
+}
+
+int fdm_gelu_and_mul(void* out, const void* in, int64_t rows, int d, fdm_stream_t stream) {
+  if (!out || !in || rows < 0 || d <= 0 || (d & 7) || !aligned16(out) || !aligned16(in)) return FDM_ERR_INVALID;
+  if (rows == 0) return FDM_OK;
+  gelu_and_mul_kernel<<<grid_for(rows * (d / 8), 256), 256, 0, to_stream(stream)>>>((bf16_t*)out, (const bf16_t*)in, rows, d);
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+int fdm_gelu(void* out, const void* in, int64_t n, int mode, fdm_stream_t stream) {
+  if (!out || !in || n < 0 || (n & 7) || !aligned16(out) || !aligned16(in)) return FDM_ERR_INVALID;
+  if (mode != 1 && mode != 2) return FDM_ERR_UNSUPPORTED;
+  if (n == 0) return FDM_OK;
+  if (mode == 1) gelu_kernel<1><<<grid_for(n / 8, 256), 256, 0, to_stream(stream)>>>((bf16_t*)out, (const bf16_t*)in, n / 8);
+  else gelu_kernel<2><<<grid_for(n / 8, 256), 256, 0, to_stream(stream)>>>((bf16_t*)out, (const bf16_t*)in, n / 8);
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+int fdm_gate_residual(void* out, const void* res, const void* y, const void* gate, int64_t gate_batch_stride, int64_t rows,
+                      int hidden, int64_t rows_per_batch, fdm_stream_t stream) {
+  if (!out || !res || !y || !gate || rows < 0 || hidden <= 0 || (hidden & 7) || rows_per_batch <= 0 || (gate_batch_stride & 7))
+    return FDM_ERR_INVALID;
+  if (!aligned16(out) || !aligned16(res) || !aligned16(y) || !aligned16(gate)) return FDM_ERR_INVALID;
+  if (rows == 0) return FDM_OK;
+  const int64_t nvec = rows * (hidden / 8);
+  gate_residual_kernel<<<grid_for(nvec, 256), 256, 0, to_stream(stream)>>>((bf16_t*)out, (const bf16_t*)res, (const bf16_t*)y,
+                                                                         (const bf16_t*)gate, gate_batch_stride, nvec,
+                                                                         hidden / 8, rows_per_batch);
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+int fdm_ln_modulate(void* out_bf16, void* out_q, float* out_scale, int32_t* out_azp, int quant_mode, const void* x,
+                    const void* scale, const void* shift, int64_t mod_batch_stride, const void* res, const void* gate,
+                    void* x_out, int64_t rows, int hidden, int64_t rows_per_batch, float eps, fdm_stream_t stream) {
+  if (!x || !scale || !shift || rows < 0 || hidden <= 0 || (hidden & 7) || rows_per_batch <= 0 || (mod_batch_stride & 7))
+    return FDM_ERR_INVALID;
+  if (quant_mode != 0 && (!out_q || !out_scale)) return FDM_ERR_INVALID;
+  if (quant_mode == 2 && !out_azp) return FDM_ERR_INVALID;
+  if ((res != nullptr) != (gate != nullptr)) return FDM_ERR_INVALID;
+  if (!aligned16(x) || !aligned16(scale) || !aligned16(shift) || !aligned16(res) || !aligned16(gate) || !aligned16(out_bf16) ||
+      !aligned16(x_out) || (reinterpret_cast<uintptr_t>(out_q) & 7))
+    return FDM_ERR_INVALID;
+  if (hidden > MAXV * 256 * 8) return FDM_ERR_UNSUPPORTED;
+  if (rows == 0) return FDM_OK;
+  hipStream_t s = to_stream(stream);
+  if (hidden <= 4096)
+    return launch_ln<64>(out_bf16, out_q, out_scale, out_azp, quant_mode, x, scale, shift, mod_batch_stride, res, gate, x_out,
+                         rows, hidden, rows_per_batch, eps, s);
+  return launch_ln<256>(out_bf16, out_q, out_scale, out_azp, quant_mode, x, scale, shift, mod_batch_stride, res, gate, x_out,
+                        rows, hidden, rows_per_batch, eps, s);
+}
+
+int fdm_qk_norm_rope(void* q_out, void* k_out, void* v_out, const void* qkv, const void* wq, const void* wk,
+                     const void* cos_sin_cache, int64_t rows, int64_t rows_per_batch, int64_t seq_total, int64_t seq_offset,
+                     int heads, int head_dim, float eps, fdm_stream_t stream) {
+  if (!q_out || !k_out || !v_out || !qkv || !wq || !wk || rows < 0 || rows_per_batch <= 0 || heads <= 0) return FDM_ERR_INVALID;
+  if (seq_offset < 0 || seq_offset + rows_per_batch > seq_total) return FDM_ERR_INVALID;
+  if (!aligned16(q_out) || !aligned16(k_out) || !aligned16(v_out) || !aligned16(qkv) || !aligned16(wq) || !aligned16(wk))
+    return FDM_ERR_INVALID;
+  if (head_dim != 64 && head_dim != 128 && head_dim != 32) return FDM_ERR_UNSUPPORTED;
+  if (rows == 0) return FDM_OK;
+  const int lph = head_dim / 8;
+  const int64_t threads = rows * 3 * heads * lph;
+  const int64_t grid = (threads + 255) / 256;
+  hipStream_t s = to_stream(stream);
+#define FDM_QK(HD)                                                                                                         \
+  qk_norm_rope_kernel<HD><<<(unsigned)grid, 256, 0, s>>>((bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)v_out, (const bf16_t*)qkv, \
+                                                         (const bf16_t*)wq, (const bf16_t*)wk, (const bf16_t*)cos_sin_cache, \
+                                                         rows, rows_per_batch, seq_total, seq_offset, heads, eps)
+  if (head_dim == 128) FDM_QK(128);
+  else if (head_dim == 64) FDM_QK(64);
+  else FDM_QK(32);
+#undef FDM_QK
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+int fdm_absdiff_sums(float* out2, const void* a, const void* b, int64_t n, fdm_stream_t stream) {
+  if (!out2 || !a || !b || n < 0 || (n & 7) || !aligned16(a) || !aligned16(b)) return FDM_ERR_INVALID;
+  if (n == 0) return FDM_OK;
+  absdiff_sums_kernel<<<grid_for(n / 8, 256, 1024), 256, 0, to_stream(stream)>>>(out2, (const bf16_t*)a, (const bf16_t*)b, n / 8);
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+int fdm_synth_fill_bf16(void* out, int64_t n, uint32_t seed, int kind, float scale, float offset, fdm_stream_t stream) {
+  if (!out || n < 0 || (kind != 0 && kind != 1)) return FDM_ERR_INVALID;
+  if (n == 0) return FDM_OK;
+  synth_fill_kernel<<<grid_for(n, 256, 256 * 16), 256, 0, to_stream(stream)>>>((bf16_t*)out, n, seed, kind, scale, offset);
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+int fdm_debug_cvt_fp8(void* out_u8, const float* in, int64_t n, int use_sw, fdm_stream_t stream) {
+  if (!out_u8 || !in || n < 0) return FDM_ERR_INVALID;
+  if (n == 0) return FDM_OK;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (use_sw) debug_cvt_fp8_kernel<true><<<grid, 256, 0, to_stream(stream)>>>((uint8_t*)out_u8, in, n);
+  else debug_cvt_fp8_kernel<false><<<grid, 256, 0, to_stream(stream)>>>((uint8_t*)out_u8, in, n);
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+}  // extern "C"

@@ -11,9 +11,11 @@ The reference is imported from /root/reference with two stub modules
 extension / triton kernels) and KERNEL_BACKEND=torch, QLinear forced to the CPU
 (SURVEY.md §8c).  `fp8_matmul` has no CPU implementation upstream
 (torch._scaled_mm row-wise is CUDA-only), so an extra backend is registered for that one
-op: the reference's own primitive `torch._scaled_mm` with unit per-tensor scales yields
-the fp32 accumulator, to which the row/column scales and bias are applied in fp32 exactly
-as csrc/gemm/hopper_w8a8_fp8.cu:95-142 does.  Nothing here travels to the GPU box except
+op: an fp32 matmul of the fp8 operands (every fp8 x fp8 product is exact in fp32; the same
+`a.float() @ b.float()` idiom the reference's int8 torch op uses, torch/matrixmul.py:67) yields
+the accumulator, to which the row/column scales and bias are applied in fp32 exactly as
+csrc/gemm/hopper_w8a8_fp8.cu:95-142 does.  (CPU `torch._scaled_mm` with unit per-tensor scales
+gives the same numbers to ~6e-5 but runs at ~25 MFLOP/s, unusable at full width.)  Nothing here travels to the GPU box except
 the vectors it writes under tests/golden/.
 """
 import argparse
@@ -44,10 +46,10 @@ def import_reference():
     reg = kernel_registry._registry
     if "cpu_fp8" not in reg["fp8_matmul"]:
         def fp8_matmul_cpu(a, b, scale_a, scale_b, out_dtype, bias=None):
-            one = torch.tensor(1.0)
             outs = []
+            bf = b.float()
             for s in range(0, a.shape[0], 2048):
-                acc = torch._scaled_mm(a[s:s + 2048], b, one, one, None, out_dtype=torch.float32)
+                acc = a[s:s + 2048].float() @ bf
                 r = acc * scale_a[s:s + 2048] * scale_b.reshape(1, -1)
                 if bias is not None:
                     r = r + bias.float()
