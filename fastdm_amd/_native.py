@@ -1,0 +1,102 @@
+"""ctypes binding of libfastdm_amd.so (the C ABI declared in include/fastdm_amd.h).
+
+The signatures below mirror the header one-to-one; tests/test_abi.py checks that every `fdm_*`
+prototype in the header is present here and exported by the library.  There is no fallback: if the
+library cannot be found (or built in-tree with hipcc) importing a kernel raises.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libfastdm_amd.so")
+BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
+
+P, I64, I32, U32, F32 = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_float
+
+# name -> (restype, argtypes); order = include/fastdm_amd.h
+SIGNATURES = {
+    "fdm_version": (I32, []),
+    "fdm_error_string": (C.c_char_p, [I32]),
+    "fdm_rms_norm": (I32, [P, P, P, F32, I64, I32, P]),
+    "fdm_rope_inplace": (I32, [P, P, P, I64, I64, I32, I32, I32, I32, I64, I64, I32, P]),
+    "fdm_quant_fp8_rowwise": (I32, [P, P, P, I64, I32, I64, P]),
+    "fdm_quant_int8_rowwise": (I32, [P, P, P, P, I64, I32, I64, P]),
+    "fdm_gelu_and_mul": (I32, [P, P, I64, I32, P]),
+    "fdm_gemm_w8a8_fp8": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, P, I64, P]),
+    "fdm_gemm_w8a8_int8": (I32, [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, P]),
+    "fdm_gemm_bf16": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, P, I64, P]),
+    "fdm_attn_fwd": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I32, I32, P]),
+    "fdm_ln_modulate": (I32, [P, P, P, P, I32, P, P, P, I64, P, P, P, I64, I32, I64, F32, P]),
+    "fdm_gate_residual": (I32, [P, P, P, P, I64, I64, I32, I64, P]),
+    "fdm_gelu": (I32, [P, P, I64, I32, P]),
+    "fdm_quant_rowwise_cat2": (I32, [P, P, P, I32, P, I32, I64, P, I32, I64, I64, P]),
+    "fdm_qk_norm_rope": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, I32, F32, P]),
+    "fdm_absdiff_sums": (I32, [P, P, P, I64, P]),
+    "fdm_synth_fill_bf16": (I32, [P, I64, U32, I32, F32, F32, P]),
+    "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
+}
+
+EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL = 0, 1, 2, 3
+
+_lib = None
+_lock = threading.Lock()
+
+
+class NativeLibraryError(ImportError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))
+            if f.endswith((".hip", ".h", ".sh"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "fastdm_amd.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    res = subprocess.run(["bash", BUILD_SCRIPT], capture_output=True, text=True)
+    if res.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(f"building libfastdm_amd.so failed:\n{res.stdout}\n{res.stderr}")
+    return LIB_PATH
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises NativeLibraryError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            try:
+                build()
+            except Exception as e:  # noqa: BLE001
+                raise NativeLibraryError(
+                    f"fastdm_amd: HIP library {LIB_PATH} is missing and could not be built ({e}). "
+                    "This package has no CPU / eager fallback.") from e
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise NativeLibraryError(f"fastdm_amd: cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError -> missing export: let it propagate loudly
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().fdm_error_string(rc).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {rc})")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

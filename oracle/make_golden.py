@@ -329,7 +329,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
     (flux.py:445-485) is spelled out here so that each block's weights can be freed."""
     import_reference()
     from oracle import flux as OF
-    from fastdm.model.flux import FluxTransformer2DModelCore
+    from fastdm.model.flux import FluxTransformer2DModelCore, FluxTransformerBlock, FluxSingleTransformerBlock
     import contextlib
     import io
     cfg = OF.FluxConfig(num_layers=n_double, num_single_layers=n_single)
@@ -379,6 +379,9 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
             for i in range(n_double):
                 names = [((n, n.replace(f"transformer_blocks.{i}.", "transformer_blocks.0.")), s, k)
                          for n, s, k in specs_with_prefix(f"transformer_blocks.{i}.")]
+                # fresh block object: QLinear.weight_loading_and_quant casts to the *previous* weight dtype
+                core.transformer_blocks = [FluxTransformerBlock(dim=cfg.inner_dim, num_attention_heads=cfg.num_attention_heads,
+                                                                attention_head_dim=cfg.attention_head_dim, data_type=torch.bfloat16)]
                 load_part(core, names, core._FluxTransformer2DModelCore__transformer_block_loading)
                 encoder, hidden = core.transformer_blocks[0].forward(
                     hidden_states=hidden, encoder_hidden_states=encoder, temb=temb, image_rotary_emb=rope)
@@ -390,6 +393,8 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
             for i in range(n_single):
                 names = [((n, n.replace(f"single_transformer_blocks.{i}.", "single_transformer_blocks.0.")), s, k)
                          for n, s, k in specs_with_prefix(f"single_transformer_blocks.{i}.")]
+                core.single_transformer_blocks = [FluxSingleTransformerBlock(dim=cfg.inner_dim, num_attention_heads=cfg.num_attention_heads,
+                                                                             attention_head_dim=cfg.attention_head_dim, data_type=torch.bfloat16)]
                 load_part(core, names, core._FluxTransformer2DModelCore__single_trans_block_loading)
                 x = core.single_transformer_blocks[0].forward(hidden_states=x, temb=temb, image_rotary_emb=rope)
                 print(f"[{tag}] single {i} done  t={time.time() - t0:.0f}s  |x|={x.float().abs().mean():.4f}", flush=True)

@@ -1,0 +1,67 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/fastdm_amd.h declares,
+and the ctypes table mirrors the header.  No compute calls (no GPU here)."""
+import os
+import re
+
+from fastdm_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_prototypes():
+    src = open(os.path.join(ROOT, "include", "fastdm_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|const char\*)\s+(fdm_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = [a.strip() for a in m.group(3).split(",") if a.strip() and a.strip() != "void"]
+        protos[m.group(2)] = args
+    return protos
+
+
+def test_library_builds_and_loads():
+    path = N.build()
+    assert os.path.exists(path)
+    lib = N.lib()
+    assert lib.fdm_version() >= 100
+    assert lib.fdm_error_string(0) == b"ok"
+    assert b"unsupported" in lib.fdm_error_string(-2)
+
+
+def test_every_header_symbol_is_exported_and_bound():
+    protos = header_prototypes()
+    assert len(protos) >= 19
+    lib = N.lib()
+    assert set(protos) == set(N.SIGNATURES), set(protos) ^ set(N.SIGNATURES)
+    for name, args in protos.items():
+        assert hasattr(lib, name), f"{name} not exported"
+        assert len(args) == len(N.SIGNATURES[name][1]), f"{name}: header has {len(args)} args, binding {len(N.SIGNATURES[name][1])}"
+
+
+def test_argument_kinds_match_header():
+    """pointer <-> c_void_p, int64_t <-> c_int64, int <-> c_int, float <-> c_float, uint32_t <-> c_uint32."""
+    import ctypes as C
+    kind = {C.c_void_p: "ptr", C.c_int64: "i64", C.c_int: "i32", C.c_float: "f32", C.c_uint32: "u32"}
+    for name, args in header_prototypes().items():
+        for decl, ct in zip(args, N.SIGNATURES[name][1]):
+            if "*" in decl or decl.startswith("fdm_stream_t"):
+                want = "ptr"
+            elif decl.startswith("int64_t"):
+                want = "i64"
+            elif decl.startswith("uint32_t"):
+                want = "u32"
+            elif decl.startswith("float"):
+                want = "f32"
+            else:
+                want = "i32"
+            assert kind[ct] == want, f"{name}: '{decl}' bound as {kind[ct]}"
+
+
+def test_ops_reject_cpu_tensors_loudly():
+    import pytest
+    import torch
+    from fastdm_amd.kernel import operators_set as ops
+    x = torch.zeros(4, 128, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        ops.rms_norm(x, torch.ones(128, dtype=torch.bfloat16), 1e-6)
+    with pytest.raises(RuntimeError):
+        ops.quantize_to_fp8(x)

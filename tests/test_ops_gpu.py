@@ -1,0 +1,315 @@
+"""GPU parity: every operator of the HIP path (through the C ABI) against the CPU oracle and the
+committed golden vectors.  Shapes follow /root/reference/tests/test_*.py (model-derived tables)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+FP8 = torch.float8_e4m3fn
+
+
+@pytest.fixture(scope="module")
+def K():
+    from fastdm_amd.kernel import operators_set
+    assert torch.cuda.is_available()
+    return operators_set
+
+
+def dev(t):
+    return None if t is None else t.cuda()
+
+
+def ulp_close(got, ref, max_frac, what, ulps=1):
+    """bf16 results equal up to `ulps` bf16 ulp on at most `max_frac` of the elements."""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    diff = (got - ref).abs()
+    tol = ulps * 2.0 ** -7 * torch.maximum(ref.abs(), got.abs()) + 1e-30
+    bad = diff > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} elems beyond {ulps} ulp, max diff {diff.max().item()}"
+    frac = (diff > 0).float().mean().item()
+    assert frac <= max_frac, f"{what}: {frac:.4%} elements differ (allowed {max_frac:.4%})"
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rbf(g, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(BF16)
+
+
+# ------------------------------------------------------------------ conversions / synthetic data
+def test_fp8_conversion_hw_and_sw_match_torch():
+    from fastdm_amd import _native as N
+    # every bf16 bit pattern with |x| <= 448 plus dense fp32 samples around rounding boundaries
+    bits = np.arange(0, 1 << 16, dtype=np.uint16)
+    f = synth.bf16_bits_to_f32(bits)
+    g = torch.Generator().manual_seed(0)
+    dense = torch.cat([torch.randn(1 << 16, generator=g) * s for s in (1e-3, 0.02, 1.0, 30.0, 200.0)])
+    x = torch.cat([torch.from_numpy(f[np.isfinite(f)]), dense, torch.tensor([0.0, -0.0, 448.0, -448.0, 464.0, 1e9, 2.0 ** -9, 2.0 ** -10, 3 * 2.0 ** -10])])
+    ref = x.clamp(-448, 448).to(FP8).view(torch.uint8)
+    xd = x.cuda()
+    for sw in (1, 0):
+        out = torch.empty(x.numel(), dtype=torch.uint8, device="cuda")
+        N.check(N.lib().fdm_debug_cvt_fp8(out.data_ptr(), xd.data_ptr(), x.numel(), sw, N.stream()), "cvt")
+        got = out.cpu()
+        # -0.0 vs +0.0 sign of zero is irrelevant downstream; compare modulo that
+        same = (got == ref) | ((got & 0x7f) == 0) & ((ref & 0x7f) == 0)
+        assert same.all(), f"sw={sw}: {int((~same).sum())} mismatches, first {x[~same][:5]}, got {got[~same][:5]}, ref {ref[~same][:5]}"
+
+
+def test_synth_fill_matches_numpy_twin():
+    from fastdm_amd import _native as N
+    n = (1 << 20) + 37
+    for seed, kind, std, off in ((3, 0, 0.02, 0.0), (11, 0, 0.1, 1.0), (5, 1, 0.0, 0.0), (synth.key_seed("proj_out.weight", 0), 0, 3072 ** -0.5, 0.0)):
+        out = torch.empty(n, dtype=BF16, device="cuda")
+        scale = float(synth.normal_scale(std)) if kind == 0 else 0.0
+        N.check(N.lib().fdm_synth_fill_bf16(out.data_ptr(), n, seed, kind, scale, off, N.stream()), "fill")
+        ref = synth.normal_bf16_bits(seed, n, std, off) if kind == 0 else synth.uniform_bf16_bits(seed, n)
+        got = out.cpu().view(torch.int16).numpy().view(np.uint16)
+        assert np.array_equal(got, ref), f"seed {seed} kind {kind}: {(got != ref).sum()} mismatches"
+
+
+# ------------------------------------------------------------------ golden vectors (reference outputs)
+@pytest.mark.parametrize("tag", ["rms4d", "rms3d", "rms64"])
+def test_rms_norm_golden(K, ops_golden, tag):
+    g = ops_golden
+    ulp_close(K.rms_norm(dev(g[f"{tag}_x"]), dev(g[f"{tag}_w"]), 1e-6), g[f"{tag}_out"], 0.01, tag)
+
+
+@pytest.mark.parametrize("tag,hd,neox", [("ropej", 64, False), ("ropej128", 128, False), ("ropen", 64, True)])
+def test_rope_golden_bit_exact(K, ops_golden, tag, hd, neox):
+    g = ops_golden
+    q, k = dev(g[f"{tag}_q"]), dev(g[f"{tag}_k"])
+    assert K.rotary_pos_embedding(q, k, hd, dev(g[f"{tag}_cache"]), is_neox=neox) is None
+    assert torch.equal(q.cpu(), g[f"{tag}_qout"]) and torch.equal(k.cpu(), g[f"{tag}_kout"])
+
+
+def test_quant_golden_bit_exact(K, ops_golden):
+    g = ops_golden
+    q, s = K.quantize_to_fp8(dev(g["quant_x"]))
+    assert torch.equal(s.cpu(), g["quant_fp8_s"])
+    assert torch.equal(q.cpu().view(torch.uint8), g["quant_fp8_q"].view(torch.uint8))
+    q, s, zp = K.quantize_to_int8(dev(g["quant_xi"]), symmetric=False)
+    assert torch.equal(s.cpu(), g["quant_i8a_s"]) and torch.equal(zp.cpu(), g["quant_i8a_zp"]) and torch.equal(q.cpu(), g["quant_i8a_q"])
+    q, s, zp = K.quantize_to_int8(dev(g["quant_xi"]), symmetric=True)
+    assert zp is None and torch.equal(s.cpu(), g["quant_i8s_s"]) and torch.equal(q.cpu(), g["quant_i8s_q"])
+
+
+@pytest.mark.parametrize("tag", ["mm14", "mm130"])
+def test_matmul_golden(K, ops_golden, tag):
+    g = ops_golden
+    for bias_key, suffix in ((None, "out"), (f"{tag}_bias", "out_bias")):
+        bias = dev(g[bias_key]) if bias_key else None
+        got = K.int8_matmul(dev(g[f"{tag}_i8_a"]), dev(g[f"{tag}_i8_b"].t().contiguous().t()), dev(g[f"{tag}_sa"]), dev(g[f"{tag}_sb"]), BF16,
+                            dev(g[f"{tag}_adj"]), dev(g[f"{tag}_azp"]), bias)
+        ulp_close(got, g[f"{tag}_i8_{suffix}"], 0.02, f"int8 {tag}")
+        got = K.fp8_matmul(dev(g[f"{tag}_f8_a"]), dev(g[f"{tag}_f8_b"].t().contiguous().t()), dev(g[f"{tag}_sa"]), dev(g[f"{tag}_sb"]), BF16, bias)
+        ulp_close(got, g[f"{tag}_f8_{suffix}"], 0.01, f"fp8 {tag}")
+
+
+@pytest.mark.parametrize("tag,H,hd", [("att128", 3, 128), ("att64", 2, 64), ("attx64", 2, 64)])
+def test_attention_golden(K, ops_golden, tag, H, hd):
+    g = ops_golden
+    got = K.scaled_dot_product_attention(dev(g[f"{tag}_q"]), dev(g[f"{tag}_k"]), dev(g[f"{tag}_v"]), H, H, hd, scale=hd ** -0.5)
+    # /root/reference/tests/test_attention.py:94
+    torch.testing.assert_close(got.cpu(), g[f"{tag}_out"], rtol=0.0, atol=1.8e-2)
+    assert (got.cpu().float() - g[f"{tag}_out"].float()).abs().mean() < 2e-3
+
+
+def test_gelu_and_mul_golden(K, ops_golden):
+    ulp_close(K.gelu_and_mul(dev(ops_golden["gm_x"])), ops_golden["gm_out"], 0.01, "gelu_and_mul")
+
+
+# ------------------------------------------------------------------ model-derived shapes vs the oracle
+def test_rms_norm_flux_shape(K):
+    g = gen(1)
+    x, w = rbf(g, 1, 4608, 24, 128, scale=2.0), (1 + 0.1 * torch.randn(128, generator=g)).to(BF16)
+    ulp_close(K.rms_norm(x.cuda(), w.cuda(), 1e-6), O.rms_norm(x, w, 1e-6), 0.01, "rms flux")
+    x, w = rbf(g, 2, 300, 5120), (1 + 0.1 * torch.randn(5120, generator=g)).to(BF16)   # Wan: across heads
+    ulp_close(K.rms_norm(x.cuda(), w.cuda(), 1e-6), O.rms_norm(x, w, 1e-6), 0.01, "rms wan")
+    x, w = rbf(g, 3, 40960), torch.ones(40960, dtype=BF16)                                # wide fallback path
+    ulp_close(K.rms_norm(x.cuda(), w.cuda(), 1e-5), O.rms_norm(x, w, 1e-5), 0.01, "rms wide")
+
+
+def test_rope_flux_shape_bit_exact(K):
+    g = gen(2)
+    q, k = rbf(g, 1, 4608, 3072), rbf(g, 1, 4608, 3072)
+    ang = torch.rand(4608, 64, generator=g) * 6.28
+    cache = torch.cat((ang.cos(), ang.sin()), -1).to(BF16)
+    qd, kd = q.cuda(), k.cuda()
+    K.rotary_pos_embedding(qd, kd, 128, cache.cuda(), is_neox=False)
+    O.rotary_pos_embedding(q, k, 128, cache, is_neox=False)
+    assert torch.equal(qd.cpu(), q) and torch.equal(kd.cpu(), k)
+
+
+@pytest.mark.parametrize("M,Kd", [(4096, 3072), (512, 12288), (14, 3072), (4608, 15360), (8192, 640), (154, 2048), (3, 20480)])
+def test_quant_shapes_bit_exact(K, M, Kd):
+    g = gen(M + Kd)
+    x = rbf(g, M, Kd, scale=1.5)
+    x[0] = 0.0
+    q, s = K.quantize_to_fp8(x.cuda())
+    rq, rs = O.quantize_to_fp8(x)
+    assert torch.equal(s.cpu(), rs)
+    assert torch.equal(q.cpu().view(torch.uint8), rq.view(torch.uint8))
+    x[0, 0] = 1.0
+    q, s, zp = K.quantize_to_int8(x.cuda(), symmetric=False)
+    rq, rs, rzp = O.quantize_to_int8(x, symmetric=False)
+    assert torch.equal(s.cpu(), rs) and torch.equal(zp.cpu(), rzp) and torch.equal(q.cpu(), rq)
+
+
+def test_quant_strided_input(K):
+    g = gen(77)
+    big = rbf(g, 100, 9216)
+    view = big[:, 3072:6144]          # a q/k/v slice of a fused projection: row stride 9216
+    q, s = K.quantize_to_fp8(view.cuda())
+    rq, rs = O.quantize_to_fp8(view.contiguous())
+    assert torch.equal(s.cpu(), rs) and torch.equal(q.cpu().view(torch.uint8), rq.view(torch.uint8))
+
+
+MM_SHAPES = [  # /root/reference/tests/test_matmul.py:5-44 (M, K, N)
+    [4096, 3072, 9216], [512, 3072, 9216], [512, 3072, 3072], [4096, 3072, 3072], [4096, 3072, 12288], [4096, 12288, 3072],
+    [512, 3072, 12288], [512, 12288, 3072], [4608, 3072, 12288], [4608, 3072, 9216], [4608, 15360, 3072], [14, 3072, 9216],
+    [14, 3072, 3072], [14, 3072, 12288], [14, 12288, 3072], [8192, 1536, 4608], [1178, 1536, 4608], [1178, 1536, 1536],
+    [8192, 1536, 1536], [8192, 1536, 6144], [8192, 6144, 1536], [1178, 1536, 6144], [1178, 6144, 1536], [2, 1536, 3072],
+    [8192, 1536, 64], [2, 320, 1280], [2, 1280, 1280], [2, 2816, 1280], [8192, 640, 640], [8192, 640, 1920], [154, 2048, 1280],
+    [8192, 640, 5120], [8192, 2560, 640], [2048, 1280, 1280], [2048, 1280, 3840], [154, 2048, 2560], [2048, 1280, 10240],
+    [2048, 5120, 1280], [8704, 3072, 9216], [8704, 15360, 3072],
+]
+
+
+def sample_rows(M, n=48):
+    rows = sorted(set([0, M - 1] + [(i * 2654435761) % M for i in range(n)] + [min(M - 1, r) for r in (255, 256, 257)]))
+    return torch.tensor(rows)
+
+
+@pytest.mark.parametrize("M,Kd,Nn", MM_SHAPES)
+def test_fp8_matmul_reference_shapes(K, M, Kd, Nn):
+    g = gen(M * 31 + Kd * 7 + Nn)
+    a = torch.randn(M, Kd, generator=g).to(FP8)
+    b = torch.randn(Nn, Kd, generator=g).to(FP8).t()            # [K,N] column-major
+    sa, sb = torch.rand(M, 1, generator=g) + 0.5, torch.rand(Nn, 1, generator=g) * 0.02 + 0.001
+    bias = rbf(g, Nn)
+    got = K.fp8_matmul(a.cuda(), b.t().contiguous().cuda().t(), sa.cuda(), sb.cuda(), BF16, bias.cuda()).cpu()
+    rows = sample_rows(M)
+    ref = O.fp8_matmul(a[rows], b, sa[rows], sb, BF16, bias)
+    ulp_close(got[rows], ref, 0.02, f"fp8 {M}x{Kd}x{Nn}")
+    assert torch.isfinite(got.float()).all()
+
+
+@pytest.mark.parametrize("M,Kd,Nn", MM_SHAPES[::3] + [[130, 16, 16], [257, 48, 272]])
+def test_int8_matmul_reference_shapes(K, M, Kd, Nn):
+    g = gen(M * 13 + Kd * 5 + Nn)
+    a = torch.randint(-128, 128, (M, Kd), generator=g).to(torch.int8)
+    b = torch.randint(-128, 128, (Nn, Kd), generator=g).to(torch.int8).t()
+    sa, sb = torch.rand(M, 1, generator=g) * 0.01 + 0.001, torch.rand(Nn, 1, generator=g) * 0.01 + 0.001
+    adj = b.to(torch.int32).sum(dim=0, keepdim=True, dtype=torch.int32)
+    azp = torch.randint(-128, 127, (M, 1), generator=g).to(torch.int32)
+    bias = rbf(g, Nn)
+    got = K.int8_matmul(a.cuda(), b.t().contiguous().cuda().t(), sa.cuda(), sb.cuda(), BF16, adj.cuda(), azp.cuda(), bias.cuda()).cpu()
+    rows = sample_rows(M)
+    ref = O.int8_matmul(a[rows], b, sa[rows], sb, BF16, adj, azp[rows], bias)
+    assert torch.equal(got[rows], ref), f"int8 {M}x{Kd}x{Nn}: max diff {(got[rows].float() - ref.float()).abs().max()}"
+
+
+def test_bf16_gemm_and_epilogues():
+    from fastdm_amd import _native as N
+    g = gen(5)
+    M, Kd, Nn = 300, 64 + 8, 528
+    a, w, bias = rbf(g, M, Kd), rbf(g, Nn, Kd, scale=Kd ** -0.5), rbf(g, Nn, scale=0.1)
+    res, gate = rbf(g, M, Nn), rbf(g, 2, Nn)
+    ad, wd, bd, rd, gd = a.cuda(), w.cuda(), bias.cuda(), res.cuda(), gate.cuda()
+    y = torch.addmm(bias.float(), a.float(), w.float().t()).to(BF16)       # fp32 accumulate, one rounding
+    for epi, want in ((N.EPI_NONE, y),
+                      (N.EPI_GELU_TANH, torch.nn.functional.gelu(y, approximate="tanh")),
+                      (N.EPI_GELU_ERF, torch.nn.functional.gelu(y)),
+                      (N.EPI_GATE_RESIDUAL, res + gate.repeat_interleave(150, 0) * y)):
+        out = torch.empty(M, Nn, dtype=BF16, device="cuda")
+        N.check(N.lib().fdm_gemm_bf16(out.data_ptr(), ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), M, Nn, Kd, Kd, Kd, Nn, epi,
+                                      gd.data_ptr(), rd.data_ptr(), 150, N.stream()), "gemm_bf16")
+        ulp_close(out, want, 0.03, f"bf16 gemm epi {epi}", ulps=2)
+
+
+ATT_SHAPES = [  # /root/reference/tests/test_attention.py:7-21  (B, Sq, Skv, H, hd)
+    (1, 4608, 4608, 24, 128), (1, 4110, 4110, 24, 128), (2, 4096, 4096, 10, 64), (2, 4096, 77, 10, 64), (2, 1024, 1024, 20, 64),
+    (2, 1024, 77, 20, 64), (1, 4106, 4106, 24, 128), (2, 4685, 4685, 24, 64), (1, 8704, 8704, 24, 128),
+]
+
+
+@pytest.mark.parametrize("B,Sq,Sk,H,hd", ATT_SHAPES)
+def test_attention_reference_shapes(K, B, Sq, Sk, H, hd):
+    torch.manual_seed(0)
+    g = gen(Sq + Sk + H)
+    q, k, v = rbf(g, B, Sq, H * hd), rbf(g, B, Sk, H * hd), rbf(g, B, Sk, H * hd)
+    got = K.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5).cpu()
+    assert torch.isfinite(got.float()).all()
+    rows = sample_rows(Sq, 24)
+    heads = sorted({0, H - 1, H // 2})
+    hsel = torch.cat([torch.arange(h * hd, (h + 1) * hd) for h in heads])
+    ref = O.scaled_dot_product_attention(q[:, rows][:, :, hsel].contiguous(), k[:, :, hsel].contiguous(), v[:, :, hsel].contiguous(),
+                                         len(heads), len(heads), hd, scale=hd ** -0.5)
+    sub = got[:, rows][:, :, hsel]
+    torch.testing.assert_close(sub, ref, rtol=0.0, atol=1.8e-2)
+    assert (sub.float() - ref.float()).abs().mean() < 1.5e-3
+
+
+def test_attention_rescale_branch_forced(K):
+    """A late key that dominates one query row (online-softmax max jumps at a chosen tile)."""
+    g = gen(9)
+    B, S, H, hd = 1, 700, 2, 128
+    q, k, v = rbf(g, B, S, H * hd), rbf(g, B, S, H * hd), rbf(g, B, S, H * hd)
+    k[0, 650, :hd] = q[0, 5, :hd] * 4.0          # spike for row 5, head 0 in the last tiles
+    k[0, 3, hd:] = q[0, 300, hd:] * 6.0          # spike in the first tile for row 300, head 1
+    got = K.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5).cpu()
+    ref = O.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5)
+    torch.testing.assert_close(got, ref, rtol=0.0, atol=1.8e-2)
+
+
+def test_sparse_attention_masks(K):
+    """All-ones mask == dense (the reference's only sparse test, tests/test_sparge_attention.py:81);
+    a banded mask against the oracle's -inf definition."""
+    g = gen(10)
+    B, S, H, hd = 1, 1000, 3, 128
+    q, k, v = rbf(g, B, S, H * hd), rbf(g, B, S, H * hd), rbf(g, B, S, H * hd)
+    nq, nk = -(-S // 128), -(-S // 64)
+    ones = torch.ones(B, H, nq, nk, dtype=torch.int8)
+    dense = K.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5)
+    sp = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=ones.cuda())
+    assert torch.equal(dense, sp)
+    band = torch.zeros(B, H, nq, nk, dtype=torch.int8)
+    for i in range(nq):
+        for j in range(nk):
+            if abs(2 * i - j) <= 2 + i % 3 or j == 0:
+                band[:, :, i, j] = 1
+    band[:, 1] = torch.roll(band[:, 1], 1, dims=-1) | band[:, 1]
+    got = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=band.cuda()).cpu()
+    ref = O.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5, block_mask=band)
+    torch.testing.assert_close(got, ref, rtol=0.0, atol=1.8e-2)
+
+
+@pytest.mark.parametrize("rows,d", [(8192, 5120), (2048, 10240), (7, 8)])
+def test_gelu_and_mul_shapes(K, rows, d):
+    g = gen(rows + d)
+    x = rbf(g, rows, 2 * d, scale=1.5)
+    ulp_close(K.gelu_and_mul(x.cuda()), O.gelu_and_mul(x), 0.01, "gelu_and_mul")
+
+
+def test_error_behaviour(K):
+    x = torch.zeros(4, 100, dtype=BF16, device="cuda")
+    with pytest.raises(RuntimeError):
+        K.rms_norm(x, torch.ones(100, dtype=BF16, device="cuda"), 1e-6)    # hidden % 8 != 0 -> native layer rejects
+    with pytest.raises(AssertionError):
+        K.quantize_to_fp8(torch.zeros(2, 2, 16, dtype=BF16, device="cuda"))
+    a = torch.zeros(16, 32, dtype=FP8, device="cuda")
+    with pytest.raises(RuntimeError):
+        K.fp8_matmul(a, torch.zeros(32, 16, dtype=FP8, device="cuda"), torch.ones(16, 1, device="cuda"), torch.ones(16, 1, device="cuda"), BF16)
+    # empty inputs are fine
+    q, s = K.quantize_to_fp8(torch.zeros(0, 64, dtype=BF16, device="cuda"))
+    assert q.shape == (0, 64) and s.shape == (0, 1)
