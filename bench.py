@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: FLUX.1-dev denoise step, fp8 W8A8, 1024x2048 (S = 8192 image + 512 text
+tokens), 25-step flow-match schedule, synthetic weights and prompts (BASELINE.json configs[2]).
+
+    python bench.py --gpus 1 --steps 25 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path: one transformer forward (19 double + 38 single blocks, full
+width) plus the Euler latent update, with every input already resident in HBM.  With N GPUs each rank
+denoises its own image (batch sharded, weights replicated, no per-step exchange) and the ranks meet
+once in an RCCL all-gather of the final latents; `value` is the whole-job denoise rate
+(N * K / max-over-ranks time).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_TFLOPS = {"fp8": 5000.0, "bf16": 2500.0, "int8": 5000.0}   # dense MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+IMAGE_STEPS = 25
+
+
+def cpu_baseline_leg(height, width, n_txt, quant_tag):
+    """The oracle (CPU restatement of the reference's torch backend) timed on this box's host cores
+    on a bounded sample: ONE double-stream + ONE single-stream FLUX block at full width (S = 8704),
+    extrapolated x19 / x38 to a denoise step (a full step is 165 TFLOP)."""
+    from oracle import flux as OF
+    cfg = OF.FluxConfig(num_layers=1, num_single_layers=1)
+    quant = {"fp8": torch.float8_e4m3fn, "int8": torch.int8, "bf16": None}[quant_tag]
+    sd = {}
+    for name, shape, kind in OF.param_specs(cfg):
+        if name.startswith(("transformer_blocks.0.", "single_transformer_blocks.0.")):
+            sd[name] = OF.synth_tensor(name, shape, kind, 0)
+    dbl = OF.FluxTransformerBlock(sd, 0, cfg, quant)
+    sgl = OF.FluxSingleTransformerBlock(sd, 0, cfg, quant)
+    n_img = (height // 16) * (width // 16)
+    g = torch.Generator().manual_seed(0)
+    hidden = torch.randn(1, n_img, cfg.inner_dim, generator=g).to(torch.bfloat16)
+    enc = torch.randn(1, n_txt, cfg.inner_dim, generator=g).to(torch.bfloat16)
+    temb = torch.randn(1, cfg.inner_dim, generator=g).to(torch.bfloat16)
+    inp = OF.synth_inputs(cfg, 1, 2, 2, 4)
+    from oracle import layers as OL
+    ids = torch.zeros(n_img, 3)
+    rope = OL.flux_rope_cache(torch.zeros(n_txt, 3), ids, cfg.axes_dims_rope)
+    del inp
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        enc2, hid2 = dbl(hidden, enc, temb, rope)
+        t1 = time.perf_counter()
+        sgl(torch.cat([enc2, hid2], dim=1), temb, rope)
+        t2 = time.perf_counter()
+    step_s = 19 * (t1 - t0) + 38 * (t2 - t1)
+    return {"value": 1.0 / step_s, "unit": "it/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (torch-CPU restatement of the reference torch backend, {quant_tag}): 1 double block "
+                      f"{t1 - t0:.1f}s + 1 single block {t2 - t1:.1f}s at full width S={n_img + n_txt}, extrapolated x19/x38 "
+                      f"to one denoise step ({step_s:.0f}s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=IMAGE_STEPS)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--max-seq-len", type=int, default=512)
+    ap.add_argument("--quant", choices=["fp8", "int8", "bf16"], default="fp8")
+    ap.add_argument("--cache-config", default=None, help="TeaCache JSON (changes the metric: reported as a different workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event spans")
+    args = ap.parse_args()
+
+    from fastdm_amd import distributed as D
+    rank, world, local_rank = D.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from fastdm_amd.caching import AutoCache
+    from fastdm_amd.kernel import timing
+    from fastdm_amd.model_entry import create_model
+    from fastdm_amd.pipeline import SyntheticFluxPipeline, flow_match_sigmas
+    from fastdm_amd.synthetic import SyntheticFluxStateDict
+
+    quant = {"fp8": torch.float8_e4m3fn, "int8": torch.int8, "bf16": None}[args.quant]
+    cache = AutoCache.from_json(args.cache_config) if args.cache_config else None
+    model = create_model("flux", ckpt_path=SyntheticFluxStateDict(seed=0), dtype=torch.bfloat16, quant_type=quant,
+                         kernel_backend="hip", cache=cache).eval()
+    pipe = SyntheticFluxPipeline(model, seed=0)
+    if cache:
+        cache.config.current_steps_callback = lambda: pipe.scheduler_step_index
+    # rank r denoises image r of the global batch (different latents/prompt per image)
+    inp = pipe.prepare(1, args.height, args.width, args.max_seq_len, seed=rank)
+    n_img = inp["hidden_states"].shape[1]
+    sig = flow_match_sigmas(IMAGE_STEPS, n_img)
+    guidance = torch.full((1,), 3.5, device=dev, dtype=torch.float32)
+
+    state = {"lat": inp["hidden_states"].clone(), "i": 0}
+
+    def one_step():
+        i = state["i"] % IMAGE_STEPS
+        if i == 0:
+            state["lat"] = inp["hidden_states"].clone()
+        pipe.scheduler_step_index = i
+        t = torch.full((1,), float(sig[i]), device=dev, dtype=torch.bfloat16)
+        with model.cache_context("cond"):
+            v = model(hidden_states=state["lat"], timestep=t, guidance=guidance, pooled_projections=inp["pooled_projections"],
+                      encoder_hidden_states=inp["encoder_hidden_states"], txt_ids=inp["txt_ids"], img_ids=inp["img_ids"],
+                      joint_attention_kwargs=None, return_dict=False)[0]
+        state["lat"] = (state["lat"].float() + float(sig[i + 1] - sig[i]) * v.float()).to(torch.bfloat16)
+        state["i"] += 1
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            one_step()
+        state["i"] = 0
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+        rec = timing.Recorder() if not args.no_kernel_timing else None
+        t0 = time.perf_counter()
+        if rec:
+            rec.__enter__()
+        for _ in range(args.steps):
+            one_step()
+        if rec:
+            rec.__exit__(None, None, None)
+        final = D.gather_latents(state["lat"], world, rank, world)      # the job's single collective (RCCL all-gather)
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed, dev)
+    assert torch.isfinite(final.float()).all(), "non-finite latents"
+
+    if rank != 0:
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    skipped = 0
+    if cache is not None:
+        skipped = sum(1 for t in cache.trace[-args.steps:] if not t[3])
+    workload = (f"FLUX.1-dev {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step flow-match schedule, "
+                f"batch 1 per GPU, 19 double + 38 single blocks" + (f", TeaCache ({skipped}/{args.steps} steps skipped)" if cache else ""))
+    out = {
+        "metric": "denoise it/s (sec/image = 25 / (value / n_gpus)), FLUX 1024x2048 fp8 @25 steps",
+        "value": world * args.steps / elapsed,
+        "unit": "it/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "sec_per_image": ms_per_step * IMAGE_STEPS / 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": {"fp8": "fp8_e4m3 W8A8 GEMM (fp32 accumulate) + bf16 attention", "int8": "int8 W8A8 + bf16 attention", "bf16": "bf16"}[args.quant],
+        "data": "synthetic (counter-based random weights of the FLUX.1-dev architecture, U[0,1) latents/prompt embeddings)",
+        "config": {"workload": workload, "global_batch": world, "height": args.height, "width": args.width, "parallelism": f"dp{world} (image-sharded, one all-gather of final latents)"},
+    }
+    if rec:
+        summ = rec.summary()
+        kernels = {}
+        for name, s in summ.items():
+            dt = "bf16" if "bf16" in name else ("int8" if "int8" in name else "fp8")
+            tf = s["work"] / (s["total_ms"] * 1e-3) / 1e12
+            kernels[name] = {"launches_per_step": s["launches"] / args.steps, "avg_ms": s["avg_ms"], "ms_per_step": s["total_ms"] / args.steps,
+                             "achieved_TFLOPs": tf, "peak_TFLOPs": PEAK_TFLOPS[dt], "frac": tf / PEAK_TFLOPS[dt]}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["achieved_TFLOPs"], "peak": kernels[dom]["peak_TFLOPs"],
+                           "unit": "TFLOP/s", "frac": kernels[dom]["frac"], "traffic": None,
+                           "avg_launch_ms": kernels[dom]["avg_ms"]}
+        out["kernels"] = kernels
+        flops_step = sum(s["work"] for s in summ.values()) / args.steps
+        out["step_TFLOP"] = flops_step / 1e12
+        out["step_achieved_TFLOPs"] = flops_step / (ms_per_step * 1e-3) / 1e12
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline_leg(args.height, args.width, args.max_seq_len, args.quant)
+        except Exception as e:  # noqa: BLE001  -- the baseline leg must never take the GPU number down with it
+            out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e}"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

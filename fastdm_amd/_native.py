@@ -24,9 +24,9 @@ SIGNATURES = {
     "fdm_quant_fp8_rowwise": (I32, [P, P, P, I64, I32, I64, P]),
     "fdm_quant_int8_rowwise": (I32, [P, P, P, P, I64, I32, I64, P]),
     "fdm_gelu_and_mul": (I32, [P, P, I64, I32, P]),
-    "fdm_gemm_w8a8_fp8": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, P, I64, P]),
-    "fdm_gemm_w8a8_int8": (I32, [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, P]),
-    "fdm_gemm_bf16": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, P, I64, P]),
+    "fdm_gemm_w8a8_fp8": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
+    "fdm_gemm_w8a8_int8": (I32, [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
+    "fdm_gemm_bf16": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_attn_fwd": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I32, I32, P]),
     "fdm_ln_modulate": (I32, [P, P, P, P, I32, P, P, P, I64, P, P, P, I64, I32, I64, F32, P]),
     "fdm_gate_residual": (I32, [P, P, P, P, I64, I64, I32, I64, P]),

@@ -1,0 +1,120 @@
+"""TeaCache step skipping, host side (mirror of fastdm/caching/xcaching.py:9-276 for FLUX).
+
+The decision stays on the host as the north star asks: one device-side reduction
+(fdm_absdiff_sums) produces sum|mod - prev| and sum|prev|; two floats cross PCIe (the reference's
+`.cpu().item()` sync, xcaching.py:214-215); the polynomial rescale and threshold test are Python.
+The reference evaluates the ratio on bf16 tensors, so the means and the quotient are rounded to
+bf16 here as well before they reach the polynomial.
+"""
+from typing import Any, Dict, Optional, Type
+
+import numpy as np
+import torch
+
+from fastdm_amd.caching.config import CacheConfig
+from fastdm_amd.kernel import fused
+
+
+def _bf16(x: float) -> float:
+    return float(torch.tensor(x, dtype=torch.float32).to(torch.bfloat16).float())
+
+
+class AutoCache:
+    _registry: Dict[str, Type["AutoCache"]] = {}
+
+    def __init__(self, config: CacheConfig):
+        self.config = config
+        self.accumulated_rel_l1_distance_dict = {"positive": 0.0, "negative": 0.0}
+        self.previous_modulated_input_dict = {"positive": None, "negative": None}
+        self.previous_residual_dict = {"positive": None, "negative": None}
+        self.cache_status = {"positive": True, "negative": False}
+        self.trace = []   # (step, rel_distance | None, accumulated, should_calc): for tests / logging
+
+    @classmethod
+    def register(cls, name: str):
+        def decorator(sub_cls):
+            cls._registry[name.lower()] = sub_cls
+            return sub_cls
+        return decorator
+
+    @classmethod
+    def _make(cls, config: CacheConfig) -> "AutoCache":
+        cache_cls = cls._registry.get(config.cache_algorithm.lower())
+        if cache_cls is None:
+            raise ValueError(f"Unknown cache algorithm: {config.cache_algorithm.lower()}")
+        return cache_cls(config)
+
+    @classmethod
+    def from_dict(cls, data: Dict[str, Any]) -> "AutoCache":
+        return cls._make(CacheConfig.from_dict(data))
+
+    @classmethod
+    def from_json(cls, file_path: str) -> "AutoCache":
+        return cls._make(CacheConfig.from_json(file_path))
+
+    def get_current_step(self):
+        cb = self.config.current_steps_callback
+        step = cb() if cb is not None else None
+        return step if step is not None else 0
+
+    def get_cache_key(self):
+        """xcaching.py:66-76: alternate positive/negative on successive calls when negtive_cache is set."""
+        if not self.config.negtive_cache:
+            return "positive"
+        cache_key = None
+        for k in self.cache_status:
+            if self.cache_status[k] and cache_key is None:
+                cache_key = k
+            self.cache_status[k] = not self.cache_status[k]
+        return cache_key
+
+    def apply_cache(self, *args, **kwargs):
+        raise NotImplementedError("Subclasses must implement apply_cache method")
+
+
+@AutoCache.register("teacache")
+class TeaCache(AutoCache):
+    def __init__(self, config):
+        super().__init__(config)
+        self.coefficients = {"positive": config.coefficients, "negative": config.negtive_coefficients}
+
+    def _get_modulated_input(self, model_type, hidden_states, temb, transformer_blocks):
+        """xcaching.py:165-183: the first block's norm1 output (bf16 [B,S,D])."""
+        if model_type not in ("flux", "sd35"):
+            raise ValueError(f"TeaCache unsupported model type: {model_type}. Supported types: flux")
+        return transformer_blocks[0].norm1.forward(hidden_states, emb=temb)[0]
+
+    def rel_distance(self, modulated, previous) -> float:
+        sums = fused.absdiff_sums(modulated.contiguous(), previous.contiguous()).cpu()     # the one D2H sync per step
+        n = float(modulated.numel())
+        mean_diff, mean_prev = _bf16(float(sums[0]) / n), _bf16(float(sums[1]) / n)
+        return _bf16(mean_diff / mean_prev)
+
+    def apply_cache(self, model_type: str, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
+                    temb: torch.Tensor = None, image_rotary_emb: torch.Tensor = None, attention_kwargs: Optional[Dict[str, Any]] = None,
+                    transformer_blocks=None, single_transformer_blocks=None, core=None, **_):
+        """xcaching.py:187-276 (FLUX branch)."""
+        current_step = self.get_current_step()
+        modulated_inp = self._get_modulated_input(model_type, hidden_states, temb, transformer_blocks)
+        cache_key = self.get_cache_key()
+        rel = None
+        if current_step == 0:
+            should_calc = True
+            self.accumulated_rel_l1_distance_dict[cache_key] = 0
+        else:
+            rescale_func = np.poly1d(self.coefficients[cache_key])
+            rel = self.rel_distance(modulated_inp, self.previous_modulated_input_dict[cache_key])
+            self.accumulated_rel_l1_distance_dict[cache_key] += rescale_func(rel)
+            if self.accumulated_rel_l1_distance_dict[cache_key] < self.config.threshold:
+                should_calc = False
+            else:
+                should_calc = True
+                self.accumulated_rel_l1_distance_dict[cache_key] = 0
+        self.trace.append((current_step, rel, float(self.accumulated_rel_l1_distance_dict[cache_key]), should_calc))
+        self.previous_modulated_input_dict[cache_key] = modulated_inp
+        if not should_calc:
+            return hidden_states + self.previous_residual_dict[cache_key]
+        ori_hidden_states = hidden_states.clone()     # the fused blocks update the residual stream in place
+        out = core.run_blocks(hidden_states, encoder_hidden_states, temb, image_rotary_emb, attention_kwargs)
+        self.previous_residual_dict[cache_key] = out - ori_hidden_states
+        return out

@@ -169,7 +169,7 @@ __device__ __forceinline__ void quant_row_cached(const Vec8 (&x)[MAXV], int nvec
   float scale, zpf = 0.f;
   if constexpr (MODE == 1) {
     amax = block_reduce<THREADS>(amax, OpMax(), smem);
-    amax = fmaxf(amax, 9.9920072216264089e-13f);  // bf16(1e-12): the clamp runs on the bf16 tensor
+    amax = fmaxf(amax, __builtin_bit_cast(float, 0x2B8D0000u));  // bf16(1e-12): the clamp runs on the bf16 tensor
     scale = amax / 448.0f;
   } else if constexpr (MODE == 3) {
     amax = block_reduce<THREADS>(amax, OpMax(), smem);
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256) quant_rowwise_wide_kernel(uint8_t* __rest
   }
   float sc, zpf = 0.f;
   if constexpr (MODE == 1) {
-    amax = fmaxf(block_reduce<256>(amax, OpMax(), smem), 9.9920072216264089e-13f);
+    amax = fmaxf(block_reduce<256>(amax, OpMax(), smem), __builtin_bit_cast(float, 0x2B8D0000u));
     sc = amax / 448.0f;
   } else if constexpr (MODE == 3) {
     sc = block_reduce<256>(amax, OpMax(), smem) / 127.0f;
@@ -555,6 +555,7 @@ static int launch_ln(void* out_bf16, void* out_q, float* out_scale, int32_t* out
 extern "C" {
 
 int fdm_rms_norm(void* out, const void* in, const void* weight, float eps, int64_t rows, int hidden, fdm_stream_t stream) {
+  if (rows == 0 && hidden > 0 && !(hidden & 7)) return FDM_OK;
   if (!out || !in || !weight || rows < 0 || hidden <= 0 || (hidden & 7) || !aligned16(out) || !aligned16(in) || !aligned16(weight))
     return FDM_ERR_INVALID;
   if (rows == 0) return FDM_OK;
@@ -609,6 +610,7 @@ int fdm_rope_inplace(void* q, void* k, const void* cos_sin_cache, int64_t tokens
 
 int fdm_quant_rowwise_cat2(void* q_out, float* scale_out, int32_t* azp_out, int quant_mode, const void* src0, int w0,
                            int64_t stride0, const void* src1, int w1, int64_t stride1, int64_t rows, fdm_stream_t stream) {
+  if (rows == 0 && w0 > 0 && !(w0 & 7) && w1 >= 0 && !(w1 & 7)) return FDM_OK;
   if (!q_out || !scale_out || !src0 || w0 <= 0 || (w0 & 7) || (w1 & 7) || w1 < 0 || (stride0 & 7) || (stride1 & 7) || rows < 0)
     return FDM_ERR_INVALID;
   if ((w1 > 0) != (src1 != nullptr)) return FDM_ERR_INVALID;

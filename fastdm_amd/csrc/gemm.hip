@@ -38,6 +38,7 @@ struct GemmParams {
   const bf16_t* gate;
   const bf16_t* res;
   int64_t rows_per_batch;
+  int64_t gate_stride;
   int M, N;
   int64_t Kb;        // K in bytes
   int64_t lda, ldb;  // bytes
@@ -238,7 +239,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmParams 
           if constexpr (EPI == FDM_EPI_GELU_ERF) y = gelu_erf_f(y);
           if constexpr (EPI == FDM_EPI_GATE_RESIDUAL) {
             const int64_t b = m / p.rows_per_batch;
-            const float gt = bf2f(p.gate[b * p.N + n]);
+            const float gt = bf2f(p.gate[b * p.gate_stride + n]);
             y = bf2f(p.res[(int64_t)m * p.ldc + n]) + rbf(gt * y);
           }
           p.C[(int64_t)m * p.ldc + n] = f2bf(y);
@@ -263,7 +264,9 @@ static int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
 }
 
 static int fill_params(GemmParams& p, void* out, const void* a, const void* b, int64_t M, int64_t N, int64_t K, int64_t lda,
-                       int64_t ldb, int64_t ldc, int elem_bytes, int epi, const void* gate, const void* res, int64_t rpb) {
+                       int64_t ldb, int64_t ldc, int elem_bytes, int epi, const void* gate, int64_t gate_stride, const void* res,
+                       int64_t rpb) {
+  if (M == 0 && N > 0 && K > 0) return FDM_OK;  // callers re-check M == 0 before launching
   if (!out || !a || !b || M < 0 || N <= 0 || K <= 0) return FDM_ERR_INVALID;
   if (M > 0x7fffffff || N > 0x7fffffff) return FDM_ERR_UNSUPPORTED;
   if ((K * elem_bytes) % 16 || (lda * elem_bytes) % 16 || (ldb * elem_bytes) % 16 || lda < K || ldb < K || ldc < N)
@@ -277,6 +280,7 @@ static int fill_params(GemmParams& p, void* out, const void* a, const void* b, i
   p.gate = (const bf16_t*)gate;
   p.res = (const bf16_t*)res;
   p.rows_per_batch = rpb > 0 ? rpb : 1;
+  p.gate_stride = gate_stride;
   p.M = (int)M;
   p.N = (int)N;
   p.Kb = K * elem_bytes;
@@ -299,10 +303,12 @@ extern "C" {
 
 int fdm_gemm_w8a8_fp8(void* out, const void* a, const void* b, const float* scale_a, const float* scale_b, const void* bias,
                       int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int epilogue,
-                      const void* epi_gate, const void* epi_res, int64_t epi_rows_per_batch, fdm_stream_t stream) {
+                      const void* epi_gate, int64_t epi_gate_stride, const void* epi_res, int64_t epi_rows_per_batch,
+                      fdm_stream_t stream) {
   GemmParams p;
-  int rc = fill_params(p, out, a, b, M, N, K, lda, ldb, ldc, 1, epilogue, epi_gate, epi_res, epi_rows_per_batch);
+  int rc = fill_params(p, out, a, b, M, N, K, lda, ldb, ldc, 1, epilogue, epi_gate, epi_gate_stride, epi_res, epi_rows_per_batch);
   if (rc != FDM_OK) return rc;
+  if (M == 0) return FDM_OK;
   if (!scale_a || !scale_b) return FDM_ERR_INVALID;
   if (M == 0) return FDM_OK;
   p.sa = scale_a;
@@ -313,10 +319,12 @@ int fdm_gemm_w8a8_fp8(void* out, const void* a, const void* b, const float* scal
 
 int fdm_gemm_w8a8_int8(void* out, const void* a, const void* b, const float* scale_a, const float* scale_b,
                        const int32_t* azp_adj, const int32_t* azp, const void* bias, int64_t M, int64_t N, int64_t K,
-                       int64_t lda, int64_t ldb, int64_t ldc, fdm_stream_t stream) {
+                       int64_t lda, int64_t ldb, int64_t ldc, int epilogue, const void* epi_gate, int64_t epi_gate_stride,
+                       const void* epi_res, int64_t epi_rows_per_batch, fdm_stream_t stream) {
   GemmParams p;
-  int rc = fill_params(p, out, a, b, M, N, K, lda, ldb, ldc, 1, FDM_EPI_NONE, nullptr, nullptr, 0);
+  int rc = fill_params(p, out, a, b, M, N, K, lda, ldb, ldc, 1, epilogue, epi_gate, epi_gate_stride, epi_res, epi_rows_per_batch);
   if (rc != FDM_OK) return rc;
+  if (M == 0) return FDM_OK;
   if (!scale_a || !scale_b || ((azp == nullptr) != (azp_adj == nullptr))) return FDM_ERR_INVALID;
   if (M == 0) return FDM_OK;
   p.sa = scale_a;
@@ -324,15 +332,16 @@ int fdm_gemm_w8a8_int8(void* out, const void* a, const void* b, const float* sca
   p.bias = (const bf16_t*)bias;
   p.azp = azp;
   p.azp_adj = azp_adj;
-  return launch_gemm<DT_INT8>(p, FDM_EPI_NONE, to_stream(stream));
+  return launch_gemm<DT_INT8>(p, epilogue, to_stream(stream));
 }
 
 int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
-                  int64_t ldb, int64_t ldc, int epilogue, const void* epi_gate, const void* epi_res,
+                  int64_t ldb, int64_t ldc, int epilogue, const void* epi_gate, int64_t epi_gate_stride, const void* epi_res,
                   int64_t epi_rows_per_batch, fdm_stream_t stream) {
   GemmParams p;
-  int rc = fill_params(p, out, a, b, M, N, K, lda, ldb, ldc, 2, epilogue, epi_gate, epi_res, epi_rows_per_batch);
+  int rc = fill_params(p, out, a, b, M, N, K, lda, ldb, ldc, 2, epilogue, epi_gate, epi_gate_stride, epi_res, epi_rows_per_batch);
   if (rc != FDM_OK) return rc;
+  if (M == 0) return FDM_OK;
   if (M == 0) return FDM_OK;
   p.bias = (const bf16_t*)bias;
   return launch_gemm<DT_BF16>(p, epilogue, to_stream(stream));

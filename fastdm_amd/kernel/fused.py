@@ -1,0 +1,116 @@
+"""Python entry points of the fused HIP kernels the FLUX wiring uses (C ABI: include/fastdm_amd.h).
+
+Activations are 2-D row-major bf16 matrices [rows, width]; `rows_per_batch` tells a kernel which
+row of a per-batch modulation vector applies.  Nothing here computes on the host.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from fastdm_amd import _native as N
+from fastdm_amd.kernel.timing import span
+
+BF16 = torch.bfloat16
+FP8 = torch.float8_e4m3fn
+QUANT_MODE = {None: 0, FP8: 1, torch.int8: 2}
+
+
+class Quantized:
+    """A per-row quantised activation: q [M,K] (fp8 / int8), scale [M,1] f32, azp [M,1] i32 | None."""
+    __slots__ = ("q", "scale", "azp")
+
+    def __init__(self, q, scale, azp=None):
+        self.q, self.scale, self.azp = q, scale, azp
+
+
+def _alloc_q(rows, width, quant, device):
+    q = torch.empty((rows, width), device=device, dtype=quant)
+    s = torch.empty((rows, 1), device=device, dtype=torch.float32)
+    zp = torch.empty((rows, 1), device=device, dtype=torch.int32) if quant == torch.int8 else None
+    return Quantized(q, s, zp)
+
+
+def ln_modulate(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, rows_per_batch: int, quant=None,
+                want_bf16: bool = False, res: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+                eps: float = 1e-6) -> Tuple[Optional[torch.Tensor], Optional[Quantized], Optional[torch.Tensor]]:
+    """y = LN(x)*(1+scale)+shift (torch bf16 rounding order), optionally quantised per row.
+
+    scale/shift/gate are [B, width] views (any batch stride, unit inner stride).  With res/gate:
+    x := res + gate*x first; the updated x is returned as the third value.
+    """
+    rows, width = x.shape
+    assert x.is_contiguous() and scale.stride(-1) == 1 and shift.stride(-1) == 1 and scale.stride(0) == shift.stride(0)
+    out = torch.empty_like(x) if (want_bf16 or quant is None) else None
+    qz = _alloc_q(rows, width, quant, x.device) if quant is not None else None
+    x_new = torch.empty_like(x) if res is not None else None
+    if gate is not None:
+        assert gate.stride(0) == scale.stride(0) and gate.stride(-1) == 1
+    N.check(N.lib().fdm_ln_modulate(N.ptr(out), N.ptr(qz.q) if qz else None, N.ptr(qz.scale) if qz else None,
+                                    N.ptr(qz.azp) if (qz and qz.azp is not None) else None, QUANT_MODE[quant], N.ptr(x),
+                                    N.ptr(scale), N.ptr(shift), scale.stride(0), N.ptr(res), N.ptr(gate), N.ptr(x_new), rows,
+                                    width, rows_per_batch, eps, N.stream()), "ln_modulate")
+    return out, qz, x_new
+
+
+def gate_residual(res: torch.Tensor, y: torch.Tensor, gate: torch.Tensor, rows_per_batch: int) -> torch.Tensor:
+    """res + gate[b]*y (model/flux.py:153-154)."""
+    rows, width = res.shape
+    assert res.is_contiguous() and y.is_contiguous() and gate.stride(-1) == 1
+    out = torch.empty_like(res)
+    N.check(N.lib().fdm_gate_residual(N.ptr(out), N.ptr(res), N.ptr(y), N.ptr(gate), gate.stride(0), rows, width, rows_per_batch,
+                                      N.stream()), "gate_residual")
+    return out
+
+
+def gelu(x: torch.Tensor, approximate: str = "none") -> torch.Tensor:
+    assert x.is_contiguous() and x.dtype == BF16
+    out = torch.empty_like(x)
+    N.check(N.lib().fdm_gelu(N.ptr(out), N.ptr(x), x.numel(), 1 if approximate == "tanh" else 2, N.stream()), "gelu")
+    return out
+
+
+def quantize_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], quant) -> Quantized:
+    """Per-row quantisation of [x0 | x1] without materialising the concatenation (model/flux.py:69)."""
+    rows, w0 = x0.shape
+    w1 = 0 if x1 is None else x1.shape[1]
+    assert x0.stride(1) == 1 and (x1 is None or (x1.stride(1) == 1 and x1.shape[0] == rows))
+    qz = _alloc_q(rows, w0 + w1, quant, x0.device)
+    N.check(N.lib().fdm_quant_rowwise_cat2(N.ptr(qz.q), N.ptr(qz.scale), N.ptr(qz.azp), QUANT_MODE[quant], N.ptr(x0), w0,
+                                           x0.stride(0), N.ptr(x1), w1, 0 if x1 is None else x1.stride(0), rows, N.stream()),
+            "quant_rowwise")
+    return qz
+
+
+def qk_norm_rope(qkv: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, rope: Optional[torch.Tensor], q_out, k_out, v_out,
+                 rows_per_batch: int, seq_total: int, seq_offset: int, heads: int, head_dim: int, eps: float = 1e-6):
+    """RMS-norm(q,k) -> RoPE -> scatter into the joint [text ; image] q/k/v buffers [B*seq_total, heads*hd]."""
+    rows = qkv.shape[0]
+    assert qkv.is_contiguous() and qkv.shape[1] == 3 * heads * head_dim
+    N.check(N.lib().fdm_qk_norm_rope(N.ptr(q_out), N.ptr(k_out), N.ptr(v_out), N.ptr(qkv), N.ptr(wq), N.ptr(wk), N.ptr(rope), rows,
+                                     rows_per_batch, seq_total, seq_offset, heads, head_dim, eps, N.stream()), "qk_norm_rope")
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, head_dim: int, scale: float) -> torch.Tensor:
+    """Dense attention on [B*S, H*D] buffers (same kernel as operators_set.scaled_dot_product_attention)."""
+    S = q.shape[0] // batch
+    Sk = k.shape[0] // batch
+    out = torch.empty_like(q)
+    with span("attn_fwd_bf16", 4.0 * batch * S * Sk * heads * head_dim):
+        N.check(N.lib().fdm_attn_fwd(N.ptr(out), N.ptr(q), N.ptr(k), N.ptr(v), batch, S, Sk, heads, heads, head_dim,
+                                     q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), None, 0, 0, N.stream()),
+                "attention")
+    return out
+
+
+def absdiff_sums(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[sum|a-b|, sum|b|] in fp32 on the device (TeaCache metric, caching/xcaching.py:214)."""
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    out = torch.zeros(2, device=a.device, dtype=torch.float32)
+    N.check(N.lib().fdm_absdiff_sums(N.ptr(out), N.ptr(a), N.ptr(b), a.numel(), N.stream()), "absdiff_sums")
+    return out
+
+
+def synth_fill(out: torch.Tensor, seed: int, kind: int, scale: float = 0.0, offset: float = 0.0):
+    assert out.dtype == BF16 and out.is_contiguous()
+    N.check(N.lib().fdm_synth_fill_bf16(N.ptr(out), out.numel(), seed, kind, scale, offset, N.stream()), "synth_fill")
+    return out

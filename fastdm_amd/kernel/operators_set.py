@@ -117,7 +117,7 @@ def fp8_matmul(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b:
     Nn = b.shape[1]
     out = torch.empty((M, Nn), device=a.device, dtype=out_dtype)
     N.check(N.lib().fdm_gemm_w8a8_fp8(N.ptr(out), N.ptr(a), N.ptr(b), N.ptr(scale_a), N.ptr(scale_b), N.ptr(bias), M, Nn, K,
-                                      a.stride(0), b.stride(1), Nn, N.EPI_NONE, None, None, 0, N.stream()), "fp8_matmul")
+                                      a.stride(0), b.stride(1), Nn, N.EPI_NONE, None, 0, None, 0, N.stream()), "fp8_matmul")
     return out
 
 
@@ -133,7 +133,8 @@ def int8_matmul(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b
     assert azp.dtype == torch.int32 and azp_adj.dtype == torch.int32
     out = torch.empty((M, Nn), device=a.device, dtype=out_dtype)
     N.check(N.lib().fdm_gemm_w8a8_int8(N.ptr(out), N.ptr(a), N.ptr(b), N.ptr(scale_a), N.ptr(scale_b), N.ptr(azp_adj), N.ptr(azp),
-                                       N.ptr(bias), M, Nn, K, a.stride(0), b.stride(1), Nn, N.stream()), "int8_matmul")
+                                       N.ptr(bias), M, Nn, K, a.stride(0), b.stride(1), Nn, N.EPI_NONE, None, 0, None, 0,
+                                       N.stream()), "int8_matmul")
     return out
 
 

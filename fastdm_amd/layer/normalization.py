@@ -1,0 +1,108 @@
+"""AdaLN layers of the FLUX path (mirror of fastdm/layer/normalization.py:90-128,162-236).
+
+`forward` keeps the reference's signature/returns.  `modulation()` exposes the [B, n*D] projection
+so the block wiring can feed the fused LN+modulate(+quant) kernel; when the model core has batched
+every AdaLN projection of the step into one GEMM (`ModulationTable`), it returns that slice.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from fastdm_amd.kernel import fused
+from fastdm_amd.layer.qlinear import QLinear
+
+BF16 = torch.bfloat16
+
+
+class _AdaLNBase:
+    chunks = 0
+
+    def __init__(self, embedding_dim: int, cond_dim: Optional[int] = None, bias=True, eps=1e-6, data_type=BF16):
+        self.dim = embedding_dim
+        self.linear = QLinear(cond_dim or embedding_dim, self.chunks * embedding_dim, bias=bias, data_type=data_type)
+        self.norm_eps = eps
+        self._cached_mod = None     # set by ModulationTable for the current step
+
+    def modulation(self, emb: torch.Tensor) -> torch.Tensor:
+        """[B, chunks*D] = Linear(silu(emb)) (normalization.py:195,231; never quantised for FLUX)."""
+        if self._cached_mod is not None:
+            return self._cached_mod
+        return self.linear.forward(F.silu(emb))
+
+    def _apply(self, x, scale, shift):
+        B, S, D = x.shape
+        y, _, _ = fused.ln_modulate(x.reshape(B * S, D), scale, shift, S, quant=None, eps=self.norm_eps)
+        return y.view(B, S, D)
+
+
+class AdaLayerNormZero(_AdaLNBase):
+    """normalization.py:162-199."""
+    chunks = 6
+
+    def forward(self, x, emb=None):
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.modulation(emb).chunk(6, dim=1)
+        return self._apply(x, scale_msa, shift_msa), gate_msa, shift_mlp, scale_mlp, gate_mlp
+
+
+class AdaLayerNormZeroSingle(_AdaLNBase):
+    """normalization.py:201-236."""
+    chunks = 3
+
+    def forward(self, x, emb=None):
+        shift_msa, scale_msa, gate_msa = self.modulation(emb).chunk(3, dim=1)
+        return self._apply(x, scale_msa, shift_msa), gate_msa
+
+
+class AdaLayerNormContinuous(_AdaLNBase):
+    """normalization.py:90-128: chunks are (scale, shift) -- scale first."""
+    chunks = 2
+
+    def __init__(self, embedding_dim, conditioning_embedding_dim, elementwise_affine=False, eps=1e-5, bias=True, data_type=BF16):
+        assert not elementwise_affine, "FLUX uses elementwise_affine=False (model/flux.py:259)"
+        super().__init__(embedding_dim, conditioning_embedding_dim, bias=bias, eps=eps, data_type=data_type)
+
+    def forward(self, x, conditioning_embedding):
+        scale, shift = self.modulation(conditioning_embedding.to(x.dtype)).chunk(2, dim=1)
+        return self._apply(x, scale, shift)
+
+
+class ModulationTable:
+    """All AdaLN projections of one denoise step as ONE [B,3072] x [3072, sum(n_i)] GEMM.
+
+    Every AdaLN layer of FLUX consumes the same silu(temb) (model/flux.py:130-134,57; 6.46 GB of
+    bf16 weights per step).  The weights are concatenated once at load time
+    (each layer's QLinear keeps a view, so the layers still work on their own) and the step does a
+    single weight-streaming launch instead of 77 M=1 GEMVs.
+    """
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        ws = [l.linear.weight.t() for l in self.layers]            # [n_i, K] each (K contiguous)
+        K = ws[0].shape[1]
+        total = sum(w.shape[0] for w in ws)
+        dev = ws[0].device
+        w_all = torch.empty((total, K), device=dev, dtype=ws[0].dtype)
+        b_all = torch.empty((total,), device=dev, dtype=ws[0].dtype)
+        self.offsets = []
+        off = 0
+        for l, w in zip(self.layers, ws):
+            n = w.shape[0]
+            w_all[off:off + n].copy_(w)
+            b_all[off:off + n].copy_(l.linear.bias)
+            l.linear.weight = w_all[off:off + n].t()                # view into the table
+            l.linear.bias = b_all[off:off + n]
+            self.offsets.append((off, n))
+            off += n
+        self.table = QLinear(K, total, bias=True, data_type=ws[0].dtype)
+        self.table.weight, self.table.bias = w_all.t(), b_all
+        self.table.quant_type = None
+
+    def begin_step(self, temb: torch.Tensor):
+        mod = self.table.forward(F.silu(temb))                      # [B, total]
+        for l, (off, n) in zip(self.layers, self.offsets):
+            l._cached_mod = mod[:, off:off + n]
+
+    def end_step(self):
+        for l in self.layers:
+            l._cached_mod = None

@@ -1,0 +1,109 @@
+"""QLinear on the HIP library (mirror of fastdm/layer/qlinear.py:6-81).
+
+Same constructor, `weight_loading_and_quant(src_weight, src_bias, quant_type)` contract (weights
+arrive as [in, out] views, several are fused along N) and `forward`.  Differences by design:
+weights are moved to the GPU first and quantised there by the same row-quant kernel that quantises
+activations (identical arithmetic to fastdm/utils/quantization.py, verified bit-exact in the
+tests), instead of on the CPU; and `forward_q` exposes the GEMM epilogues to the block wiring.
+"""
+from typing import Optional
+
+import torch
+
+from fastdm_amd import _native as N
+from fastdm_amd.kernel import fused
+from fastdm_amd.kernel.fused import Quantized
+from fastdm_amd.kernel.timing import span
+
+BF16 = torch.bfloat16
+FP8 = torch.float8_e4m3fn
+
+
+class QLinear:
+    def __init__(self, in_features, out_features, bias=True, data_type=BF16, device_type="cuda"):
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = None              # [K, N] view with stride(0) == 1 (the reference's column-major layout)
+        self.bias = None
+        self.device = device_type
+        self.has_bias = bias
+        self.dtype = data_type
+        self.weight_quant_scale = None  # [N, 1] f32
+        self.weight_asym_sumcol = None  # [1, N] i32 (int8 only)
+        self.quant_type = None
+
+    # ------------------------------------------------------------------ loading
+    def weight_loading_and_quant(self, src_weight, src_bias, quant_type=None):
+        """fastdm/layer/qlinear.py:18-54.  src_weight: list of [K, N_i] tensors (transposed views of
+        the checkpoint's [N_i, K]); fused along N in list order."""
+        assert self.dtype == BF16, "bf16 activations only in this build"
+        w_nk = torch.cat([w.transpose(0, 1) for w in src_weight], dim=0).to(device=self.device, dtype=self.dtype).contiguous()
+        if src_bias[0] is not None:
+            assert self.has_bias, "Bias is not enabled but bias tensor is provided."
+            self.bias = torch.cat(list(src_bias), dim=0).to(device=self.device, dtype=self.dtype).contiguous()
+        self.set_weight_nk(w_nk, quant_type)
+
+    def set_weight_nk(self, w_nk: torch.Tensor, quant_type=None):
+        """w_nk: [N, K] bf16 on the GPU (K contiguous)."""
+        self.quant_type = quant_type
+        self.out_features, self.in_features = w_nk.shape
+        if quant_type is None:
+            self.weight = w_nk.t()
+        elif quant_type in (FP8, torch.int8):
+            n, k = w_nk.shape
+            q = torch.empty((n, k), device=w_nk.device, dtype=quant_type)
+            s = torch.empty((n, 1), device=w_nk.device, dtype=torch.float32)
+            if quant_type == FP8:
+                N.check(N.lib().fdm_quant_fp8_rowwise(N.ptr(q), N.ptr(s), N.ptr(w_nk), n, k, k, N.stream()), "weight quant fp8")
+            else:  # symmetric per output channel (utils/quantization.py:29-33)
+                N.check(N.lib().fdm_quant_int8_rowwise(N.ptr(q), N.ptr(s), None, N.ptr(w_nk), n, k, k, N.stream()), "weight quant int8")
+                self.weight_asym_sumcol = q.to(torch.int32).sum(dim=1, dtype=torch.int32).reshape(1, n).contiguous()
+            self.weight, self.weight_quant_scale = q.t(), s
+        else:
+            raise ValueError(f"Unsupported quantization type: {quant_type}")
+
+    # ------------------------------------------------------------------ forward
+    def quantize_input(self, x2d: torch.Tensor) -> Quantized:
+        return fused.quantize_rows(x2d, None, self.quant_type)
+
+    def forward_q(self, x, epilogue: int = N.EPI_NONE, gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+                  rows_per_batch: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: a `Quantized` (for W8A8 layers) or a bf16 [M,K] matrix (bf16 layers).  Epilogues:
+        EPI_GELU_TANH / EPI_GELU_ERF / EPI_GATE_RESIDUAL (out = res + gate[b]*y; `out` may alias `res`)."""
+        wt = self.weight  # [K, N], stride(0) == 1
+        K, Nn = wt.shape
+        a = x.q if isinstance(x, Quantized) else x
+        M = a.shape[0]
+        if out is None:
+            out = torch.empty((M, Nn), device=a.device, dtype=self.dtype)
+        g_ptr, g_stride = (N.ptr(gate), gate.stride(0)) if gate is not None else (None, 0)
+        lib = N.lib()
+        flops = 2.0 * M * Nn * K
+        if self.quant_type == FP8:
+          with span("gemm_w8a8_fp8", flops):
+            N.check(lib.fdm_gemm_w8a8_fp8(N.ptr(out), N.ptr(a), N.ptr(wt), N.ptr(x.scale), N.ptr(self.weight_quant_scale),
+                                          N.ptr(self.bias), M, Nn, K, a.stride(0), wt.stride(1), out.stride(0), epilogue,
+                                          g_ptr, g_stride, N.ptr(res), rows_per_batch, N.stream()), "fp8 linear")
+        elif self.quant_type == torch.int8:
+          with span("gemm_w8a8_int8", flops):
+            N.check(lib.fdm_gemm_w8a8_int8(N.ptr(out), N.ptr(a), N.ptr(wt), N.ptr(x.scale), N.ptr(self.weight_quant_scale),
+                                           N.ptr(self.weight_asym_sumcol) if x.azp is not None else None, N.ptr(x.azp),
+                                           N.ptr(self.bias), M, Nn, K, a.stride(0), wt.stride(1), out.stride(0), epilogue,
+                                           g_ptr, g_stride, N.ptr(res), rows_per_batch, N.stream()), "int8 linear")
+        else:
+            assert a.dtype == self.dtype and a.stride(1) == 1
+            with span("gemm_bf16", flops):
+              N.check(lib.fdm_gemm_bf16(N.ptr(out), N.ptr(a), N.ptr(wt), N.ptr(self.bias), M, Nn, K, a.stride(0), wt.stride(1),
+                                      out.stride(0), epilogue, g_ptr, g_stride, N.ptr(res), rows_per_batch, N.stream()),
+                    "bf16 linear")
+        return out
+
+    def forward(self, input_tensor: torch.Tensor) -> torch.Tensor:
+        """fastdm/layer/qlinear.py:56-81: quantise per token, scaled GEMM (+bias), restore the leading dims."""
+        ori_shape = input_tensor.shape
+        x = input_tensor.reshape(-1, ori_shape[-1])
+        if self.quant_type is not None:
+            x = self.quantize_input(x if x.stride(1) == 1 else x.contiguous())
+        elif not x.is_contiguous():
+            x = x.contiguous()
+        out = self.forward_q(x)
+        return out.view(*ori_shape[:-1], self.weight.shape[-1])

@@ -1,0 +1,260 @@
+"""FLUX transformer core on the HIP library (mirror of fastdm/model/flux.py:17-494).
+
+Same classes, constructor arguments, diffusers weight names and `forward` signature/returns as the
+reference.  The block wiring is fused for gfx950:
+
+  double block, per stream:  LN+modulate+quant  ->  qkv GEMM  ->  q/k RMS-norm + RoPE + scatter into
+      the joint [text ; image] q/k/v  ->  flash attention  ->  row quant  ->  out-proj GEMM with
+      gate*y + residual epilogue  ->  LN+modulate+quant  ->  FF1 GEMM with tanh-GELU epilogue  ->
+      row quant  ->  FF2 GEMM with gate*y + residual epilogue                (19 launches / block)
+  single block:  LN+modulate+quant (once, shared by proj_mlp and qkv; the reference quantises the
+      same tensor twice, flux.py:61,63)  ->  qkv GEMM, proj_mlp GEMM with erf-GELU epilogue  ->
+      norm/RoPE/scatter  ->  attention  ->  row quant of the *virtual* cat([attn, mlp])  ->
+      proj_out GEMM with gate*y + residual epilogue                           (7 launches / block)
+
+Rounding order follows the torch backend exactly (SURVEY §8c'); every fused kernel rounds to bf16
+where the unfused torch ops would.
+"""
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+
+from fastdm_amd import _native as N
+from fastdm_amd.kernel import fused
+from fastdm_amd.layer.embeddings import (CombinedTimestepGuidanceTextProjEmbeddings, CombinedTimestepTextProjEmbeddings,
+                                         FluxPosEmbed)
+from fastdm_amd.layer.normalization import (AdaLayerNormContinuous, AdaLayerNormZero, AdaLayerNormZeroSingle, ModulationTable)
+from fastdm_amd.layer.qlinear import QLinear
+from fastdm_amd.layer.transformer import Attention, FeedForward
+from fastdm_amd.model.basemodel import BaseModelCore
+
+BF16 = torch.bfloat16
+
+
+class FluxSingleTransformerBlock:
+    """fastdm/model/flux.py:17-76."""
+
+    def __init__(self, dim, num_attention_heads, attention_head_dim, mlp_ratio=4.0, data_type=BF16):
+        self.mlp_hidden_dim = int(dim * mlp_ratio)
+        self.norm = AdaLayerNormZeroSingle(dim, data_type=data_type)
+        self.proj_mlp = QLinear(dim, self.mlp_hidden_dim, bias=True, data_type=data_type)
+        self.proj_out = QLinear(dim + self.mlp_hidden_dim, dim, bias=True, data_type=data_type)
+        self.attn = Attention(query_dim=dim, dim_head=attention_head_dim, heads=num_attention_heads, out_dim=dim, bias=True,
+                              qk_norm="rms_norm", eps=1e-6, pre_only=True, data_type=data_type)
+
+    def forward(self, hidden_states: torch.Tensor, temb: torch.Tensor, image_rotary_emb=None, joint_attention_kwargs=None):
+        B, S, D = hidden_states.shape
+        x = hidden_states.reshape(B * S, D)
+        shift, scale, gate = self.norm.modulation(temb).chunk(3, dim=1)
+        quant = self.proj_mlp.quant_type
+        nh, nq, _ = fused.ln_modulate(x, scale, shift, S, quant=quant)
+        xin = nq if quant is not None else nh
+        mlp = self.proj_mlp.forward_q(xin, epilogue=N.EPI_GELU_ERF)
+        attn = self.attn.attend(xin, B, S, image_rotary_emb)
+        if self.proj_out.quant_type is not None:
+            cat = fused.quantize_rows(attn, mlp, self.proj_out.quant_type)
+        else:
+            cat = torch.cat([attn, mlp], dim=1)
+        out = torch.empty_like(x)
+        self.proj_out.forward_q(cat, epilogue=N.EPI_GATE_RESIDUAL, gate=gate, res=x, rows_per_batch=S, out=out)
+        return out.view(B, S, D)
+
+
+class FluxTransformerBlock:
+    """fastdm/model/flux.py:78-178."""
+
+    def __init__(self, dim, num_attention_heads, attention_head_dim, qk_norm="rms_norm", eps=1e-6, data_type=BF16):
+        self.norm1 = AdaLayerNormZero(dim, data_type=data_type)
+        self.norm1_context = AdaLayerNormZero(dim, data_type=data_type)
+        self.attn = Attention(query_dim=dim, added_kv_proj_dim=dim, dim_head=attention_head_dim, heads=num_attention_heads,
+                              out_dim=dim, context_pre_only=False, bias=True, qk_norm=qk_norm, eps=eps, data_type=data_type)
+        self.ff = FeedForward(dim=dim, dim_out=dim, activation_fn="gelu-approximate", data_type=data_type)
+        self.ff_context = FeedForward(dim=dim, dim_out=dim, activation_fn="gelu-approximate", data_type=data_type)
+
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, temb: torch.Tensor,
+                image_rotary_emb=None, joint_attention_kwargs=None):
+        B, s_img, D = hidden_states.shape
+        s_txt = encoder_hidden_states.shape[1]
+        quant = self.attn.qkv.quant_type
+        x = hidden_states.reshape(B * s_img, D)
+        e = encoder_hidden_states.reshape(B * s_txt, D)
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1.modulation(temb).chunk(6, dim=1)
+        c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.norm1_context.modulation(temb).chunk(6, dim=1)
+
+        def pick(t):
+            return t[1] if quant is not None else t[0]
+
+        xin = pick(fused.ln_modulate(x, scale_msa, shift_msa, s_img, quant=quant))
+        ein = pick(fused.ln_modulate(e, c_scale_msa, c_shift_msa, s_txt, quant=quant))
+        o = self.attn.attend(xin, B, s_img, image_rotary_emb, ein, s_txt).view(B, s_txt + s_img, D)
+
+        def stream(res, attn_rows, s, to_out, gate_a, scale_m, shift_m, gate_m, ff):
+            # attention rows of this stream are a strided slice of the joint output: quantise per batch element
+            new = torch.empty_like(res)
+            for b in range(B):
+                rows = attn_rows[b]
+                aq = to_out.quantize_input(rows) if to_out.quant_type is not None else rows
+                to_out.forward_q(aq, epilogue=N.EPI_GATE_RESIDUAL, gate=gate_a[b:b + 1], res=res[b * s:(b + 1) * s], rows_per_batch=s,
+                                 out=new[b * s:(b + 1) * s])
+            fin = pick(fused.ln_modulate(new, scale_m, shift_m, s, quant=quant))
+            return ff.forward_fused(fin, gate_m, new, s)
+
+        x = stream(x, o[:, s_txt:], s_img, self.attn.to_out, gate_msa, scale_mlp, shift_mlp, gate_mlp, self.ff)
+        e = stream(e, o[:, :s_txt], s_txt, self.attn.to_add_out, c_gate_msa, c_scale_mlp, c_shift_mlp, c_gate_mlp, self.ff_context)
+        return e.view(B, s_txt, D), x.view(B, s_img, D)
+
+
+class FluxTransformer2DModelCore(BaseModelCore):
+    """fastdm/model/flux.py:180-494."""
+
+    def __init__(self, patch_size: int = 1, in_channels: int = 64, out_channels: int = 64, num_layers: int = 19,
+                 num_single_layers: int = 38, attention_head_dim: int = 128, num_attention_heads: int = 24,
+                 joint_attention_dim: int = 4096, pooled_projection_dim: int = 768, guidance_embeds: bool = True,
+                 axes_dims_rope: Tuple[int] = (16, 56, 56), data_type=BF16, quant_dtype: Optional[torch.dtype] = torch.float8_e4m3fn,
+                 cache=None, oom_ressolve: bool = False):
+        super().__init__(type="DiT")
+        self.need_resolve_oom = oom_ressolve      # accepted for signature parity; 288 GB HBM makes it moot
+        self.out_channels = out_channels
+        self.inner_dim = num_attention_heads * attention_head_dim
+        self.guidance_embeds = guidance_embeds
+        self.pos_embed = FluxPosEmbed(theta=10000, axes_dim=list(axes_dims_rope))
+        cls = CombinedTimestepGuidanceTextProjEmbeddings if guidance_embeds else CombinedTimestepTextProjEmbeddings
+        self.time_text_embed = cls(embedding_dim=self.inner_dim, pooled_projection_dim=pooled_projection_dim, data_type=data_type)
+        self.context_embedder = QLinear(joint_attention_dim, self.inner_dim, data_type=data_type)
+        self.x_embedder = QLinear(in_channels, self.inner_dim, data_type=data_type)
+        self.quant_dtype = quant_dtype
+        self.transformer_blocks = [FluxTransformerBlock(self.inner_dim, num_attention_heads, attention_head_dim, data_type=data_type)
+                                   for _ in range(num_layers)]
+        self.single_transformer_blocks = [FluxSingleTransformerBlock(self.inner_dim, num_attention_heads, attention_head_dim, data_type=data_type)
+                                          for _ in range(num_single_layers)]
+        self.norm_out = AdaLayerNormContinuous(self.inner_dim, self.inner_dim, elementwise_affine=False, eps=1e-6, data_type=data_type)
+        self.proj_out = QLinear(self.inner_dim, patch_size * patch_size * self.out_channels, data_type=data_type)
+        self.cache = cache
+        self.cache_config = cache.config if cache is not None else None
+        self.enable_caching = self.cache_config.enable_caching if cache is not None else False
+        self.mod_table = None
+        self._rope_key, self._rope_val = None, None
+
+    # ------------------------------------------------------------------ loading (flux.py:274-332)
+    def _pre_part_loading(self):
+        t = self.time_text_embed
+        self.init_weight(["time_text_embed.timestep_embedder.linear_1"], t.timestep_embedder.linear1)
+        self.init_weight(["time_text_embed.timestep_embedder.linear_2"], t.timestep_embedder.linear2)
+        if self.guidance_embeds:
+            self.init_weight(["time_text_embed.guidance_embedder.linear_1"], t.guidance_embedder.linear1)
+            self.init_weight(["time_text_embed.guidance_embedder.linear_2"], t.guidance_embedder.linear2)
+        self.init_weight(["time_text_embed.text_embedder.linear_1"], t.text_embedder.linear1)
+        self.init_weight(["time_text_embed.text_embedder.linear_2"], t.text_embedder.linear2)
+        self.init_weight(["context_embedder"], self.context_embedder)
+        self.init_weight(["x_embedder"], self.x_embedder)
+
+    def _load_double_block(self, i, blk, src_i=None):
+        p = f"transformer_blocks.{i if src_i is None else src_i}"
+        q = self.quant_dtype
+        self.init_weight([f"{p}.norm1.linear"], blk.norm1.linear)
+        self.init_weight([f"{p}.norm1_context.linear"], blk.norm1_context.linear)
+        blk.attn.norm_q_weight = self.init_weight([f"{p}.attn.norm_q.weight"])
+        blk.attn.norm_k_weight = self.init_weight([f"{p}.attn.norm_k.weight"])
+        self.init_weight([f"{p}.attn.to_q", f"{p}.attn.to_k", f"{p}.attn.to_v"], blk.attn.qkv, q)
+        self.init_weight([f"{p}.attn.add_q_proj", f"{p}.attn.add_k_proj", f"{p}.attn.add_v_proj"], blk.attn.add_qkv_proj, q)
+        self.init_weight([f"{p}.attn.to_out.0"], blk.attn.to_out, q)
+        self.init_weight([f"{p}.attn.to_add_out"], blk.attn.to_add_out, q)
+        blk.attn.norm_added_q_weight = self.init_weight([f"{p}.attn.norm_added_q.weight"])
+        blk.attn.norm_added_k_weight = self.init_weight([f"{p}.attn.norm_added_k.weight"])
+        self.init_weight([f"{p}.ff.net.0.proj"], blk.ff.act_fn.proj, q)
+        self.init_weight([f"{p}.ff.net.2"], blk.ff.ff_out_proj, q)
+        self.init_weight([f"{p}.ff_context.net.0.proj"], blk.ff_context.act_fn.proj, q)
+        self.init_weight([f"{p}.ff_context.net.2"], blk.ff_context.ff_out_proj, q)
+
+    def _load_single_block(self, i, blk, src_i=None):
+        p = f"single_transformer_blocks.{i if src_i is None else src_i}"
+        q = self.quant_dtype
+        self.init_weight([f"{p}.norm.linear"], blk.norm.linear)
+        self.init_weight([f"{p}.proj_mlp"], blk.proj_mlp, q)
+        self.init_weight([f"{p}.proj_out"], blk.proj_out, q)
+        blk.attn.norm_q_weight = self.init_weight([f"{p}.attn.norm_q.weight"])
+        blk.attn.norm_k_weight = self.init_weight([f"{p}.attn.norm_k.weight"])
+        self.init_weight([f"{p}.attn.to_q", f"{p}.attn.to_k", f"{p}.attn.to_v"], blk.attn.qkv, q)
+
+    def _major_parts_loading(self):
+        for i, blk in enumerate(self.transformer_blocks):
+            self._load_double_block(i, blk)
+        for i, blk in enumerate(self.single_transformer_blocks):
+            self._load_single_block(i, blk)
+
+    def _post_part_loading(self):
+        self.init_weight(["norm_out.linear"], self.norm_out.linear)
+        self.init_weight(["proj_out"], self.proj_out)
+
+    def _finalize_loading(self):
+        layers = []
+        for blk in self.transformer_blocks:
+            layers += [blk.norm1, blk.norm1_context]
+        layers += [blk.norm for blk in self.single_transformer_blocks]
+        layers.append(self.norm_out)
+        self.mod_table = ModulationTable(layers)
+
+    # ------------------------------------------------------------------ forward (flux.py:334-494)
+    def _rope_cache(self, txt_ids, img_ids, dtype):
+        key = (txt_ids.data_ptr(), img_ids.data_ptr(), tuple(txt_ids.shape), tuple(img_ids.shape), txt_ids._version, img_ids._version)
+        if key != self._rope_key:
+            ids = torch.cat((txt_ids, img_ids), dim=0)
+            cos, sin = self.pos_embed.forward(ids)
+            self._rope_val = torch.cat((cos[:, 0::2], sin[:, 1::2]), dim=-1).to(dtype).contiguous()
+            self._rope_key = key
+            self._rope_ids = (txt_ids, img_ids)   # keep the tensors alive so the pointers in the key stay unique
+        return self._rope_val
+
+    def run_blocks(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb, joint_attention_kwargs=None,
+                   controlnet_block_samples=None, controlnet_single_block_samples=None):
+        assert controlnet_block_samples is None and controlnet_single_block_samples is None, "ControlNet residuals are out of scope"
+        for block in self.transformer_blocks:
+            encoder_hidden_states, hidden_states = block.forward(hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                                                 temb=temb, image_rotary_emb=image_rotary_emb,
+                                                                 joint_attention_kwargs=joint_attention_kwargs)
+        n_txt = encoder_hidden_states.shape[1]
+        hidden_states = torch.cat([encoder_hidden_states, hidden_states], dim=1)
+        for block in self.single_transformer_blocks:
+            hidden_states = block.forward(hidden_states=hidden_states, temb=temb, image_rotary_emb=image_rotary_emb,
+                                          joint_attention_kwargs=joint_attention_kwargs)
+        return hidden_states[:, n_txt:, ...]
+
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None, pooled_projections: torch.Tensor = None,
+                timestep: torch.Tensor = None, img_ids: torch.Tensor = None, txt_ids: torch.Tensor = None, guidance: torch.Tensor = None,
+                joint_attention_kwargs: Optional[Dict[str, Any]] = None, controlnet_block_samples=None,
+                controlnet_single_block_samples=None, return_dict: bool = True, controlnet_blocks_repeat: bool = False):
+        dev = self.x_embedder.weight.device
+        hidden_states = hidden_states.to(dev)
+        encoder_hidden_states = encoder_hidden_states.to(dev)
+        pooled_projections = pooled_projections.to(dev)
+        hidden_states = self.x_embedder.forward(hidden_states)
+        timestep = timestep.to(dev).to(hidden_states.dtype) * 1000          # bf16 multiply: 0.75 -> 752 (flux.py:399)
+        if guidance is not None:
+            guidance = guidance.to(dev).to(hidden_states.dtype) * 1000
+        temb = (self.time_text_embed.forward(timestep, pooled_projections) if guidance is None
+                else self.time_text_embed.forward(timestep, guidance, pooled_projections))
+        encoder_hidden_states = self.context_embedder.forward(encoder_hidden_states)
+        if txt_ids.ndim == 3:
+            txt_ids = txt_ids[0]
+        if img_ids.ndim == 3:
+            img_ids = img_ids[0]
+        image_rotary_emb = self._rope_cache(txt_ids, img_ids, hidden_states.dtype)
+
+        if self.mod_table is not None:
+            self.mod_table.begin_step(temb)
+        try:
+            if self.enable_caching:
+                hidden_states = self.cache.apply_cache(model_type="flux", hidden_states=hidden_states,
+                                                       encoder_hidden_states=encoder_hidden_states, temb=temb,
+                                                       image_rotary_emb=image_rotary_emb, attention_kwargs=joint_attention_kwargs,
+                                                       transformer_blocks=self.transformer_blocks,
+                                                       single_transformer_blocks=self.single_transformer_blocks, core=self)
+            else:
+                hidden_states = self.run_blocks(hidden_states, encoder_hidden_states, temb, image_rotary_emb, joint_attention_kwargs,
+                                                controlnet_block_samples, controlnet_single_block_samples)
+            hidden_states = self.norm_out.forward(hidden_states.contiguous(), temb)
+        finally:
+            if self.mod_table is not None:
+                self.mod_table.end_step()
+        output = self.proj_out.forward(hidden_states)
+        return (output,)

@@ -1,0 +1,177 @@
+"""Drop-in wrappers and engine (mirror of fastdm/model_entry.py:30-146,463-502,529-793).
+
+`create_model('flux', ckpt_path=<state_dict | path>, dtype=, quant_type=, kernel_backend=, cache=)`
+returns an `nn.Module` exposing what a diffusers pipeline touches on `pipe.transformer`: `.config`
+(in_channels, out_channels, guidance_embeds, dtype), `.dtype`, `.device`, a no-op `.to()`, `.eval()`,
+`cache_context(name)` and `forward(hidden_states, **kw) -> (tensor,)` under no_grad.
+`FastDMEngine` wires it into a diffusers pipeline when diffusers is importable; without diffusers
+(or with model_path='') it drives the built-in synthetic denoise loop instead.
+"""
+import json
+import os
+import types
+from contextlib import contextmanager
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from fastdm_amd.caching.xcaching import AutoCache
+from fastdm_amd.kernel.utils import set_global_backend
+from fastdm_amd.model.flux import FluxTransformer2DModelCore
+
+
+class ConfigMixin:
+    def _create_diffusers_config(self, **config_params):
+        return types.SimpleNamespace(**config_params)
+
+
+class BaseModelWrapper(nn.Module, ConfigMixin):
+    """model_entry.py:39-93."""
+
+    def __init__(self, kernel_backend: str = "hip", config_path: Optional[str] = None):
+        super().__init__()
+        set_global_backend(kernel_backend)       # raises ValueError for anything but the HIP backend (alias 'cuda')
+        self.model_config_dict = self._load_config(config_path)
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.core_model = None
+
+    def _load_config(self, config_path: Optional[str]) -> Optional[Dict]:
+        if not config_path or not os.path.isfile(config_path):
+            return None
+        with open(config_path, "r", encoding="utf-8") as f:
+            return json.load(f)
+
+    @contextmanager
+    def cache_context(self, name: str):
+        """diffusers >= 0.35 enters `transformer.cache_context("cond")` around each call; no-op like the reference."""
+        yield
+
+    def to(self, *args, **kwargs):
+        """Weights already live on the GPU in their final (quantised) form: `pipe.to('cuda')` must not touch them."""
+        return self
+
+    def forward(self, *args, **kwargs):
+        if self.core_model is None:
+            raise NotImplementedError("Core model not initialized")
+        return self.core_model.forward(*args, **kwargs)
+
+
+class FluxTransformerWrapper(BaseModelWrapper):
+    """model_entry.py:96-146."""
+
+    def __init__(self, ckpt_path=None, in_channels: int = 64, out_channels: int = 64, dtype: torch.dtype = torch.bfloat16,
+                 quant_type: Optional[torch.dtype] = None, kernel_backend: str = "hip", need_resolve_oom=False,
+                 cache: AutoCache = None, **kwargs):
+        super().__init__(kernel_backend)
+        guidance_embeds = kwargs.pop("guidance_embeds", True)
+        self.config = self._create_diffusers_config(in_channels=in_channels, out_channels=out_channels,
+                                                    guidance_embeds=guidance_embeds, dtype=dtype)
+        self.need_resolve_oom = need_resolve_oom
+        self.dtype = dtype
+        self.core_model = FluxTransformer2DModelCore(in_channels=in_channels, out_channels=out_channels, guidance_embeds=guidance_embeds,
+                                                     data_type=dtype, quant_dtype=quant_type, cache=cache, oom_ressolve=need_resolve_oom,
+                                                     **kwargs)
+        if isinstance(ckpt_path, dict) or (ckpt_path and os.path.exists(ckpt_path)):
+            self.core_model.weight_loading(ckpt_path, data_type=dtype, device_type="cuda")
+        elif ckpt_path:
+            print(f"Warning: Checkpoint path {ckpt_path} does not exist")
+
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, **kwargs):
+        return self.core_model.forward(hidden_states, **kwargs)
+
+
+class ModelWrapperFactory:
+    """model_entry.py:463-497."""
+    _WRAPPER_MAPPING = {"flux": FluxTransformerWrapper}
+    _NOT_BUILT = ("sdxl", "sd35", "qwen", "wan", "sdxl-controlnet", "flux-controlnet")
+
+    @classmethod
+    def create_wrapper(cls, model_type: str, **kwargs) -> BaseModelWrapper:
+        if model_type in cls._WRAPPER_MAPPING:
+            return cls._WRAPPER_MAPPING[model_type](**kwargs)
+        if model_type in cls._NOT_BUILT:
+            raise NotImplementedError(f"model type '{model_type}' is on the roadmap (SURVEY.md §8f) but not built yet")
+        raise ValueError(f"Unsupported model type: {model_type}. Supported types: {list(cls._WRAPPER_MAPPING)}")
+
+    @classmethod
+    def get_available_models(cls) -> List[str]:
+        return list(cls._WRAPPER_MAPPING)
+
+    @classmethod
+    def register_wrapper(cls, model_type: str, wrapper_class: type):
+        if not issubclass(wrapper_class, BaseModelWrapper):
+            raise TypeError("Wrapper class must inherit from BaseModelWrapper")
+        cls._WRAPPER_MAPPING[model_type] = wrapper_class
+
+
+def create_model(model_type: str, **kwargs) -> BaseModelWrapper:
+    return ModelWrapperFactory.create_wrapper(model_type, **kwargs)
+
+
+def list_available_models() -> List[str]:
+    return ModelWrapperFactory.get_available_models()
+
+
+class FastDMEngine:
+    """model_entry.py:529-793 for architecture='flux'.
+
+    With diffusers + a checkpoint: `DiffusionPipeline.from_pretrained(model_path)`, swap
+    `pipe.transformer` for our wrapper (model_entry.py:656-667), `generate()` calls the pipeline.
+    Without (model_path == '' or diffusers missing): synthetic weights + `SyntheticFluxPipeline`, whose
+    `generate()` returns the final packed latents instead of a decoded image."""
+
+    def __init__(self, model_path, architecture="flux", device=0, data_type="bfloat16", use_fp8=False, use_int8=False,
+                 kernel_backend="hip", cache_config=None, oom_resolve=False, use_diffusers=True, task="t2i",
+                 sparse_attn_config=None, synthetic_seed=0, **model_kwargs):
+        if architecture != "flux":
+            raise NotImplementedError(f"architecture '{architecture}' is not built yet (SURVEY.md §8f)")
+        if data_type != "bfloat16":
+            raise NotImplementedError("bfloat16 activations only in this build")
+        if sparse_attn_config:
+            raise ValueError("Sparse attention is only supported for Wan models")
+        self.architecture, self.device, self.task = architecture, device, task
+        torch.cuda.set_device(device)
+        self.dtype = torch.bfloat16
+        self.quant_type = torch.float8_e4m3fn if use_fp8 else (torch.int8 if use_int8 else None)
+        self.cache = AutoCache.from_json(cache_config) if cache_config else None
+        self.pipe = None
+        have_ckpt = bool(model_path) and os.path.exists(model_path)
+        if have_ckpt:
+            try:
+                from diffusers import DiffusionPipeline
+            except ImportError as e:
+                raise ImportError("a checkpoint path was given but diffusers is not installed; use model_path='' for the "
+                                  "synthetic pipeline") from e
+            self.pipe = DiffusionPipeline.from_pretrained(model_path, torch_dtype=self.dtype, use_safetensors=True)
+            if self.cache:
+                self.cache.config.current_steps_callback = lambda: self.pipe.scheduler.step_index
+                self.cache.config.total_steps_callback = lambda: self.pipe.scheduler.timesteps.shape[0]
+            self.pipe.transformer = create_model("flux", ckpt_path=self.pipe.transformer.state_dict(), dtype=self.dtype,
+                                                 quant_type=self.quant_type, kernel_backend=kernel_backend, cache=self.cache).eval()
+            self.pipe.to("cuda")
+        else:
+            from fastdm_amd.pipeline import SyntheticFluxPipeline
+            from fastdm_amd.synthetic import SyntheticFluxStateDict
+            sd = SyntheticFluxStateDict(seed=synthetic_seed, **{k: v for k, v in model_kwargs.items() if k in
+                                                                ("num_layers", "num_single_layers", "attention_head_dim", "num_attention_heads",
+                                                                 "joint_attention_dim", "pooled_projection_dim", "in_channels", "out_channels")})
+            transformer = create_model("flux", ckpt_path=sd, dtype=self.dtype, quant_type=self.quant_type, kernel_backend=kernel_backend,
+                                       cache=self.cache, **model_kwargs).eval()
+            self.pipe = SyntheticFluxPipeline(transformer, seed=synthetic_seed)
+            if self.cache:
+                self.cache.config.current_steps_callback = lambda: self.pipe.scheduler_step_index
+                self.cache.config.total_steps_callback = lambda: self.pipe.num_steps
+
+    def generate(self, prompt=None, negative_prompt=None, src_image=None, num_frames=None, steps=50, guidance_scale=3.5,
+                 true_cfg_scale=None, gen_seed=42, gen_width=512, gen_height=512, max_seq_len=512):
+        from fastdm_amd.pipeline import SyntheticFluxPipeline
+        if isinstance(self.pipe, SyntheticFluxPipeline):
+            return self.pipe(num_inference_steps=steps, guidance_scale=guidance_scale, width=gen_width, height=gen_height,
+                             max_sequence_length=max_seq_len, seed=gen_seed)
+        gen = torch.Generator().manual_seed(gen_seed)
+        kwargs = {"prompt": prompt, "negative_prompt": negative_prompt, "num_inference_steps": steps, "generator": gen,
+                  "max_sequence_length": max_seq_len, "width": gen_width, "height": gen_height, "guidance_scale": guidance_scale}
+        with torch.inference_mode():
+            return self.pipe(**kwargs).images[0]

@@ -1,0 +1,73 @@
+"""A minimal FLUX denoise loop for machines without diffusers / checkpoints / text encoders / VAE.
+
+It reproduces what diffusers' FluxPipeline does around `pipe.transformer`: packed
+latents [B, (H/16)*(W/16), 64], img_ids grid, zero txt_ids, a flow-match Euler schedule with the
+resolution-dependent time shift, `timestep = sigma` (i.e. t/1000) and `guidance` vectors, and
+`latents += (sigma_next - sigma) * noise_pred` per step.  Prompt embeddings are synthetic (U[0,1) like
+examples/profiling/flux_profiling.py:16-23).  The hot path inside the loop is exactly the
+`transformer(hidden_states=..., timestep=..., guidance=..., pooled_projections=...,
+encoder_hidden_states=..., txt_ids=..., img_ids=..., return_dict=False)[0]` call of the real pipeline.
+"""
+import math
+
+import numpy as np
+import torch
+
+from fastdm_amd import synthetic
+
+
+def flow_match_sigmas(num_steps: int, image_seq_len: int, base_seq_len=256, max_seq_len=4096, base_shift=0.5, max_shift=1.15):
+    """FlowMatchEulerDiscreteScheduler with FLUX's dynamic shifting (diffusers FluxPipeline.calculate_shift +
+    scheduler.set_timesteps(sigmas=linspace(1, 1/N, N), mu=mu)); returns N+1 sigmas ending in 0."""
+    sigmas = np.linspace(1.0, 1.0 / num_steps, num_steps)
+    m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+    mu = image_seq_len * m + (base_shift - m * base_seq_len)
+    sigmas = math.exp(mu) / (math.exp(mu) + (1.0 / sigmas - 1.0))
+    return np.concatenate([sigmas, [0.0]]).astype(np.float32)
+
+
+class SyntheticFluxPipeline:
+    def __init__(self, transformer, seed: int = 0):
+        self.transformer = transformer
+        self.seed = seed
+        self.scheduler_step_index = None
+        self.num_steps = 0
+        self._inputs_key, self._inputs = None, None
+
+    def prepare(self, batch, height, width, max_sequence_length, seed):
+        key = (batch, height, width, max_sequence_length, seed)
+        if key != self._inputs_key:
+            cfg = self.transformer.config
+            self._inputs = synthetic.flux_step_inputs(batch, height // 16, width // 16, max_sequence_length, cfg.in_channels, seed=seed,
+                                                      joint_attention_dim=self.transformer.core_model.context_embedder.in_features,
+                                                      pooled_projection_dim=self.transformer.core_model.time_text_embed.text_embedder.linear1.in_features)
+            self._inputs_key = key
+        return self._inputs
+
+    @torch.no_grad()
+    def denoise(self, latents, inp, sigmas, guidance_scale, step_callback=None):
+        B = latents.shape[0]
+        guidance = torch.full((B,), guidance_scale, device=latents.device, dtype=torch.float32)
+        self.num_steps = len(sigmas) - 1
+        for i in range(self.num_steps):
+            self.scheduler_step_index = i
+            t = torch.full((B,), float(sigmas[i]), device=latents.device, dtype=latents.dtype)
+            with self.transformer.cache_context("cond"):
+                noise_pred = self.transformer(hidden_states=latents, timestep=t, guidance=guidance,
+                                              pooled_projections=inp["pooled_projections"],
+                                              encoder_hidden_states=inp["encoder_hidden_states"], txt_ids=inp["txt_ids"],
+                                              img_ids=inp["img_ids"], joint_attention_kwargs=None, return_dict=False)[0]
+            # scheduler.step: x += (sigma_next - sigma) * v, computed in fp32 and cast back (diffusers upcasts the sample)
+            latents = (latents.float() + float(sigmas[i + 1] - sigmas[i]) * noise_pred.float()).to(latents.dtype)
+            if step_callback is not None:
+                step_callback(i, latents)
+        self.scheduler_step_index = None
+        return latents
+
+    def __call__(self, num_inference_steps=25, guidance_scale=3.5, width=2048, height=1024, max_sequence_length=512, batch=1,
+                 seed=None, latents=None):
+        seed = self.seed if seed is None else seed
+        inp = self.prepare(batch, height, width, max_sequence_length, seed)
+        lat = inp["hidden_states"].clone() if latents is None else latents
+        sigmas = flow_match_sigmas(num_inference_steps, lat.shape[1])
+        return self.denoise(lat, inp, sigmas, guidance_scale)

@@ -1,0 +1,115 @@
+"""Synthetic FLUX weights and step inputs generated ON THE GPU by the library's counter-based
+generator (fdm_synth_fill_bf16), bit-identical to the numpy twin the oracle uses (oracle/synth.py).
+
+There are no checkpoints, text encoders or VAEs on the benchmark machines; the recipe follows
+SURVEY.md §8d: Linear W ~ N(0, 1/fan_in), AdaLN/modulation linears and all biases N(0, 0.02^2),
+RMS-norm weights 1 + 0.1 N(0,1), inputs U[0,1) as in examples/profiling/flux_profiling.py:16-23.
+"""
+import math
+
+import torch
+
+from fastdm_amd.kernel import fused
+
+_IH_STD = math.sqrt(4.0 * (65536.0 ** 2 - 1.0) / 12.0)
+
+
+def key_seed(name: str, base_seed: int = 0) -> int:
+    h = 0xCBF29CE484222325
+    for b in name.encode("utf-8"):
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    h ^= (base_seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    return int((h ^ (h >> 33)) & 0x7FFFFFFF)
+
+
+def _f32(x: float) -> float:
+    return float(torch.tensor(x, dtype=torch.float64).to(torch.float32))
+
+
+def normal(name, shape, std, offset=0.0, seed=0, device="cuda"):
+    out = torch.empty(shape, device=device, dtype=torch.bfloat16)
+    return fused.synth_fill(out, key_seed(name, seed), 0, _f32(std / _IH_STD), _f32(offset))
+
+
+def uniform(name, shape, seed=0, device="cuda"):
+    out = torch.empty(shape, device=device, dtype=torch.bfloat16)
+    return fused.synth_fill(out, key_seed(name, seed), 1)
+
+
+class SyntheticFluxStateDict(dict):
+    """A lazily generated diffusers-named FLUX state_dict: tensors are produced on the GPU when the
+    loader asks for them, so the full 24 GB bf16 checkpoint never exists at once."""
+
+    def __init__(self, in_channels=64, out_channels=64, num_layers=19, num_single_layers=38, attention_head_dim=128,
+                 num_attention_heads=24, joint_attention_dim=4096, pooled_projection_dim=768, mlp_ratio=4.0, seed=0, device="cuda"):
+        super().__init__()
+        self.seed, self.device = seed, device
+        D, mlp, hd = attention_head_dim * num_attention_heads, int(attention_head_dim * num_attention_heads * mlp_ratio), attention_head_dim
+        spec = {}
+
+        def lin(name, k, n, kind="w"):
+            spec[f"{name}.weight"] = ((n, k), kind)
+            spec[f"{name}.bias"] = ((n,), "b")
+
+        for p in ("timestep_embedder", "guidance_embedder"):
+            lin(f"time_text_embed.{p}.linear_1", 256, D)
+            lin(f"time_text_embed.{p}.linear_2", D, D)
+        lin("time_text_embed.text_embedder.linear_1", pooled_projection_dim, D)
+        lin("time_text_embed.text_embedder.linear_2", D, D)
+        lin("context_embedder", joint_attention_dim, D)
+        lin("x_embedder", in_channels, D)
+        for i in range(num_layers):
+            p = f"transformer_blocks.{i}"
+            lin(f"{p}.norm1.linear", D, 6 * D, "w_mod")
+            lin(f"{p}.norm1_context.linear", D, 6 * D, "w_mod")
+            for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out"):
+                lin(f"{p}.attn.{n}", D, D)
+            for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+                spec[f"{p}.attn.{n}.weight"] = ((hd,), "rms")
+            for ff in ("ff", "ff_context"):
+                lin(f"{p}.{ff}.net.0.proj", D, mlp)
+                lin(f"{p}.{ff}.net.2", mlp, D)
+        for i in range(num_single_layers):
+            p = f"single_transformer_blocks.{i}"
+            lin(f"{p}.norm.linear", D, 3 * D, "w_mod")
+            lin(f"{p}.proj_mlp", D, mlp)
+            lin(f"{p}.proj_out", D + mlp, D)
+            for n in ("to_q", "to_k", "to_v"):
+                lin(f"{p}.attn.{n}", D, D)
+            for n in ("norm_q", "norm_k"):
+                spec[f"{p}.attn.{n}.weight"] = ((hd,), "rms")
+        lin("norm_out.linear", D, 2 * D, "w_mod")
+        lin("proj_out", D, out_channels)
+        self.spec = spec
+        for k in spec:
+            dict.__setitem__(self, k, None)
+
+    def _make(self, name):
+        shape, kind = self.spec[name]
+        if kind == "w":
+            return normal(name, shape, (1.0 / shape[1]) ** 0.5, 0.0, self.seed, self.device)
+        if kind in ("w_mod", "b"):
+            return normal(name, shape, 0.02, 0.0, self.seed, self.device)
+        return normal(name, shape, 0.1, 1.0, self.seed, self.device)
+
+    def __getitem__(self, name):
+        return self._make(name)
+
+    def get(self, name, default=None):
+        return self._make(name) if name in self.spec else default
+
+
+def flux_step_inputs(batch, img_h, img_w, n_txt=512, in_channels=64, joint_attention_dim=4096, pooled_projection_dim=768, seed=0,
+                     device="cuda"):
+    """Same tensors as oracle.flux.synth_inputs (bit-identical), created on the GPU."""
+    n_img = img_h * img_w
+    ids = torch.zeros(n_img, 3, device=device)
+    ids[:, 1] = torch.arange(img_h, device=device).repeat_interleave(img_w).float()
+    ids[:, 2] = torch.arange(img_w, device=device).repeat(img_h).float()
+    return dict(
+        hidden_states=uniform("input.latents", (batch, n_img, in_channels), seed, device),
+        encoder_hidden_states=uniform("input.prompt_embeds", (batch, n_txt, joint_attention_dim), seed, device),
+        pooled_projections=uniform("input.pooled", (batch, pooled_projection_dim), seed, device),
+        img_ids=ids,
+        txt_ids=torch.zeros(n_txt, 3, device=device),
+    )

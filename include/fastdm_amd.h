@@ -72,13 +72,13 @@ int fdm_gelu_and_mul(void* out, const void* in, int64_t rows, int d, fdm_stream_
 /* ---- replaces cuda_ops.fp8_scaled_mm_ (torch_bindings.cpp:24-84; csrc/gemm/hopper_w8a8_fp8.cu) -
  * out[M,N] (bf16, row stride ldc) = epi( acc_f32(A[M,K] fp8 row-major lda  x  B[K,N] fp8 column-
  * major ldb) * sa[M] * sb[N] + bias[N] ).  K % 16 == 0, N % 16 == 0.  bias may be NULL.
- * epi_gate [N]/epi_res [M,N] (row stride ldc) are only read for FDM_EPI_GATE_RESIDUAL; gate is
- * indexed per batch as gate[(m / epi_rows_per_batch) * N + n].                                   */
+ * epi_gate / epi_res [M,N] (row stride ldc; may alias out) are only read for
+ * FDM_EPI_GATE_RESIDUAL; gate is indexed as gate[(m / epi_rows_per_batch) * epi_gate_stride + n]. */
 int fdm_gemm_w8a8_fp8(void* out, const void* a, const void* b, const float* scale_a,
                       const float* scale_b, const void* bias,
                       int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
-                      int epilogue, const void* epi_gate, const void* epi_res,
-                      int64_t epi_rows_per_batch, fdm_stream_t stream);
+                      int epilogue, const void* epi_gate, int64_t epi_gate_stride,
+                      const void* epi_res, int64_t epi_rows_per_batch, fdm_stream_t stream);
 
 /* ---- replaces cuda_ops.int8_scaled_mm_ (torch_bindings.cpp:86-158; hopper_w8a8_int8.cu;
  *      epilogue include/cutlass_extensions/epilogue/scaled_mm_epilogues_c3x.hpp:130-197) ---------
@@ -88,14 +88,16 @@ int fdm_gemm_w8a8_fp8(void* out, const void* a, const void* b, const float* scal
 int fdm_gemm_w8a8_int8(void* out, const void* a, const void* b, const float* scale_a,
                        const float* scale_b, const int32_t* azp_adj, const int32_t* azp,
                        const void* bias, int64_t M, int64_t N, int64_t K,
-                       int64_t lda, int64_t ldb, int64_t ldc, fdm_stream_t stream);
+                       int64_t lda, int64_t ldb, int64_t ldc,
+                       int epilogue, const void* epi_gate, int64_t epi_gate_stride,
+                       const void* epi_res, int64_t epi_rows_per_batch, fdm_stream_t stream);
 
 /* ---- bf16 GEMM (QLinear's un-quantised branch: torch.addmm, layer/qlinear.py:76) --------------
  * out[M,N] = bf16(acc_f32(A[M,K] bf16 row-major x B[K,N] bf16 column-major) + bias[N])          */
 int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias,
                   int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
-                  int epilogue, const void* epi_gate, const void* epi_res,
-                  int64_t epi_rows_per_batch, fdm_stream_t stream);
+                  int epilogue, const void* epi_gate, int64_t epi_gate_stride,
+                  const void* epi_res, int64_t epi_rows_per_batch, fdm_stream_t stream);
 
 /* ---- scaled_dot_product_attention / sparse_... (kernel/operators_set.py:154-208) --------------
  * q [B,Sq,Hq*D], k/v [B,Sk,Hkv*D], o [B,Sq,Hq*D] bf16, token strides in elements (batch stride =

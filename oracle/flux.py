@@ -32,8 +32,9 @@ class FluxConfig:
         return self.attention_head_dim * self.num_attention_heads
 
 
-TINY = FluxConfig(in_channels=16, out_channels=16, num_layers=1, num_single_layers=1, attention_head_dim=32,
-                  num_attention_heads=4, joint_attention_dim=64, pooled_projection_dim=48, axes_dims_rope=(8, 12, 12))
+# head_dim 64 (the smallest the HIP attention kernel supports), everything else shrunk
+TINY = FluxConfig(in_channels=16, out_channels=16, num_layers=2, num_single_layers=2, attention_head_dim=64,
+                  num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=48, axes_dims_rope=(16, 24, 24))
 
 
 # ------------------------------------------------------------------ synthetic weights
