@@ -4,24 +4,32 @@
 // i.e. [N,K] row-major), which is exactly the MFMA operand order, so tiles go global -> LDS with
 // 16-byte LDS-DMA (global_load_lds_dwordx4) and LDS -> VGPR with ds_read_b128, no transposes.
 //
-//   tile      256 x 256 x (128 bytes of K)    8 waves = 2 (M) x 4 (N), wave tile 128 x 64
+//   tile      256 x 256, K-step 64 bytes; 8 waves = 2 (M) x 4 (N), wave tile 128 x 64
 //   fp8       v_mfma_scale_f32_32x32x64_f8f6f4 with unit E8M0 scales (2x the bf16 MFMA rate)
 //   int8      v_mfma_i32_32x32x32_i8           bf16: v_mfma_f32_32x32x16_bf16
-//   LDS       2 stages x (32 KiB A + 32 KiB B) = 128 KiB; rows are 128 B, chunk c of row r lives in
-//             slot c ^ ((r >> 1) & 7): conflict-free for the ds_read_b128 lane groups.  LDS-DMA
-//             writes are lane-linear, so the swizzle is applied to the per-lane SOURCE address.
+//   pipeline  4-stage LDS ring of 32 KiB (A 16 KiB + B 16 KiB): while step t runs on registers, the
+//             fragments of step t+1 are read from LDS and the DMAs of steps t+2, t+3 are in flight.
+//             One raw s_barrier per step behind a COUNTED s_waitcnt vmcnt(4) (never 0 in the loop), so
+//             LDS-DMA stays in flight across barriers.
+//   LDS       rows are 64 B; chunk c of row r lives in slot c ^ ((r >> 2) & 3): conflict-free for the
+//             ds_read_b128 lane groups.  LDS-DMA writes are lane-linear, so the swizzle is applied to
+//             the per-lane SOURCE address.
+//   operands  swapped (D^T = B . A^T): a lane then owns ONE output row m and 4 consecutive columns per
+//             register quad -> per-row scale is a lane constant and stores/residual loads are 8 bytes.
 //   grid      one block per tile; block ids are remapped so each XCD (private L2) owns a contiguous
 //             range of tiles, rastered 4 (M) x n inside it.
 //   edges     M/N: source rows clamped, stores masked.  K tail: lanes past K read a zero page.
+#include <type_traits>
 #include "common.h"
 
 namespace fdm {
 
 enum { DT_FP8 = 0, DT_INT8 = 1, DT_BF16 = 2 };
 
-constexpr int BM = 256, BN = 256, BKB = 128;  // BKB = K-tile in bytes
+constexpr int BM = 256, BN = 256, BKB = 64;  // BKB = K-step in bytes
 constexpr int GEMM_THREADS = 512;
-constexpr int STAGE_BYTES = (BM + BN) * BKB;  // 64 KiB
+constexpr int NSTAGE = 4;
+constexpr int STAGE_BYTES = (BM + BN) * BKB;  // 32 KiB
 constexpr int GROUP_M = 4;
 
 __device__ __attribute__((aligned(16))) uint8_t g_zero_page[16] = {0};
@@ -100,12 +108,24 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, uint8_t* lds_wave_ba
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+template <int DT>
+struct FragsA {
+  static constexpr int NS = BKB / Mma<DT>::KS;  // MFMA k-slices per step (1 for fp8, 2 for int8/bf16)
+  typename Mma<DT>::Frag a[NS][4];
+};
+template <int DT>
+struct FragsB {
+  static constexpr int NS = BKB / Mma<DT>::KS;
+  typename Mma<DT>::Frag b[NS][2];
+};
+
 template <int DT, int EPI>
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmParams p) {
   using M = Mma<DT>;
   using Acc = typename M::Acc;
   using Frag = typename M::Frag;
-  __shared__ __attribute__((aligned(1024))) uint8_t smem[2 * STAGE_BYTES];
+  constexpr int NS = FragsA<DT>::NS;
+  __shared__ __attribute__((aligned(1024))) uint8_t smem[NSTAGE * STAGE_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -129,36 +149,69 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmParams 
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // ---- staging: thread t, round i moves 16-byte chunk (row = i*64 + t/8, slot = t%8)
-  const int srow = tid >> 3;
-  const int schunk = (tid & 7) ^ ((srow >> 1) & 7);  // source chunk that lands in slot tid%8
-  const uint8_t* ga[4];
-  const uint8_t* gb[4];
+  // ---- staging: thread t, round i moves the 16-byte chunk that lands at (row = i*128 + t/4, slot = t%4)
+  const int srow = tid >> 2;
+  const int schunk = (tid & 3) ^ ((srow >> 2) & 3);  // source chunk for that slot
+  const uint8_t* ga[2];
+  const uint8_t* gb[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int ra = min(m0 + i * 64 + srow, p.M - 1);
-    int rb = min(n0 + i * 64 + srow, p.N - 1);
+  for (int i = 0; i < 2; ++i) {
+    int ra = min(m0 + i * 128 + srow, p.M - 1);
+    int rb = min(n0 + i * 128 + srow, p.N - 1);
     ga[i] = p.A + (int64_t)ra * p.lda + schunk * 16;
     gb[i] = p.B + (int64_t)rb * p.ldb + schunk * 16;
   }
   const int nk = (int)((p.Kb + BKB - 1) / BKB);
 
-  auto stage = [&](int buf, int kt) {
-    uint8_t* sA = smem + buf * STAGE_BYTES + wave * 1024;
+  // Every step issues exactly 4 DMAs per wave, also past the end of K (then from a 16-byte zero page, which
+  // zero-fills the stage): the loop body is branch-free, s_waitcnt counts are constants, the K tail and the
+  // odd-step padding both multiply zeros.
+  const uint8_t* zero_page = g_zero_page;
+  auto stage = [&](int kt) {
+    uint8_t* sA = smem + (kt & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024;
     uint8_t* sB = sA + BM * BKB;
     const int64_t koff = (int64_t)kt * BKB;
-    const bool tail = (koff + schunk * 16 >= p.Kb);  // only possible in the last tile
+    const bool ok = koff + schunk * 16 < p.Kb;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(tail ? g_zero_page : ga[i] + koff, sA + i * 8192);
+    for (int i = 0; i < 2; ++i) glds16(ok ? ga[i] + koff : zero_page, sA + i * 8192);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(tail ? g_zero_page : gb[i] + koff, sB + i * 8192);
+    for (int i = 0; i < 2; ++i) glds16(ok ? gb[i] + koff : zero_page, sB + i * 8192);
   };
 
   // ---- fragment read addresses (byte offsets inside a stage)
   const int lrow = lane & 31, g = lane >> 5;
-  const int sw = (lrow >> 1) & 7;
+  const int sw = (lrow >> 2) & 3;
   const int a_row_off = (wm * 128 + lrow) * BKB;
   const int b_row_off = BM * BKB + (wn * 64 + lrow) * BKB;
+
+  auto frag_cols = [&](int s, int& c0, int& c1) {
+    if constexpr (M::KS == 64) {
+      c0 = ((g * 2) ^ sw) * 16;
+      c1 = ((g * 2 + 1) ^ sw) * 16;
+    } else {
+      c0 = ((s * 2 + g) ^ sw) * 16;
+      c1 = c0;
+    }
+  };
+  auto read_a = [&](FragsA<DT>& f, int kt, int i) {
+    const uint8_t* st = smem + (kt & (NSTAGE - 1)) * STAGE_BYTES + a_row_off + i * 32 * BKB;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      int c0, c1;
+      frag_cols(s, c0, c1);
+      f.a[s][i] = lds_frag<Frag>(st + c0, st + c1);
+    }
+  };
+  auto read_b = [&](FragsB<DT>& f, int kt) {
+    const uint8_t* st = smem + (kt & (NSTAGE - 1)) * STAGE_BYTES + b_row_off;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      int c0, c1;
+      frag_cols(s, c0, c1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) f.b[s][j] = lds_frag<Frag>(st + j * 32 * BKB + c0, st + j * 32 * BKB + c1);
+    }
+  };
 
   Acc acc[4][2];
 #pragma unroll
@@ -168,82 +221,117 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmParams 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
 
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // ---- prologue: DMAs of steps 0..2 in flight, fragments of step 0 in registers
+  stage(0);
+  stage(1);
+  stage(2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  FragsA<DT> fa;
+  FragsB<DT> fb0, fb1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) read_a(fa, 0, i);
+  read_b(fb0, 0);
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const uint8_t* st = smem + cur * STAGE_BYTES;
-#pragma unroll
-    for (int s = 0; s < BKB / M::KS; ++s) {
-      Frag af[4], bfr[2];
-      int c0, c1;
-      if constexpr (M::KS == 64) {
-        c0 = ((s * 4 + g * 2) ^ sw) * 16;
-        c1 = ((s * 4 + g * 2 + 1) ^ sw) * 16;
-      } else {
-        c0 = ((s * 2 + g) ^ sw) * 16;
-        c1 = c0;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = lds_frag<Frag>(st + a_row_off + i * 32 * BKB + c0, st + a_row_off + i * 32 * BKB + c1);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bfr[j] = lds_frag<Frag>(st + b_row_off + j * 32 * BKB + c0, st + b_row_off + j * 32 * BKB + c1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = M::run(af[i], bfr[j], acc[i][j]);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  // ---- epilogue.  Lane holds column n = n0 + wn*64 + j*32 + (lane&31) and rows
-  //      m = m0 + wm*128 + i*32 + (e&3) + 8*(e>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + lrow;
-    const bool n_ok = n < p.N;
-    const int nc = n_ok ? n : 0;
-    float sbn = 1.0f, biasn = 0.0f;
-    int adjn = 0;
-    if constexpr (DT != DT_BF16) sbn = p.sb[nc];
-    if (p.bias != nullptr) biasn = bf2f(p.bias[nc]);
-    if constexpr (DT == DT_INT8) {
-      if (p.azp_adj != nullptr) adjn = p.azp_adj[nc];
-    }
+  // One step: wait for DMA(t+1) (leaving DMA(t+2) in flight), barrier, issue DMA(t+3), then MFMA(t) with the
+  // fragments of step t+1 streaming in behind it: B fragments are double buffered, each A fragment is replaced
+  // in place as soon as its two MFMAs have issued (keeps the kernel under 256 VGPRs).
+  auto step = [&](FragsB<DT>& bc, FragsB<DT>& bn, int t) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(t + 3);
+    read_b(bn, t + 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-        if (m < p.M && n_ok) {
-          float y;
-          if constexpr (DT == DT_FP8) {
-            y = acc[i][j][e] * p.sa[m] * sbn;
-            if (p.bias != nullptr) y += biasn;
-            y = rbf(y);
-          } else if constexpr (DT == DT_INT8) {
-            int a = acc[i][j][e];
-            if (p.azp != nullptr) a -= p.azp[m] * adjn;
-            y = rbf((float)a * (p.sa[m] * sbn));
-            if (p.bias != nullptr) y = rbf(y + biasn);
-          } else {
-            y = acc[i][j][e];
-            if (p.bias != nullptr) y += biasn;
-            y = rbf(y);
-          }
-          if constexpr (EPI == FDM_EPI_GELU_TANH) y = gelu_tanh_f(y);
-          if constexpr (EPI == FDM_EPI_GELU_ERF) y = gelu_erf_f(y);
-          if constexpr (EPI == FDM_EPI_GATE_RESIDUAL) {
-            const int64_t b = m / p.rows_per_batch;
-            const float gt = bf2f(p.gate[b * p.gate_stride + n]);
-            y = bf2f(p.res[(int64_t)m * p.ldc + n]) + rbf(gt * y);
-          }
-          p.C[(int64_t)m * p.ldc + n] = f2bf(y);
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = M::run(bc.b[s][j], fa.a[s][i], acc[i][j]);  // swapped: rows = n, cols = m
+      read_a(fa, t + 1, i);
+    }
+  };
+  const int nk2 = (nk + 1) & ~1;
+  for (int t = 0; t < nk2; t += 2) {
+    step(fb0, fb1, t);
+    step(fb1, fb0, t + 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the padding DMAs before the LDS is released
+
+  // ---- epilogue.  Swapped operands: lane holds row m = m0 + wm*128 + i*32 + (lane&31) and columns
+  //      n = n0 + wn*64 + j*32 + 8*q + 4*(lane>>5) + (0..3) for register quad q = e>>2.
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 128 + i * 32 + lrow;
+    const bool m_ok = m < p.M;
+    const int mc = m_ok ? m : 0;
+    float sam = 1.0f;
+    int azpm = 0;
+    if constexpr (DT != DT_BF16) sam = p.sa[mc];
+    if constexpr (DT == DT_INT8) {
+      if (p.azp != nullptr) azpm = p.azp[mc];
+    }
+    const bf16_t* gate_row = nullptr;
+    if constexpr (EPI == FDM_EPI_GATE_RESIDUAL) gate_row = p.gate + (mc / p.rows_per_batch) * p.gate_stride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * g;
+        if (!m_ok || n >= p.N) continue;  // N % 4 == 0 is guaranteed (N % 16 == 0), so a quad is all-in or all-out
+        float sb4[4] = {1.f, 1.f, 1.f, 1.f}, bias4[4] = {0.f, 0.f, 0.f, 0.f};
+        int adj4[4] = {0, 0, 0, 0};
+        if constexpr (DT != DT_BF16) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(p.sb + n);
+          sb4[0] = v[0]; sb4[1] = v[1]; sb4[2] = v[2]; sb4[3] = v[3];
         }
+        if (p.bias != nullptr) {
+          const i32x2 v = *reinterpret_cast<const i32x2*>(p.bias + n);
+          bias4[0] = __builtin_bit_cast(float, (uint32_t)v[0] << 16);
+          bias4[1] = __builtin_bit_cast(float, (uint32_t)v[0] & 0xffff0000u);
+          bias4[2] = __builtin_bit_cast(float, (uint32_t)v[1] << 16);
+          bias4[3] = __builtin_bit_cast(float, (uint32_t)v[1] & 0xffff0000u);
+        }
+        if constexpr (DT == DT_INT8) {
+          if (p.azp_adj != nullptr) {
+            const i32x4 v = *reinterpret_cast<const i32x4*>(p.azp_adj + n);
+            adj4[0] = v[0]; adj4[1] = v[1]; adj4[2] = v[2]; adj4[3] = v[3];
+          }
+        }
+        float y[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int e = 4 * q + c;
+          if constexpr (DT == DT_FP8) {
+            float v = acc[i][j][e] * sam * sb4[c];
+            if (p.bias != nullptr) v += bias4[c];
+            y[c] = rbf(v);
+          } else if constexpr (DT == DT_INT8) {
+            const int a = acc[i][j][e] - azpm * adj4[c];
+            float v = rbf((float)a * (sam * sb4[c]));
+            if (p.bias != nullptr) v = rbf(v + bias4[c]);
+            y[c] = v;
+          } else {
+            float v = acc[i][j][e];
+            if (p.bias != nullptr) v += bias4[c];
+            y[c] = rbf(v);
+          }
+          if constexpr (EPI == FDM_EPI_GELU_TANH) y[c] = gelu_tanh_f(y[c]);
+          if constexpr (EPI == FDM_EPI_GELU_ERF) y[c] = gelu_erf_f(y[c]);
+        }
+        if constexpr (EPI == FDM_EPI_GATE_RESIDUAL) {
+          const i32x2 gv = *reinterpret_cast<const i32x2*>(gate_row + n);
+          const i32x2 rv = *reinterpret_cast<const i32x2*>(p.res + (int64_t)m * p.ldc + n);
+          const float g4[4] = {__builtin_bit_cast(float, (uint32_t)gv[0] << 16), __builtin_bit_cast(float, (uint32_t)gv[0] & 0xffff0000u),
+                               __builtin_bit_cast(float, (uint32_t)gv[1] << 16), __builtin_bit_cast(float, (uint32_t)gv[1] & 0xffff0000u)};
+          const float r4[4] = {__builtin_bit_cast(float, (uint32_t)rv[0] << 16), __builtin_bit_cast(float, (uint32_t)rv[0] & 0xffff0000u),
+                               __builtin_bit_cast(float, (uint32_t)rv[1] << 16), __builtin_bit_cast(float, (uint32_t)rv[1] & 0xffff0000u)};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) y[c] = r4[c] + rbf(g4[c] * y[c]);
+        }
+        i32x2 o;
+        o[0] = (int)pack2bf(y[0], y[1]);
+        o[1] = (int)pack2bf(y[2], y[3]);
+        *reinterpret_cast<i32x2*>(p.C + (int64_t)m * p.ldc + n) = o;
       }
     }
   }
@@ -271,7 +359,9 @@ static int fill_params(GemmParams& p, void* out, const void* a, const void* b, i
   if (M > 0x7fffffff || N > 0x7fffffff) return FDM_ERR_UNSUPPORTED;
   if ((K * elem_bytes) % 16 || (lda * elem_bytes) % 16 || (ldb * elem_bytes) % 16 || lda < K || ldb < K || ldc < N)
     return FDM_ERR_INVALID;
-  if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(b) & 15) || (reinterpret_cast<uintptr_t>(out) & 1))
+  if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(b) & 15) || (reinterpret_cast<uintptr_t>(out) & 7) || (ldc & 3) || (N & 3))
+    return FDM_ERR_INVALID;
+  if (epi == FDM_EPI_GATE_RESIDUAL && ((reinterpret_cast<uintptr_t>(gate) & 7) || (reinterpret_cast<uintptr_t>(res) & 7) || (gate_stride & 3)))
     return FDM_ERR_INVALID;
   if (epi == FDM_EPI_GATE_RESIDUAL && (!gate || !res || rpb <= 0)) return FDM_ERR_INVALID;
   p.A = (const uint8_t*)a;
