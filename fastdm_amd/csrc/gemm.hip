@@ -1,4 +1,4 @@
-// W8A8 (fp8 / int8) and bf16 GEMM for gfx950:  C[M,N] = epi(A[M,K] . B[N,K]^T)
+// W8A8 (fp8 / int8) and bf16 GEMM for gfx950:  C[M,N] = epi(A[M,K] . B[N,K]^T), 1 or 2 problems per launch.
 //
 // Both operands are K-contiguous (A row-major, B = the reference's column-major [K,N] weight,
 // i.e. [N,K] row-major), which is exactly the MFMA operand order, so tiles go global -> LDS with
@@ -7,18 +7,30 @@
 //   tile      256 x 256, K-step 64 bytes; 8 waves = 2 (M) x 4 (N), wave tile 128 x 64
 //   fp8       v_mfma_scale_f32_32x32x64_f8f6f4 with unit E8M0 scales (2x the bf16 MFMA rate)
 //   int8      v_mfma_i32_32x32x32_i8           bf16: v_mfma_f32_32x32x16_bf16
-//   pipeline  4-stage LDS ring of 32 KiB (A 16 KiB + B 16 KiB): while step t runs on registers, the
-//             fragments of step t+1 are read from LDS and the DMAs of steps t+2, t+3 are in flight.
-//             One raw s_barrier per step behind a COUNTED s_waitcnt vmcnt(4) (never 0 in the loop), so
-//             LDS-DMA stays in flight across barriers.
+//   grid      one block per tile; block ids are remapped so each XCD (private L2) owns a contiguous
+//             range of tiles, rastered 4 (M) x n inside it.  Two problems (e.g. the image- and text-stream
+//             projections of a double block, different weights) can share one launch: the small one's
+//             tiles fill the last partial round of the large one.
+//   pipeline  4-stage LDS ring of 32 KiB: while step t runs on registers, the fragments of step t+1 are
+//             read from LDS and the DMAs of steps t+2, t+3 are in flight.  One raw s_barrier per step
+//             behind a COUNTED s_waitcnt vmcnt(4) (never 0 in the loop), so LDS-DMA stays in flight across
+//             barriers.  B fragments are double buffered, each A fragment is replaced in place as soon as
+//             its MFMAs have issued (fits 256 VGPRs).  Measured alternatives on MI355X, both slower: a
+//             two-phase schedule with waves 4-7 one phase behind waves 0-3 (two barriers per step: -35 %),
+//             and a persistent grid with a continuous DMA stream across tile seams (cursor bookkeeping in
+//             the step body: -15 %).
 //   LDS       rows are 64 B; chunk c of row r lives in slot c ^ ((r >> 2) & 3): conflict-free for the
 //             ds_read_b128 lane groups.  LDS-DMA writes are lane-linear, so the swizzle is applied to
 //             the per-lane SOURCE address.
-//   operands  swapped (D^T = B . A^T): a lane then owns ONE output row m and 4 consecutive columns per
-//             register quad -> per-row scale is a lane constant and stores/residual loads are 8 bytes.
-//   grid      one block per tile; block ids are remapped so each XCD (private L2) owns a contiguous
-//             range of tiles, rastered 4 (M) x n inside it.
-//   edges     M/N: source rows clamped, stores masked.  K tail: lanes past K read a zero page.
+//   operands  swapped (D^T = B . A^T): a lane owns ONE output row m and 4 consecutive columns per
+//             register quad -> the per-row scale is a lane constant.
+//   epilogue  scale/bias/activation in registers, rounded to bf16, then each wave transposes its 128x64
+//             sub-tile through its own 16 KiB of the (now dead) LDS ring so that every global access is a
+//             16-byte row-contiguous vector (8 full 128-byte rows per wave-instruction): 16 stores per
+//             lane instead of 32 scattered 8-byte ones; residual / gate are read the same way, all loads
+//             before the first store (vmcnt retires in order).
+//   edges     M/N: source rows clamped, stores masked.  K tail / stream end: lanes fetch a zero page.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 
@@ -34,7 +46,7 @@ constexpr int GROUP_M = 4;
 
 __device__ __attribute__((aligned(16))) uint8_t g_zero_page[16] = {0};
 
-struct GemmParams {
+struct GemmProblem {
   const uint8_t* A;
   const uint8_t* B;
   bf16_t* C;
@@ -52,6 +64,14 @@ struct GemmParams {
   int64_t lda, ldb;  // bytes
   int64_t ldc;       // elements
   int tiles_m, tiles_n;
+  int epi;           // FDM_EPI_* (uniform per problem)
+};
+
+struct GemmGroup {
+  GemmProblem p[2];
+  int n;            // 1 or 2 problems
+  int total_tiles;
+  int debug;        // bring-up ablations (env FDM_GEMM_DEBUG): 1 = no steady-state DMA, 2 = no fragment reads, 4 = no stores
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -108,23 +128,39 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, uint8_t* lds_wave_ba
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int DT>
-struct FragsA {
-  static constexpr int NS = BKB / Mma<DT>::KS;  // MFMA k-slices per step (1 for fp8, 2 for int8/bf16)
-  typename Mma<DT>::Frag a[NS][4];
-};
-template <int DT>
-struct FragsB {
-  static constexpr int NS = BKB / Mma<DT>::KS;
-  typename Mma<DT>::Frag b[NS][2];
-};
+// cheap activations for the epilogue (libm tanhf/erff cost ~40 VALU each; x128 values per lane that is
+// longer than the K=3072 main loop).  |error| <= ~2e-7 absolute before the bf16 rounding.
+__device__ __forceinline__ float fast_gelu_tanh(float x) {
+  const float u = 0.79788456080286535588f * (x + 0.044715f * x * x * x);
+  const float e = __builtin_amdgcn_exp2f(u * 2.885390081777927f);  // exp(2u)
+  const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  return 0.5f * x * (1.0f + th);
+}
+__device__ __forceinline__ float fast_gelu_erf(float x) {
+  // Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): erf(z) = 1 - poly(t) exp(-z^2), t = 1/(1 + p z), z >= 0
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float er = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+  const float erf_x = x < 0.f ? -er : er;
+  return 0.5f * x * (1.0f + erf_x);
+}
 
-template <int DT, int EPI>
-__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void unpack4(const i32x2 v, float (&o)[4]) {
+  o[0] = __builtin_bit_cast(float, (uint32_t)v[0] << 16);
+  o[1] = __builtin_bit_cast(float, (uint32_t)v[0] & 0xffff0000u);
+  o[2] = __builtin_bit_cast(float, (uint32_t)v[1] << 16);
+  o[3] = __builtin_bit_cast(float, (uint32_t)v[1] & 0xffff0000u);
+}
+
+// RES: the launch contains a FDM_EPI_GATE_RESIDUAL problem (a separate instantiation keeps that epilogue's
+// residual registers out of the common kernels).
+template <int DT, bool RES>
+__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup grp) {
   using M = Mma<DT>;
   using Acc = typename M::Acc;
   using Frag = typename M::Frag;
-  constexpr int NS = FragsA<DT>::NS;
+  constexpr int NS = BKB / M::KS;  // MFMA k-slices per step (1 for fp8, 2 for int8/bf16)
   __shared__ __attribute__((aligned(1024))) uint8_t smem[NSTAGE * STAGE_BYTES];
 
   const int tid = threadIdx.x;
@@ -132,22 +168,28 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmParams 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
-  // ---- block -> tile (XCD-contiguous, then grouped raster)
-  int tm, tn;
+  // ---- block -> (problem, tile): XCD-contiguous ranges of the concatenated tile list, grouped raster inside a problem
+  int prob = 0, m0, n0;
   {
-    const int nwg = p.tiles_m * p.tiles_n;
+    const int nwg = grp.total_tiles;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int in_group = GROUP_M * p.tiles_n;
+    int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int t0 = grp.p[0].tiles_m * grp.p[0].tiles_n;
+    if (t >= t0) {
+      prob = 1;
+      t -= t0;
+    }
+    const GemmProblem& pp = grp.p[prob];
+    const int in_group = GROUP_M * pp.tiles_n;
     const int gid = t / in_group;
     const int first_m = gid * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int gsz = min(pp.tiles_m - first_m, GROUP_M);
     const int rem = t - gid * in_group;
-    tm = first_m + rem % gsz;
-    tn = rem / gsz;
+    m0 = (first_m + rem % gsz) * BM;
+    n0 = (rem / gsz) * BN;
   }
-  const int m0 = tm * BM, n0 = tn * BN;
+  const GemmProblem& p = grp.p[prob];
 
   // ---- staging: thread t, round i moves the 16-byte chunk that lands at (row = i*128 + t/4, slot = t%4)
   const int srow = tid >> 2;
@@ -156,12 +198,13 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmParams 
   const uint8_t* gb[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    int ra = min(m0 + i * 128 + srow, p.M - 1);
-    int rb = min(n0 + i * 128 + srow, p.N - 1);
+    const int ra = min(m0 + i * 128 + srow, p.M - 1);
+    const int rb = min(n0 + i * 128 + srow, p.N - 1);
     ga[i] = p.A + (int64_t)ra * p.lda + schunk * 16;
     gb[i] = p.B + (int64_t)rb * p.ldb + schunk * 16;
   }
-  const int nk = (int)((p.Kb + BKB - 1) / BKB);
+  const int64_t Kb = p.Kb;
+  const int nk = (int)((Kb + BKB - 1) / BKB);
 
   // Every step issues exactly 4 DMAs per wave, also past the end of K (then from a 16-byte zero page, which
   // zero-fills the stage): the loop body is branch-free, s_waitcnt counts are constants, the K tail and the
@@ -171,7 +214,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmParams 
     uint8_t* sA = smem + (kt & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024;
     uint8_t* sB = sA + BM * BKB;
     const int64_t koff = (int64_t)kt * BKB;
-    const bool ok = koff + schunk * 16 < p.Kb;
+    const bool ok = koff + schunk * 16 < Kb;
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(ok ? ga[i] + koff : zero_page, sA + i * 8192);
 #pragma unroll
@@ -183,7 +226,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmParams 
   const int sw = (lrow >> 2) & 3;
   const int a_row_off = (wm * 128 + lrow) * BKB;
   const int b_row_off = BM * BKB + (wn * 64 + lrow) * BKB;
-
+  Frag fa[NS][4], fb0[NS][2], fb1[NS][2];
   auto frag_cols = [&](int s, int& c0, int& c1) {
     if constexpr (M::KS == 64) {
       c0 = ((g * 2) ^ sw) * 16;
@@ -193,23 +236,23 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmParams 
       c1 = c0;
     }
   };
-  auto read_a = [&](FragsA<DT>& f, int kt, int i) {
+  auto read_a = [&](int kt, int i) {
     const uint8_t* st = smem + (kt & (NSTAGE - 1)) * STAGE_BYTES + a_row_off + i * 32 * BKB;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       int c0, c1;
       frag_cols(s, c0, c1);
-      f.a[s][i] = lds_frag<Frag>(st + c0, st + c1);
+      fa[s][i] = lds_frag<Frag>(st + c0, st + c1);
     }
   };
-  auto read_b = [&](FragsB<DT>& f, int kt) {
+  auto read_b = [&](Frag (&fb)[NS][2], int kt) {
     const uint8_t* st = smem + (kt & (NSTAGE - 1)) * STAGE_BYTES + b_row_off;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       int c0, c1;
       frag_cols(s, c0, c1);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) f.b[s][j] = lds_frag<Frag>(st + j * 32 * BKB + c0, st + j * 32 * BKB + c1);
+      for (int j = 0; j < 2; ++j) fb[s][j] = lds_frag<Frag>(st + j * 32 * BKB + c0, st + j * 32 * BKB + c1);
     }
   };
 
@@ -227,16 +270,13 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmParams 
   stage(2);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  FragsA<DT> fa;
-  FragsB<DT> fb0, fb1;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) read_a(fa, 0, i);
+  for (int i = 0; i < 4; ++i) read_a(0, i);
   read_b(fb0, 0);
 
   // One step: wait for DMA(t+1) (leaving DMA(t+2) in flight), barrier, issue DMA(t+3), then MFMA(t) with the
-  // fragments of step t+1 streaming in behind it: B fragments are double buffered, each A fragment is replaced
-  // in place as soon as its two MFMAs have issued (keeps the kernel under 256 VGPRs).
-  auto step = [&](FragsB<DT>& bc, FragsB<DT>& bn, int t) {
+  // fragments of step t+1 streaming in behind it.
+  auto step = [&](Frag (&bc)[NS][2], Frag (&bn)[NS][2], int t) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     stage(t + 3);
@@ -246,8 +286,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmParams 
 #pragma unroll
       for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = M::run(bc.b[s][j], fa.a[s][i], acc[i][j]);  // swapped: rows = n, cols = m
-      read_a(fa, t + 1, i);
+        for (int j = 0; j < 2; ++j) acc[i][j] = M::run(bc[s][j], fa[s][i], acc[i][j]);  // swapped: rows = n, cols = m
+      read_a(t + 1, i);
     }
   };
   const int nk2 = (nk + 1) & ~1;
@@ -255,115 +295,177 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmParams 
     step(fb0, fb1, t);
     step(fb1, fb0, t + 1);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the padding DMAs before the LDS is released
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // retire the padding DMAs and the dead fragment reads
+  __builtin_amdgcn_s_barrier();                                  // every wave is done with the ring: reuse it below
 
-  // ---- epilogue.  Swapped operands: lane holds row m = m0 + wm*128 + i*32 + (lane&31) and columns
-  //      n = n0 + wn*64 + j*32 + 8*q + 4*(lane>>5) + (0..3) for register quad q = e>>2.
+  // ---- epilogue
+  // MFMA layout (swapped operands): lane holds row m = wm*128 + i*32 + (lane&31) and columns
+  // n = wn*64 + j*32 + 8*q + 4*(lane>>5) + (0..3) for register quad q = e>>2, i.e. 8-byte pieces [m][chunk j*4+q][half g].
+  // Wave-private LDS tile: 128 rows x 128 B, 16-byte chunk c of row r stored at chunk c ^ (r & 7).
+  uint8_t* wt = smem + wave * 16384;
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  auto epilogue = [&](auto epi_c) {
+    constexpr int EPI = decltype(epi_c)::value;
+    // pass 1: scale / bias / activation, round to bf16, write 8-byte pieces to the LDS tile
+    float sam[4];
+    int azpm[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 128 + i * 32 + lrow;
-    const bool m_ok = m < p.M;
-    const int mc = m_ok ? m : 0;
-    float sam = 1.0f;
-    int azpm = 0;
-    if constexpr (DT != DT_BF16) sam = p.sa[mc];
-    if constexpr (DT == DT_INT8) {
-      if (p.azp != nullptr) azpm = p.azp[mc];
+    for (int i = 0; i < 4; ++i) {
+      const int mc = min(m0 + wm * 128 + i * 32 + lrow, p.M - 1);
+      sam[i] = 1.0f;
+      azpm[i] = 0;
+      if constexpr (DT != DT_BF16) sam[i] = p.sa[mc];
+      if constexpr (DT == DT_INT8) {
+        if (p.azp != nullptr) azpm[i] = p.azp[mc];
+      }
     }
-    const bf16_t* gate_row = nullptr;
-    if constexpr (EPI == FDM_EPI_GATE_RESIDUAL) gate_row = p.gate + (mc / p.rows_per_batch) * p.gate_stride;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * g;
-        if (!m_ok || n >= p.N) continue;  // N % 4 == 0 is guaranteed (N % 16 == 0), so a quad is all-in or all-out
-        float sb4[4] = {1.f, 1.f, 1.f, 1.f}, bias4[4] = {0.f, 0.f, 0.f, 0.f};
-        int adj4[4] = {0, 0, 0, 0};
-        if constexpr (DT != DT_BF16) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(p.sb + n);
-          sb4[0] = v[0]; sb4[1] = v[1]; sb4[2] = v[2]; sb4[3] = v[3];
-        }
-        if (p.bias != nullptr) {
-          const i32x2 v = *reinterpret_cast<const i32x2*>(p.bias + n);
-          bias4[0] = __builtin_bit_cast(float, (uint32_t)v[0] << 16);
-          bias4[1] = __builtin_bit_cast(float, (uint32_t)v[0] & 0xffff0000u);
-          bias4[2] = __builtin_bit_cast(float, (uint32_t)v[1] << 16);
-          bias4[3] = __builtin_bit_cast(float, (uint32_t)v[1] & 0xffff0000u);
-        }
+        const int nc = min(n0 + wn * 64 + j * 32 + 8 * q + 4 * g, p.N - 4);
+        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sbq = {1.f, 1.f, 1.f, 1.f};
+        i32x4 adjq = {0, 0, 0, 0};
+        if constexpr (DT != DT_BF16) sbq = *reinterpret_cast<const f32x4*>(p.sb + nc);
+        if (p.bias != nullptr) unpack4(*reinterpret_cast<const i32x2*>(p.bias + nc), bias4);
         if constexpr (DT == DT_INT8) {
-          if (p.azp_adj != nullptr) {
-            const i32x4 v = *reinterpret_cast<const i32x4*>(p.azp_adj + n);
-            adj4[0] = v[0]; adj4[1] = v[1]; adj4[2] = v[2]; adj4[3] = v[3];
-          }
+          if (p.azp_adj != nullptr) adjq = *reinterpret_cast<const i32x4*>(p.azp_adj + nc);
         }
-        float y[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int e = 4 * q + c;
-          if constexpr (DT == DT_FP8) {
-            float v = acc[i][j][e] * sam * sb4[c];
-            if (p.bias != nullptr) v += bias4[c];
-            y[c] = rbf(v);
-          } else if constexpr (DT == DT_INT8) {
-            const int a = acc[i][j][e] - azpm * adj4[c];
-            float v = rbf((float)a * (sam * sb4[c]));
-            if (p.bias != nullptr) v = rbf(v + bias4[c]);
-            y[c] = v;
-          } else {
-            float v = acc[i][j][e];
-            if (p.bias != nullptr) v += bias4[c];
-            y[c] = rbf(v);
-          }
-          if constexpr (EPI == FDM_EPI_GELU_TANH) y[c] = gelu_tanh_f(y[c]);
-          if constexpr (EPI == FDM_EPI_GELU_ERF) y[c] = gelu_erf_f(y[c]);
-        }
-        if constexpr (EPI == FDM_EPI_GATE_RESIDUAL) {
-          const i32x2 gv = *reinterpret_cast<const i32x2*>(gate_row + n);
-          const i32x2 rv = *reinterpret_cast<const i32x2*>(p.res + (int64_t)m * p.ldc + n);
-          const float g4[4] = {__builtin_bit_cast(float, (uint32_t)gv[0] << 16), __builtin_bit_cast(float, (uint32_t)gv[0] & 0xffff0000u),
-                               __builtin_bit_cast(float, (uint32_t)gv[1] << 16), __builtin_bit_cast(float, (uint32_t)gv[1] & 0xffff0000u)};
-          const float r4[4] = {__builtin_bit_cast(float, (uint32_t)rv[0] << 16), __builtin_bit_cast(float, (uint32_t)rv[0] & 0xffff0000u),
-                               __builtin_bit_cast(float, (uint32_t)rv[1] << 16), __builtin_bit_cast(float, (uint32_t)rv[1] & 0xffff0000u)};
+        for (int i = 0; i < 4; ++i) {
+          float y[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) y[c] = r4[c] + rbf(g4[c] * y[c]);
+          for (int c = 0; c < 4; ++c) {
+            const int e = 4 * q + c;
+            if constexpr (DT == DT_FP8) {
+              y[c] = acc[i][j][e] * sam[i] * sbq[c] + bias4[c];
+            } else if constexpr (DT == DT_INT8) {
+              const int a = acc[i][j][e] - azpm[i] * adjq[c];
+              y[c] = (float)a * (sam[i] * sbq[c]);
+              if (p.bias != nullptr) y[c] = rbf(y[c]) + bias4[c];
+            } else {
+              y[c] = acc[i][j][e] + bias4[c];
+            }
+            if constexpr (EPI == FDM_EPI_GELU_TANH) y[c] = fast_gelu_tanh(rbf(y[c]));
+            if constexpr (EPI == FDM_EPI_GELU_ERF) y[c] = fast_gelu_erf(rbf(y[c]));
+          }
+          i32x2 o;
+          o[0] = (int)pack2bf(y[0], y[1]);
+          o[1] = (int)pack2bf(y[2], y[3]);
+          const int r = i * 32 + lrow;
+          *reinterpret_cast<i32x2*>(wt + r * 128 + (((j * 4 + q) ^ (r & 7)) << 4) + g * 8) = o;
         }
-        i32x2 o;
-        o[0] = (int)pack2bf(y[0], y[1]);
-        o[1] = (int)pack2bf(y[2], y[3]);
-        *reinterpret_cast<i32x2*>(p.C + (int64_t)m * p.ldc + n) = o;
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: no block barrier needed
+    __builtin_amdgcn_sched_barrier(0);
+    // pass 2: row-contiguous 16-byte pieces.  Instruction it: lane -> row 8*it + lane/8, chunk lane%8.
+    const int rsub = lane >> 3, ch = lane & 7;
+    const int ncol = n0 + wn * 64 + ch * 8;
+    const bool n_ok = full || ncol < p.N;      // N % 8 == 0 is required by the host check for this path
+    const int ncc = n_ok ? ncol : 0;
+    auto lds_row = [&](int it) -> i32x4 {
+      const int r = it * 8 + rsub;
+      return *reinterpret_cast<const i32x4*>(wt + r * 128 + ((ch ^ (r & 7)) << 4));
+    };
+    auto store_row = [&](int it, const i32x4& v) {
+      const int m = m0 + wm * 128 + it * 8 + rsub;
+      if (n_ok && (full || m < p.M) && !(grp.debug & 4)) *reinterpret_cast<i32x4*>(p.C + (int64_t)m * p.ldc + ncc) = v;
+    };
+    auto combine = [&](const i32x4& yv, const i32x4& gv, const i32x4& rv) -> i32x4 {
+      i32x4 o;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t yw = (uint32_t)yv[w], gw = (uint32_t)gv[w], rw = (uint32_t)rv[w];
+        const float lo = __builtin_bit_cast(float, rw << 16) + rbf(__builtin_bit_cast(float, gw << 16) * __builtin_bit_cast(float, yw << 16));
+        const float hi = __builtin_bit_cast(float, rw & 0xffff0000u) +
+                         rbf(__builtin_bit_cast(float, gw & 0xffff0000u) * __builtin_bit_cast(float, yw & 0xffff0000u));
+        o[w] = (int)pack2bf(lo, hi);
+      }
+      return o;
+    };
+    if constexpr (EPI == FDM_EPI_GATE_RESIDUAL) {
+      const int m_first = m0 + wm * 128, m_last = min(m0 + wm * 128 + 128, p.M) - 1;
+      const bool one_batch = (m_first / p.rows_per_batch) == (m_last / p.rows_per_batch);
+      auto res_row = [&](int it) -> i32x4 {
+        const int mc = min(m0 + wm * 128 + it * 8 + rsub, p.M - 1);
+        return *reinterpret_cast<const i32x4*>(p.res + (int64_t)mc * p.ldc + ncc);
+      };
+      if (one_batch) {
+        // loads(h0) | combine(h0) | loads(h1) | stores(h0) | combine(h1) | stores(h1): every load precedes every store
+        const i32x4 gv = *reinterpret_cast<const i32x4*>(p.gate + (m_first / p.rows_per_batch) * p.gate_stride + ncc);
+        i32x4 r0[8], o0[8], r1[8], o1[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) r0[it] = res_row(it);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) o0[it] = combine(lds_row(it), gv, r0[it]);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) r1[it] = res_row(8 + it);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) store_row(it, o0[it]);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) o1[it] = combine(lds_row(8 + it), gv, r1[it]);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) store_row(8 + it, o1[it]);
+      } else {
+        // the wave's 128 rows straddle a batch boundary (rare): per-row gate vector, unpipelined
+        for (int it = 0; it < 16; ++it) {
+          const int mc = min(m0 + wm * 128 + it * 8 + rsub, p.M - 1);
+          const i32x4 gv = *reinterpret_cast<const i32x4*>(p.gate + (mc / p.rows_per_batch) * p.gate_stride + ncc);
+          store_row(it, combine(lds_row(it), gv, res_row(it)));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) store_row(it, lds_row(it));
+    }
+  };
+  if constexpr (RES) {
+    if (p.epi == FDM_EPI_GATE_RESIDUAL) epilogue(std::integral_constant<int, FDM_EPI_GATE_RESIDUAL>{});
+    else if (p.epi == FDM_EPI_GELU_TANH) epilogue(std::integral_constant<int, FDM_EPI_GELU_TANH>{});
+    else if (p.epi == FDM_EPI_GELU_ERF) epilogue(std::integral_constant<int, FDM_EPI_GELU_ERF>{});
+    else epilogue(std::integral_constant<int, FDM_EPI_NONE>{});
+  } else {
+    if (p.epi == FDM_EPI_GELU_TANH) epilogue(std::integral_constant<int, FDM_EPI_GELU_TANH>{});
+    else if (p.epi == FDM_EPI_GELU_ERF) epilogue(std::integral_constant<int, FDM_EPI_GELU_ERF>{});
+    else epilogue(std::integral_constant<int, FDM_EPI_NONE>{});
   }
 }
 
 template <int DT>
-static int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
-  const int grid = p.tiles_m * p.tiles_n;
-  switch (epi) {
-    case FDM_EPI_NONE: gemm_kernel<DT, FDM_EPI_NONE><<<grid, GEMM_THREADS, 0, s>>>(p); break;
-    case FDM_EPI_GELU_TANH: gemm_kernel<DT, FDM_EPI_GELU_TANH><<<grid, GEMM_THREADS, 0, s>>>(p); break;
-    case FDM_EPI_GELU_ERF: gemm_kernel<DT, FDM_EPI_GELU_ERF><<<grid, GEMM_THREADS, 0, s>>>(p); break;
-    case FDM_EPI_GATE_RESIDUAL: gemm_kernel<DT, FDM_EPI_GATE_RESIDUAL><<<grid, GEMM_THREADS, 0, s>>>(p); break;
-    default: return FDM_ERR_UNSUPPORTED;
+static int launch_gemm(const GemmGroup& grp, hipStream_t s) {
+  const int grid = grp.total_tiles;
+  static int debug = -1;
+  if (debug < 0) {
+    const char* e = getenv("FDM_GEMM_DEBUG");
+    debug = e ? atoi(e) : 0;
   }
+  const_cast<GemmGroup&>(grp).debug = debug;
+  const bool res = grp.p[0].epi == FDM_EPI_GATE_RESIDUAL || (grp.n > 1 && grp.p[1].epi == FDM_EPI_GATE_RESIDUAL);
+  if (res) gemm_kernel<DT, true><<<grid, GEMM_THREADS, 0, s>>>(grp);
+  else gemm_kernel<DT, false><<<grid, GEMM_THREADS, 0, s>>>(grp);
   FDM_CHECK_LAUNCH();
   return FDM_OK;
 }
 
-static int fill_params(GemmParams& p, void* out, const void* a, const void* b, int64_t M, int64_t N, int64_t K, int64_t lda,
-                       int64_t ldb, int64_t ldc, int elem_bytes, int epi, const void* gate, int64_t gate_stride, const void* res,
-                       int64_t rpb) {
-  if (M == 0 && N > 0 && K > 0) return FDM_OK;  // callers re-check M == 0 before launching
-  if (!out || !a || !b || M < 0 || N <= 0 || K <= 0) return FDM_ERR_INVALID;
+static int fill_problem(GemmProblem& p, void* out, const void* a, const void* b, int64_t M, int64_t N, int64_t K, int64_t lda,
+                        int64_t ldb, int64_t ldc, int elem_bytes, int epi, const void* gate, int64_t gate_stride, const void* res,
+                        int64_t rpb) {
+  if (!out || !a || !b || M <= 0 || N <= 0 || K <= 0) return FDM_ERR_INVALID;
   if (M > 0x7fffffff || N > 0x7fffffff) return FDM_ERR_UNSUPPORTED;
+  if (epi < FDM_EPI_NONE || epi > FDM_EPI_GATE_RESIDUAL) return FDM_ERR_UNSUPPORTED;
   if ((K * elem_bytes) % 16 || (lda * elem_bytes) % 16 || (ldb * elem_bytes) % 16 || lda < K || ldb < K || ldc < N)
     return FDM_ERR_INVALID;
-  if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(b) & 15) || (reinterpret_cast<uintptr_t>(out) & 7) || (ldc & 3) || (N & 3))
+  if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(b) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) || (ldc & 7) || (N & 7))
     return FDM_ERR_INVALID;
-  if (epi == FDM_EPI_GATE_RESIDUAL && ((reinterpret_cast<uintptr_t>(gate) & 7) || (reinterpret_cast<uintptr_t>(res) & 7) || (gate_stride & 3)))
+  if (epi == FDM_EPI_GATE_RESIDUAL && (!gate || !res || rpb <= 0 || (reinterpret_cast<uintptr_t>(gate) & 15) ||
+                                       (reinterpret_cast<uintptr_t>(res) & 15) || (gate_stride & 7)))
     return FDM_ERR_INVALID;
-  if (epi == FDM_EPI_GATE_RESIDUAL && (!gate || !res || rpb <= 0)) return FDM_ERR_INVALID;
   p.A = (const uint8_t*)a;
   p.B = (const uint8_t*)b;
   p.C = (bf16_t*)out;
@@ -379,10 +481,21 @@ static int fill_params(GemmParams& p, void* out, const void* a, const void* b, i
   p.ldc = ldc;
   p.tiles_m = (int)((M + BM - 1) / BM);
   p.tiles_n = (int)((N + BN - 1) / BN);
+  p.epi = epi;
   p.sa = p.sb = nullptr;
   p.bias = nullptr;
   p.azp = p.azp_adj = nullptr;
   return FDM_OK;
+}
+
+static void finish_group(GemmGroup& g, int n) {
+  g.n = n;
+  g.total_tiles = 0;
+  for (int i = 0; i < n; ++i) g.total_tiles += g.p[i].tiles_m * g.p[i].tiles_n;
+  if (n == 1) {
+    g.p[1] = g.p[0];
+    g.p[1].tiles_m = g.p[1].tiles_n = 0;
+  }
 }
 
 }  // namespace fdm
@@ -395,46 +508,69 @@ int fdm_gemm_w8a8_fp8(void* out, const void* a, const void* b, const float* scal
                       int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int epilogue,
                       const void* epi_gate, int64_t epi_gate_stride, const void* epi_res, int64_t epi_rows_per_batch,
                       fdm_stream_t stream) {
-  GemmParams p;
-  int rc = fill_params(p, out, a, b, M, N, K, lda, ldb, ldc, 1, epilogue, epi_gate, epi_gate_stride, epi_res, epi_rows_per_batch);
+  if (M == 0 && N > 0 && K > 0) return FDM_OK;
+  GemmGroup g;
+  int rc = fill_problem(g.p[0], out, a, b, M, N, K, lda, ldb, ldc, 1, epilogue, epi_gate, epi_gate_stride, epi_res, epi_rows_per_batch);
   if (rc != FDM_OK) return rc;
-  if (M == 0) return FDM_OK;
   if (!scale_a || !scale_b) return FDM_ERR_INVALID;
-  if (M == 0) return FDM_OK;
-  p.sa = scale_a;
-  p.sb = scale_b;
-  p.bias = (const bf16_t*)bias;
-  return launch_gemm<DT_FP8>(p, epilogue, to_stream(stream));
+  g.p[0].sa = scale_a;
+  g.p[0].sb = scale_b;
+  g.p[0].bias = (const bf16_t*)bias;
+  finish_group(g, 1);
+  return launch_gemm<DT_FP8>(g, to_stream(stream));
+}
+
+int fdm_gemm_w8a8_fp8_x2(const fdm_gemm_fp8_desc* d0, const fdm_gemm_fp8_desc* d1, fdm_stream_t stream) {
+  if (!d0 || !d1) return FDM_ERR_INVALID;
+  const fdm_gemm_fp8_desc* ds[2] = {d0, d1};
+  GemmGroup g;
+  int n = 0;
+  for (int i = 0; i < 2; ++i) {
+    const fdm_gemm_fp8_desc* d = ds[i];
+    if (d->M == 0 && d->N > 0 && d->K > 0) continue;
+    int rc = fill_problem(g.p[n], d->out, d->a, d->b, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, 1, (int)d->epilogue, d->epi_gate,
+                          d->epi_gate_stride, d->epi_res, d->epi_rows_per_batch);
+    if (rc != FDM_OK) return rc;
+    if (!d->scale_a || !d->scale_b) return FDM_ERR_INVALID;
+    g.p[n].sa = d->scale_a;
+    g.p[n].sb = d->scale_b;
+    g.p[n].bias = (const bf16_t*)d->bias;
+    ++n;
+  }
+  if (n == 0) return FDM_OK;
+  finish_group(g, n);
+  return launch_gemm<DT_FP8>(g, to_stream(stream));
 }
 
 int fdm_gemm_w8a8_int8(void* out, const void* a, const void* b, const float* scale_a, const float* scale_b,
                        const int32_t* azp_adj, const int32_t* azp, const void* bias, int64_t M, int64_t N, int64_t K,
                        int64_t lda, int64_t ldb, int64_t ldc, int epilogue, const void* epi_gate, int64_t epi_gate_stride,
                        const void* epi_res, int64_t epi_rows_per_batch, fdm_stream_t stream) {
-  GemmParams p;
-  int rc = fill_params(p, out, a, b, M, N, K, lda, ldb, ldc, 1, epilogue, epi_gate, epi_gate_stride, epi_res, epi_rows_per_batch);
+  if (M == 0 && N > 0 && K > 0) return FDM_OK;
+  GemmGroup g;
+  int rc = fill_problem(g.p[0], out, a, b, M, N, K, lda, ldb, ldc, 1, epilogue, epi_gate, epi_gate_stride, epi_res, epi_rows_per_batch);
   if (rc != FDM_OK) return rc;
-  if (M == 0) return FDM_OK;
   if (!scale_a || !scale_b || ((azp == nullptr) != (azp_adj == nullptr))) return FDM_ERR_INVALID;
-  if (M == 0) return FDM_OK;
-  p.sa = scale_a;
-  p.sb = scale_b;
-  p.bias = (const bf16_t*)bias;
-  p.azp = azp;
-  p.azp_adj = azp_adj;
-  return launch_gemm<DT_INT8>(p, epilogue, to_stream(stream));
+  if (azp_adj && (reinterpret_cast<uintptr_t>(azp_adj) & 15)) return FDM_ERR_INVALID;
+  g.p[0].sa = scale_a;
+  g.p[0].sb = scale_b;
+  g.p[0].bias = (const bf16_t*)bias;
+  g.p[0].azp = azp;
+  g.p[0].azp_adj = azp_adj;
+  finish_group(g, 1);
+  return launch_gemm<DT_INT8>(g, to_stream(stream));
 }
 
 int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
                   int64_t ldb, int64_t ldc, int epilogue, const void* epi_gate, int64_t epi_gate_stride, const void* epi_res,
                   int64_t epi_rows_per_batch, fdm_stream_t stream) {
-  GemmParams p;
-  int rc = fill_params(p, out, a, b, M, N, K, lda, ldb, ldc, 2, epilogue, epi_gate, epi_gate_stride, epi_res, epi_rows_per_batch);
+  if (M == 0 && N > 0 && K > 0) return FDM_OK;
+  GemmGroup g;
+  int rc = fill_problem(g.p[0], out, a, b, M, N, K, lda, ldb, ldc, 2, epilogue, epi_gate, epi_gate_stride, epi_res, epi_rows_per_batch);
   if (rc != FDM_OK) return rc;
-  if (M == 0) return FDM_OK;
-  if (M == 0) return FDM_OK;
-  p.bias = (const bf16_t*)bias;
-  return launch_gemm<DT_BF16>(p, epilogue, to_stream(stream));
+  g.p[0].bias = (const bf16_t*)bias;
+  finish_group(g, 1);
+  return launch_gemm<DT_BF16>(g, to_stream(stream));
 }
 
 }  // extern "C"

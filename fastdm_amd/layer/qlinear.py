@@ -97,6 +97,36 @@ class QLinear:
                     "bf16 linear")
         return out
 
+    def _desc(self, x, epilogue, gate, res, rows_per_batch, out):
+        wt = self.weight
+        K, Nn = wt.shape
+        a = x.q
+        M = a.shape[0]
+        if out is None:
+            out = torch.empty((M, Nn), device=a.device, dtype=self.dtype)
+        d = N.GemmFp8Desc()
+        d.out, d.a, d.b = N.ptr(out), N.ptr(a), N.ptr(wt)
+        d.scale_a, d.scale_b, d.bias = N.ptr(x.scale), N.ptr(self.weight_quant_scale), N.ptr(self.bias)
+        d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, Nn, K, a.stride(0), wt.stride(1), out.stride(0)
+        d.epilogue = epilogue
+        d.epi_gate, d.epi_gate_stride = (N.ptr(gate), gate.stride(0)) if gate is not None else (None, 0)
+        d.epi_res, d.epi_rows_per_batch = N.ptr(res), rows_per_batch
+        return d, out, 2.0 * M * Nn * K
+
+    @staticmethod
+    def forward_q_pair(lin0, x0, lin1, x1, epilogue: int = N.EPI_NONE, gate0=None, res0=None, rpb0: int = 0, out0=None,
+                       gate1=None, res1=None, rpb1: int = 0, out1=None):
+        """Two independent linears (e.g. the image- and text-stream projection of a double block) in ONE launch
+        when both are fp8; otherwise two launches.  Returns (out0, out1)."""
+        if lin0.quant_type == FP8 and lin1.quant_type == FP8:
+            import ctypes
+            d0, o0, f0 = lin0._desc(x0, epilogue, gate0, res0, rpb0, out0)
+            d1, o1, f1 = lin1._desc(x1, epilogue, gate1, res1, rpb1, out1)
+            with span("gemm_w8a8_fp8", f0 + f1):
+                N.check(N.lib().fdm_gemm_w8a8_fp8_x2(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "fp8 linear pair")
+            return o0, o1
+        return (lin0.forward_q(x0, epilogue, gate0, res0, rpb0, out0), lin1.forward_q(x1, epilogue, gate1, res1, rpb1, out1))
+
     def forward(self, input_tensor: torch.Tensor) -> torch.Tensor:
         """fastdm/layer/qlinear.py:56-81: quantise per token, scaled GEMM (+bias), restore the leading dims."""
         ori_shape = input_tensor.shape

@@ -35,6 +35,16 @@ class FeedForward:
         hq = self.ff_out_proj.quantize_input(h) if self.ff_out_proj.quant_type is not None else h
         return self.ff_out_proj.forward_q(hq, epilogue=N.EPI_GATE_RESIDUAL, gate=gate, res=res, rows_per_batch=rows_per_batch, out=res)
 
+    @staticmethod
+    def forward_fused_pair(ff0, xq0, gate0, res0, rpb0, ff1, xq1, gate1, res1, rpb1):
+        """The image- and text-stream FFNs of a double block side by side: each GEMM pair is one launch."""
+        from fastdm_amd.layer.qlinear import QLinear as QL
+        h0, h1 = QL.forward_q_pair(ff0.act_fn.proj, xq0, ff1.act_fn.proj, xq1, epilogue=ff0.epilogue)
+        q0 = ff0.ff_out_proj.quantize_input(h0) if ff0.ff_out_proj.quant_type is not None else h0
+        q1 = ff1.ff_out_proj.quantize_input(h1) if ff1.ff_out_proj.quant_type is not None else h1
+        return QL.forward_q_pair(ff0.ff_out_proj, q0, ff1.ff_out_proj, q1, epilogue=N.EPI_GATE_RESIDUAL, gate0=gate0, res0=res0,
+                                 rpb0=rpb0, out0=res0, gate1=gate1, res1=res1, rpb1=rpb1, out1=res1)
+
     def forward(self, hidden_states: torch.Tensor, *args, **kwargs) -> torch.Tensor:
         shp = hidden_states.shape
         x = hidden_states.reshape(-1, shp[-1])
@@ -84,10 +94,12 @@ class Attention:
         q = torch.empty((batch * s_tot, self.inner_dim), device=dev, dtype=BF16)
         k = torch.empty_like(q)
         v = torch.empty_like(q)
-        qkv = self.qkv.forward_q(xq)
+        if enc_q is not None:
+            qkv, eqkv = QLinear.forward_q_pair(self.qkv, xq, self.add_qkv_proj, enc_q)
+        else:
+            qkv = self.qkv.forward_q(xq)
         fused.qk_norm_rope(qkv, self.norm_q_weight, self.norm_k_weight, rope, q, k, v, s_img, s_tot, s_txt, self.heads, self.head_dim, self.eps)
         if enc_q is not None:
-            eqkv = self.add_qkv_proj.forward_q(enc_q)
             fused.qk_norm_rope(eqkv, self.norm_added_q_weight, self.norm_added_k_weight, rope, q, k, v, s_txt, s_tot, 0, self.heads,
                                self.head_dim, self.eps)
         return fused.attention(q, k, v, batch, self.heads, self.head_dim, self.scale)

@@ -88,19 +88,20 @@ class FluxTransformerBlock:
         ein = pick(fused.ln_modulate(e, c_scale_msa, c_shift_msa, s_txt, quant=quant))
         o = self.attn.attend(xin, B, s_img, image_rotary_emb, ein, s_txt).view(B, s_txt + s_img, D)
 
-        def stream(res, attn_rows, s, to_out, gate_a, scale_m, shift_m, gate_m, ff):
-            # attention rows of this stream are a strided slice of the joint output: quantise per batch element
-            new = torch.empty_like(res)
-            for b in range(B):
-                rows = attn_rows[b]
-                aq = to_out.quantize_input(rows) if to_out.quant_type is not None else rows
-                to_out.forward_q(aq, epilogue=N.EPI_GATE_RESIDUAL, gate=gate_a[b:b + 1], res=res[b * s:(b + 1) * s], rows_per_batch=s,
-                                 out=new[b * s:(b + 1) * s])
-            fin = pick(fused.ln_modulate(new, scale_m, shift_m, s, quant=quant))
-            return ff.forward_fused(fin, gate_m, new, s)
-
-        x = stream(x, o[:, s_txt:], s_img, self.attn.to_out, gate_msa, scale_mlp, shift_mlp, gate_mlp, self.ff)
-        e = stream(e, o[:, :s_txt], s_txt, self.attn.to_add_out, c_gate_msa, c_scale_mlp, c_shift_mlp, c_gate_mlp, self.ff_context)
+        # attention rows of a stream are a strided slice of the joint output: quantise / project per batch element;
+        # the image and text projections of one batch element share a launch
+        x_new, e_new = torch.empty_like(x), torch.empty_like(e)
+        to_o, to_ao = self.attn.to_out, self.attn.to_add_out
+        for b in range(B):
+            ai, at = o[b, s_txt:], o[b, :s_txt]
+            aqi = to_o.quantize_input(ai) if to_o.quant_type is not None else ai
+            aqt = to_ao.quantize_input(at) if to_ao.quant_type is not None else at
+            QLinear.forward_q_pair(to_o, aqi, to_ao, aqt, epilogue=N.EPI_GATE_RESIDUAL,
+                                   gate0=gate_msa[b:b + 1], res0=x[b * s_img:(b + 1) * s_img], rpb0=s_img, out0=x_new[b * s_img:(b + 1) * s_img],
+                                   gate1=c_gate_msa[b:b + 1], res1=e[b * s_txt:(b + 1) * s_txt], rpb1=s_txt, out1=e_new[b * s_txt:(b + 1) * s_txt])
+        fin_x = pick(fused.ln_modulate(x_new, scale_mlp, shift_mlp, s_img, quant=quant))
+        fin_e = pick(fused.ln_modulate(e_new, c_scale_mlp, c_shift_mlp, s_txt, quant=quant))
+        x, e = FeedForward.forward_fused_pair(self.ff, fin_x, gate_mlp, x_new, s_img, self.ff_context, fin_e, c_gate_mlp, e_new, s_txt)
         return e.view(B, s_txt, D), x.view(B, s_img, D)
 
 

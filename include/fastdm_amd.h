@@ -80,6 +80,25 @@ int fdm_gemm_w8a8_fp8(void* out, const void* a, const void* b, const float* scal
                       int epilogue, const void* epi_gate, int64_t epi_gate_stride,
                       const void* epi_res, int64_t epi_rows_per_batch, fdm_stream_t stream);
 
+/* Two independent fp8 GEMMs in ONE persistent launch (e.g. the image- and text-stream projections of a
+ * double block: same op, different weights).  The small problem's tiles fill the last partial round of the
+ * large one instead of running at < 10 % occupancy on their own.  Fields as in fdm_gemm_w8a8_fp8.        */
+typedef struct fdm_gemm_fp8_desc {
+  void* out;
+  const void* a;
+  const void* b;
+  const float* scale_a;
+  const float* scale_b;
+  const void* bias;
+  int64_t M, N, K, lda, ldb, ldc;
+  int64_t epilogue;
+  const void* epi_gate;
+  int64_t epi_gate_stride;
+  const void* epi_res;
+  int64_t epi_rows_per_batch;
+} fdm_gemm_fp8_desc;
+int fdm_gemm_w8a8_fp8_x2(const fdm_gemm_fp8_desc* d0, const fdm_gemm_fp8_desc* d1, fdm_stream_t stream);
+
 /* ---- replaces cuda_ops.int8_scaled_mm_ (torch_bindings.cpp:86-158; hopper_w8a8_int8.cu;
  *      epilogue include/cutlass_extensions/epilogue/scaled_mm_epilogues_c3x.hpp:130-197) ---------
  * out = bf16( bf16( f32(acc_i32 - azp[M]*azp_adj[N]) * (sa[M]*sb[N]) ) + bias[N] )
