@@ -16,6 +16,7 @@
 //             K/V (4.4 MB per head at S = 8704) is fetched from HBM once and re-read from that L2.
 //   mask      optional int8 block mask [B, H, ceil(Sq/bq), ceil(Sk/bk)] (1 = compute): tiles masked
 //             for both 128-row halves of the Q block are skipped entirely (no loads, no barrier).
+#include <type_traits>
 #include "common.h"
 
 namespace fdm {
@@ -158,8 +159,102 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
     for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
   float m_run = -1.0e30f, l_run = 0.f;
 
-  // tr-read lane geometry (see header): 16-lane group gi, lane-in-group li = 4*tq + tp
+  // ---- LDS read bases (byte offsets into smem; the buffer bit is toggled with one XOR per tile, every other
+  //      term of an address is a compile-time immediate).  tr-read geometry: 16-lane group gi, lane li = 4*tq + tp.
+  constexpr uint32_t ROWB = D * 2;
   const int gi = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  // K: chunk (2ks + h) ^ Y = (h ^ Y) ^ 2ks, so one base and a compile-time XOR per k-step
+  uint32_t kld0 = lq * ROWB + (uint32_t)Swz<D>::k(lq, h) * 16;
+  uint32_t vld[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+    vld[d] = TILE_BYTES + (4 * h + tq) * ROWB + (uint32_t)Swz<D>::v(4 * h + tq, d * 4 + 2 * (gi & 1) + (tp >> 1)) * 16 + 8 * (tp & 1);
+  constexpr float RESCALE_THR = 8.0f;  // lazy rescale: P <= 2^8 between rescales (exp2 domain)
+
+  // One KV tile for this wave.  TAIL: keys >= sk are masked (only the last tile of a sequence can need it).
+  auto process_tile = [&](auto tail_c, int t) {
+    constexpr bool TAIL = decltype(tail_c)::value;
+    // ---- S^T = K . Q^T  (two 32-key tiles)
+    f32x16 sacc[2];
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[kt2][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const i32x4 qfr = qf[ks];
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2) {
+        const i32x4 kf = *reinterpret_cast<const i32x4*>(smem + (kld0 ^ (uint32_t)(ks << 5)) + kt2 * 32 * ROWB);
+        sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qfr),
+                                                            sacc[kt2], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (TAIL) {
+      const int rem = (int)(p.sk - (int64_t)t * KT) - 4 * h;  // keys of this tile that exist, shifted by the lane-half offset
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (kt2 * 32 + (e & 3) + 8 * (e >> 2) >= rem) sacc[kt2][e] = -INFINITY;
+    }
+    // ---- online softmax in the exp2 domain with lazy rescale: the running max only moves (and O, l are only
+    //      rescaled) when some row's tile max exceeds it by more than RESCALE_THR; the decision is taken before
+    //      this tile is exponentiated and after the previous tile's P.V has been issued (textbook order).
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(sacc[0][e], sacc[1][e]));
+    {
+      const int mi = __builtin_bit_cast(int, mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mi, mi, false, false);  // both halves of the query row
+      mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    }
+    const float mt = mx * p.scale_log2e;
+    if (__any(mt > m_run + RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+    }
+    float psum = 0.f;
+    i32x4 pf[2][2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt2][e], p.scale_log2e, -m_run));
+        sacc[kt2][e] = pv;
+        psum += pv;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) pf[kt2][s][w2] = (int)pack2bf(sacc[kt2][8 * s + 2 * w2], sacc[kt2][8 * s + 2 * w2 + 1]);
+    }
+    l_run += psum;
+    // ---- O^T += V^T . P^T
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const uint8_t* a0 = smem + vld[d] + (kt2 * 32 + 16 * s) * ROWB;  // keys 4h+tq .. (+8 for the second group)
+          const i32x4 vf = tr_pair(a0, a0 + 8 * ROWB);
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[kt2][s]),
+                                                            oacc[d], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the V-fragment prefetch depth at one (kt2, s) group: VGPR budget
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
 
   int t = next_active(0);
   int cur = 0;
@@ -169,92 +264,28 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
   }
   __syncthreads();
 
-  while (t < ntiles) {
+  // Full tiles run the TAIL=false body in the loop; a partial last tile (sk % 64 != 0) is handled once, after
+  // the loop, by the masked body (keeping both bodies inside the loop costs > 90 VGPRs on this compiler).
+  const int n_main = (p.sk % KT == 0) ? ntiles : ntiles - 1;
+  while (t < n_main) {
     const int tn = next_active(t + 1);
     if (tn < ntiles) issue_loads(tn);
 
     bool active = true;
     if (p.mask != nullptr) active = mrow_w[(t * KT) / p.mask_bk] != 0;
-    if (active) {
-      const uint8_t* sk_ = smem + cur * 2 * TILE_BYTES;
-      const uint8_t* sv_ = sk_ + TILE_BYTES;
-      // ---- S^T = K . Q^T  (two 32-key tiles)
-      f32x16 sacc[2];
-#pragma unroll
-      for (int kt2 = 0; kt2 < 2; ++kt2) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sacc[kt2][e] = 0.f;
-        const int row = kt2 * 32 + lq;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          i32x4 kf = *reinterpret_cast<const i32x4*>(sk_ + row * (D * 2) + Swz<D>::k(row, 2 * ks + h) * 16);
-          sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]),
-                                                              sacc[kt2], 0, 0, 0);
-        }
-      }
-      // ---- mask the key tail (keys >= sk)
-      const int64_t key0 = (int64_t)t * KT;
-      if (key0 + KT > p.sk) {
-#pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int64_t key = key0 + kt2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (key >= p.sk) sacc[kt2][e] = -INFINITY;
-          }
-      }
-      // ---- online softmax (exp2 domain)
-      float mx = sacc[0][0];
-#pragma unroll
-      for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt2][e]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx * p.scale_log2e);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      float psum = 0.f;
-      i32x4 pf[2][2];
-#pragma unroll
-      for (int kt2 = 0; kt2 < 2; ++kt2) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt2][e], p.scale_log2e, -m_new));
-          sacc[kt2][e] = pv;
-          psum += pv;
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int w2 = 0; w2 < 4; ++w2)
-            pf[kt2][s][w2] = (int)pack2bf(sacc[kt2][8 * s + 2 * w2], sacc[kt2][8 * s + 2 * w2 + 1]);
-      }
-      l_run = l_run * alpha + psum;
-#pragma unroll
-      for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
-      // ---- O^T += V^T . P^T
-#pragma unroll
-      for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int krow = kt2 * 32 + 16 * s + 4 * h + tq;  // first of the two 4-key groups (second = +8)
-#pragma unroll
-          for (int d = 0; d < DT; ++d) {
-            const int ch = d * 4 + 2 * (gi & 1) + (tp >> 1);
-            const uint8_t* a0 = sv_ + krow * (D * 2) + Swz<D>::v(krow, ch) * 16 + 8 * (tp & 1);
-            const uint8_t* a1 = a0 + 8 * (D * 2);  // key + 8: same (key & 3) and ((key>>1)&1)
-            i32x4 vf = tr_pair(a0, a1);
-            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[kt2][s]),
-                                                              oacc[d], 0, 0, 0);
-          }
-        }
-    }
+    if (active) process_tile(std::false_type{}, t);
     if (tn < ntiles) write_lds(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+    kld0 ^= 2 * TILE_BYTES;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) vld[d] ^= 2 * TILE_BYTES;
     t = tn;
+  }
+  if (t < ntiles) {  // the partial tile is resident in buffer `cur`
+    bool active = true;
+    if (p.mask != nullptr) active = mrow_w[(t * KT) / p.mask_bk] != 0;
+    if (active) process_tile(std::true_type{}, t);
   }
 
   // ---- finalize: l = own half + other half; O = O^T / l

@@ -26,8 +26,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16
 // round an fp32 value to bf16 precision and keep it as fp32 (one "torch bf16 op" rounding)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
+// two floats -> packed bf16x2 with ONE v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // 8 bf16 (16 bytes) <-> 8 floats
