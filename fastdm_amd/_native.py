@@ -28,7 +28,8 @@ SIGNATURES = {
     "fdm_gemm_w8a8_fp8_x2": (I32, [P, P, P]),
     "fdm_gemm_w8a8_int8": (I32, [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_gemm_bf16": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
-    "fdm_attn_fwd": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I32, I32, P]),
+    "fdm_attn_fwd": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I32, I32, P, I64, P]),
+    "fdm_attn_fwd_workspace_bytes": (I64, [I32]),
     "fdm_ln_modulate": (I32, [P, P, P, P, I32, P, P, P, I64, P, P, P, I64, I32, I64, F32, P]),
     "fdm_gate_residual": (I32, [P, P, P, P, I64, I64, I32, I64, P]),
     "fdm_gelu": (I32, [P, P, I64, I32, P]),
@@ -108,3 +109,18 @@ def ptr(t):
 def stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+_attn_ws = {}
+
+
+def attn_workspace(device, head_dim):
+    """Per-device scratch for fdm_attn_fwd's split-KV tail balancing (allocated once, ~34 MB at D=128)."""
+    import torch
+    key = (device.index if device.index is not None else torch.cuda.current_device(), head_dim)
+    ws = _attn_ws.get(key)
+    if ws is None:
+        nbytes = int(lib().fdm_attn_fwd_workspace_bytes(head_dim))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _attn_ws[key] = ws
+    return ws

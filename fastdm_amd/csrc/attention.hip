@@ -40,6 +40,10 @@ struct AttnParams {
   int n_qblocks;
   int mask_bq, mask_bk, mask_nq, mask_nk;
   float scale_log2e;
+  // split-KV tail balancing: block ids >= n_full are parts of tail q-blocks (S parts each, consecutive KV ranges)
+  int n_full, split;
+  float* ws_o;   // [tail part][256 rows][D] unnormalised fp32 O
+  float* ws_ml;  // [tail part][256 rows][2] running max (exp2 domain), row sum
 };
 
 template <int D>
@@ -81,7 +85,13 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
 
   // ---- block id -> (batch*head, q block), heads pinned to XCDs
   const int BH = p.batch * p.heads;
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  int item = blockIdx.x, part = 0;
+  const bool is_part = item >= p.n_full;
+  if (is_part) {
+    part = (item - p.n_full) % p.split;
+    item = p.n_full + (item - p.n_full) / p.split;
+  }
+  const int xcd = item & 7, j = item >> 3;
   const int bh = xcd + 8 * (j / p.n_qblocks);
   if (bh >= BH) return;
   const int qb = j % p.n_qblocks;
@@ -256,9 +266,12 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
     __builtin_amdgcn_s_setprio(0);
   };
 
-  int t = next_active(0);
+  // KV range of this work item: everything, or the part-th of `split` consecutive ranges
+  const int t_begin = is_part ? (int)((int64_t)part * ntiles / p.split) : 0;
+  const int t_end = is_part ? (int)((int64_t)(part + 1) * ntiles / p.split) : ntiles;
+  int t = next_active(t_begin);
   int cur = 0;
-  if (t < ntiles) {
+  if (t < t_end) {
     issue_loads(t);
     write_lds(0);
   }
@@ -266,15 +279,15 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
 
   // Full tiles run the TAIL=false body in the loop; a partial last tile (sk % 64 != 0) is handled once, after
   // the loop, by the masked body (keeping both bodies inside the loop costs > 90 VGPRs on this compiler).
-  const int n_main = (p.sk % KT == 0) ? ntiles : ntiles - 1;
+  const int n_main = (p.sk % KT == 0 || t_end < ntiles) ? t_end : ntiles - 1;
   while (t < n_main) {
     const int tn = next_active(t + 1);
-    if (tn < ntiles) issue_loads(tn);
+    if (tn < t_end) issue_loads(tn);
 
     bool active = true;
     if (p.mask != nullptr) active = mrow_w[(t * KT) / p.mask_bk] != 0;
     if (active) process_tile(std::false_type{}, t);
-    if (tn < ntiles) write_lds(cur ^ 1);
+    if (tn < t_end) write_lds(cur ^ 1);
     __syncthreads();
     cur ^= 1;
     kld0 ^= 2 * TILE_BYTES;
@@ -282,7 +295,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
     for (int d = 0; d < DT; ++d) vld[d] ^= 2 * TILE_BYTES;
     t = tn;
   }
-  if (t < ntiles) {  // the partial tile is resident in buffer `cur`
+  if (t < t_end) {  // the partial tile is resident in buffer `cur`
     bool active = true;
     if (p.mask != nullptr) active = mrow_w[(t * KT) / p.mask_bk] != 0;
     if (active) process_tile(std::true_type{}, t);
@@ -290,6 +303,24 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
 
   // ---- finalize: l = own half + other half; O = O^T / l
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (is_part) {  // unnormalised partial: O (fp32), m, l -> workspace; attn_combine_kernel merges the parts
+    const int64_t slot = (int64_t)(blockIdx.x - p.n_full);
+    const int row = wave * 32 + lq;
+    float* wo = p.ws_o + (slot * QB + row) * D;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 w;
+        w[0] = oacc[d][4 * g4]; w[1] = oacc[d][4 * g4 + 1]; w[2] = oacc[d][4 * g4 + 2]; w[3] = oacc[d][4 * g4 + 3];
+        *reinterpret_cast<f32x4*>(wo + 32 * d + 8 * g4 + 4 * h) = w;
+      }
+    if (h == 0) {
+      p.ws_ml[(slot * QB + row) * 2] = m_run;
+      p.ws_ml[(slot * QB + row) * 2 + 1] = l_tot;
+    }
+    return;
+  }
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   const int64_t qrow = q0 + wave * 32 + lq;
   if (qrow < p.sq) {
@@ -307,20 +338,65 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
   }
 }
 
+// Merge the split-KV parts of the tail q-blocks: O = sum_p 2^(m_p - M) O_p / sum_p 2^(m_p - M) l_p, M = max_p m_p.
+// One thread per (row, 8 consecutive d).
+template <int D>
+__global__ void __launch_bounds__(256) attn_combine_kernel(const AttnParams p, int n_tail) {
+  constexpr int CPR = D / 8;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)n_tail * QB * CPR) return;
+  const int ch = (int)(gid % CPR);
+  const int row = (int)((gid / CPR) % QB);
+  const int tail = (int)(gid / ((int64_t)CPR * QB));
+  const int item = p.n_full + tail;
+  const int xcd = item & 7, j = item >> 3;
+  const int bh = xcd + 8 * (j / p.n_qblocks);
+  const int qb = j % p.n_qblocks;
+  const int b = bh / p.heads, head = bh % p.heads;
+  const int64_t qrow = (int64_t)qb * QB + row;
+  if (bh >= p.batch * p.heads || qrow >= p.sq) return;
+  float M = -3.0e38f;
+  for (int s = 0; s < p.split; ++s) M = fmaxf(M, p.ws_ml[(((int64_t)tail * p.split + s) * QB + row) * 2]);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float L = 0.f;
+  for (int s = 0; s < p.split; ++s) {
+    const int64_t slot = (int64_t)tail * p.split + s;
+    const float w = __builtin_amdgcn_exp2f(p.ws_ml[(slot * QB + row) * 2] - M);
+    L += w * p.ws_ml[(slot * QB + row) * 2 + 1];
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p.ws_o + (slot * QB + row) * D + ch * 8);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(p.ws_o + (slot * QB + row) * D + ch * 8 + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[i] += w * a[i];
+      acc[4 + i] += w * c[i];
+    }
+  }
+  const float inv = L > 0.f ? 1.0f / L : 0.f;
+  i32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (int)pack2bf(acc[2 * i] * inv, acc[2 * i + 1] * inv);
+  *reinterpret_cast<i32x4*>(p.o + ((int64_t)b * p.sq + qrow) * p.o_ts + (int64_t)head * D + ch * 8) = o;
+}
+
 }  // namespace fdm
 
 using namespace fdm;
 
+extern "C" int64_t fdm_attn_fwd_workspace_bytes(int head_dim) {
+  // 1024 part slots x 256 rows x (D + 2) floats (136 MB at D = 128); fdm_attn_fwd only picks splits that fit
+  return (int64_t)1024 * QB * (head_dim + 2) * 4;
+}
+
 extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v, int64_t batch, int64_t sq, int64_t sk,
                             int q_heads, int kv_heads, int head_dim, int64_t q_tok_stride, int64_t k_tok_stride,
                             int64_t v_tok_stride, int64_t o_tok_stride, float scale, const int8_t* block_mask, int block_q,
-                            int block_k, fdm_stream_t stream) {
+                            int block_k, void* workspace, int64_t workspace_bytes, fdm_stream_t stream) {
   if (!o || !q || !k || !v || batch <= 0 || sq <= 0 || sk <= 0 || q_heads <= 0 || kv_heads <= 0 || q_heads % kv_heads)
     return FDM_ERR_INVALID;
   if (head_dim != 64 && head_dim != 128) return FDM_ERR_UNSUPPORTED;
-  if ((q_tok_stride & 7) || (k_tok_stride & 7) || (v_tok_stride & 7) || (o_tok_stride & 3)) return FDM_ERR_INVALID;
+  if ((q_tok_stride & 7) || (k_tok_stride & 7) || (v_tok_stride & 7) || (o_tok_stride & 7)) return FDM_ERR_INVALID;
   if ((reinterpret_cast<uintptr_t>(q) & 15) || (reinterpret_cast<uintptr_t>(k) & 15) || (reinterpret_cast<uintptr_t>(v) & 15) ||
-      (reinterpret_cast<uintptr_t>(o) & 7))
+      (reinterpret_cast<uintptr_t>(o) & 15))
     return FDM_ERR_INVALID;
   AttnParams p;
   p.o = (bf16_t*)o;
@@ -349,10 +425,60 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
   }
   p.scale_log2e = scale * 1.4426950408889634f;
   const int64_t bh = batch * q_heads;
-  const int64_t grid = 8 * ((bh + 7) / 8) * p.n_qblocks;
+  int64_t grid = 8 * ((bh + 7) / 8) * p.n_qblocks;
   hipStream_t s = to_stream(stream);
+  // Split-KV tail balancing: q-blocks are equal-sized work items, one per CU at a time; when the last round would
+  // fill less than half of the chip (FLUX 1024x2048: 816 items on 256 CUs = 3.19 rounds), the items of that round
+  // are split along KV into S parts that run side by side and are merged by a small combine kernel.
+  p.n_full = (int)grid;
+  p.split = 1;
+  p.ws_o = nullptr;
+  p.ws_ml = nullptr;
+  int n_tail = 0;
+  if (block_mask == nullptr && workspace != nullptr && (bh % 8) == 0) {
+    static int num_cu = 0;
+    if (num_cu == 0) {
+      int dev = 0, cu = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+      num_cu = cu;
+    }
+    const int rem = (int)(grid % num_cu);
+    const int ntiles = (int)((sk + KT - 1) / KT);
+    if (rem > 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+      // time of the last round in units of one whole item: ceil(rem*S / CUs) rounds of 1/S-sized parts, plus a
+      // per-part overhead (Q load, prologue, fp32 partial write + merge) priced at 2% of an item
+      // (a split must save >= 0.3 item-times: measured at 432 items, a predicted 0.17 saving was a 5% loss -- a
+      // partly filled last round runs faster per item than the model assumes)
+      int best = 1;
+      float best_cost = 0.75f;
+      for (int S = 2; S <= 8 && S * 8 <= ntiles; ++S) {
+        const int64_t need = (int64_t)rem * S * QB * (head_dim + 2) * 4;
+        if (need > workspace_bytes) break;
+        const float cost = (float)(((int64_t)rem * S + num_cu - 1) / num_cu) / (float)S + 0.02f * (float)S;
+        if (cost < best_cost - 0.05f) {
+          best = S;
+          best_cost = cost;
+        }
+      }
+      if (best > 1) {
+        n_tail = rem;
+        p.split = best;
+        p.n_full = (int)(grid - rem);
+        p.ws_o = reinterpret_cast<float*>(workspace);
+        p.ws_ml = p.ws_o + (int64_t)rem * best * QB * head_dim;
+        grid = p.n_full + (int64_t)rem * best;
+      }
+    }
+  }
   if (head_dim == 128) attn_fwd_kernel<128><<<(unsigned)grid, ATT_THREADS, 0, s>>>(p);
   else attn_fwd_kernel<64><<<(unsigned)grid, ATT_THREADS, 0, s>>>(p);
   FDM_CHECK_LAUNCH();
+  if (n_tail > 0) {
+    const int64_t threads = (int64_t)n_tail * QB * (head_dim / 8);
+    const unsigned cgrid = (unsigned)((threads + 255) / 256);
+    if (head_dim == 128) attn_combine_kernel<128><<<cgrid, 256, 0, s>>>(p, n_tail);
+    else attn_combine_kernel<64><<<cgrid, 256, 0, s>>>(p, n_tail);
+    FDM_CHECK_LAUNCH();
+  }
   return FDM_OK;
 }

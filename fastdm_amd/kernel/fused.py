@@ -95,9 +95,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     S = q.shape[0] // batch
     Sk = k.shape[0] // batch
     out = torch.empty_like(q)
+    ws = N.attn_workspace(q.device, head_dim)
     with span("attn_fwd_bf16", 4.0 * batch * S * Sk * heads * head_dim):
         N.check(N.lib().fdm_attn_fwd(N.ptr(out), N.ptr(q), N.ptr(k), N.ptr(v), batch, S, Sk, heads, heads, head_dim,
-                                     q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), None, 0, 0, N.stream()),
+                                     q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), None, 0, 0, N.ptr(ws), ws.numel(),
+                                     N.stream()),
                 "attention")
     return out
 

@@ -151,9 +151,10 @@ def _attn(query, key, value, num_q_heads, num_kv_heads, head_dim, is_causal, sca
     if scale is None:
         scale = head_dim ** -0.5
     out = torch.empty((B, Sq, num_q_heads * head_dim), device=query.device, dtype=query.dtype)
+    ws = N.attn_workspace(query.device, head_dim)
     N.check(N.lib().fdm_attn_fwd(N.ptr(out), N.ptr(query), N.ptr(key), N.ptr(value), B, Sq, Sk, num_q_heads, num_kv_heads,
                                  head_dim, query.stride(1), key.stride(1), value.stride(1), out.stride(1), float(scale),
-                                 N.ptr(mask), bq, bk, N.stream()), "scaled_dot_product_attention")
+                                 N.ptr(mask), bq, bk, N.ptr(ws), ws.numel(), N.stream()), "scaled_dot_product_attention")
     return out
 
 

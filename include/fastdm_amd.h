@@ -122,12 +122,18 @@ int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias,
  * q [B,Sq,Hq*D], k/v [B,Sk,Hkv*D], o [B,Sq,Hq*D] bf16, token strides in elements (batch stride =
  * S * token stride).  Non-causal softmax(q k^T * scale) v with fp32 softmax state.  D in {64,128}.
  * block_mask (may be NULL): int8 [B,Hq,ceil(Sq/block_q),ceil(Sk/block_k)], 1 = compute
- * (kernel/cuda/attention.py:77-147); requires block_q % 128 == 0 and block_k % 64 == 0.          */
+ * (kernel/cuda/attention.py:77-147); requires block_q % 128 == 0 and block_k % 64 == 0.
+ * o must be 16-byte aligned with o_tok_stride % 8 == 0.                                            */
 int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v,
                  int64_t batch, int64_t sq, int64_t sk, int q_heads, int kv_heads, int head_dim,
                  int64_t q_tok_stride, int64_t k_tok_stride, int64_t v_tok_stride,
                  int64_t o_tok_stride, float scale,
-                 const int8_t* block_mask, int block_q, int block_k, fdm_stream_t stream);
+                 const int8_t* block_mask, int block_q, int block_k,
+                 void* workspace, int64_t workspace_bytes, fdm_stream_t stream);
+/* Optional scratch for fdm_attn_fwd (NULL / 0 = never split): when the last round of equal-sized q-block work
+ * items would fill less than half the chip, those items are split along KV and merged (split-KV tail
+ * balancing).  Returns the number of bytes that is always sufficient for the given head_dim.                 */
+int64_t fdm_attn_fwd_workspace_bytes(int head_dim);
 
 /* ================= fused kernels used by the FLUX block wiring (no reference export) ========== */
 

@@ -12,7 +12,7 @@ def header_prototypes():
     src = open(os.path.join(ROOT, "include", "fastdm_amd.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(fdm_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int|int64_t|const char\*)\s+(fdm_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = [a.strip() for a in m.group(3).split(",") if a.strip() and a.strip() != "void"]
         protos[m.group(2)] = args
     return protos

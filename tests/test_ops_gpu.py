@@ -263,6 +263,32 @@ def test_attention_reference_shapes(K, B, Sq, Sk, H, hd):
     assert (sub.float() - ref.float()).abs().mean() < 1.5e-3
 
 
+@pytest.mark.parametrize("S", [8704, 8650])
+def test_attention_split_kv_tail(K, S):
+    """FLUX 1024x2048 geometry: 816 q-block items on 256 CUs -> the last 48 items are split along KV into parts and
+    merged by the combine kernel.  The split result must agree with the unsplit kernel (workspace = NULL) to bf16
+    rounding everywhere, and with the oracle on rows of the tail items (heads 16..23, q rows >= 7168)."""
+    from fastdm_amd import _native as N
+    g = gen(S)
+    B, H, hd = 1, 24, 128
+    q, k, v = (rbf(g, B, S, H * hd).cuda() for _ in range(3))
+    split = K.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5)
+    plain = torch.empty_like(split)
+    N.check(N.lib().fdm_attn_fwd(N.ptr(plain), N.ptr(q), N.ptr(k), N.ptr(v), B, S, S, H, H, hd, q.stride(1), k.stride(1), v.stride(1),
+                                 plain.stride(1), hd ** -0.5, None, 0, 0, None, 0, N.stream()), "attn")
+    d = (split.float() - plain.float()).abs()
+    assert d.max().item() <= 2.0 ** -8 and d.mean().item() < 2e-5, (d.max().item(), d.mean().item())
+    assert not torch.equal(split[:, 7168:, 16 * hd:], plain[:, 7168:, 16 * hd:]), "split path did not run"
+    assert torch.equal(split[:, :7168], plain[:, :7168])
+    rows = torch.tensor([7168, 7300, 7423, 7424, 8000, S - 257, S - 256, S - 1])
+    heads = [16, 23]
+    hsel = torch.cat([torch.arange(h * hd, (h + 1) * hd) for h in heads])
+    qc, kc, vc = q.cpu(), k.cpu(), v.cpu()
+    ref = O.scaled_dot_product_attention(qc[:, rows][:, :, hsel].contiguous(), kc[:, :, hsel].contiguous(), vc[:, :, hsel].contiguous(),
+                                         len(heads), len(heads), hd, scale=hd ** -0.5)
+    torch.testing.assert_close(split.cpu()[:, rows][:, :, hsel], ref, rtol=0.0, atol=1.8e-2)
+
+
 def test_attention_rescale_branch_forced(K):
     """A late key that dominates one query row (online-softmax max jumps at a chosen tile)."""
     g = gen(9)
