@@ -26,6 +26,21 @@ import torch  # noqa: E402
 
 PEAK_TFLOPS = {"fp8": 5000.0, "bf16": 2500.0, "int8": 5000.0}   # dense MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 IMAGE_STEPS = 25
+# timing-span name -> HIP kernel it launches (the name rocprofv3 reports; profiles/*_summary.txt)
+HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd_kernel<128>", "gemm_w8a8_fp8": "fdm::gemm_kernel<0, false>", "gemm_w8a8_fp8_res": "fdm::gemm_kernel<0, true>",
+              "gemm_w8a8_int8": "fdm::gemm_kernel<1, false>", "gemm_w8a8_int8_res": "fdm::gemm_kernel<1, true>",
+              "gemm_bf16": "fdm::gemm_kernel<2, false>", "gemm_bf16_res": "fdm::gemm_kernel<2, true>"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, made by
+    tools/gpu_evidence.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950 guide
+    prescribes).  None when the file does not hold this kernel for this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def cpu_baseline_leg(height, width, n_txt, quant_tag):
@@ -175,8 +190,10 @@ def main():
             kernels[name] = {"launches_per_step": s["launches"] / args.steps, "avg_ms": s["avg_ms"], "ms_per_step": s["total_ms"] / args.steps,
                              "achieved_TFLOPs": tf, "peak_TFLOPs": PEAK_TFLOPS[dt], "frac": tf / PEAK_TFLOPS[dt]}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["achieved_TFLOPs"], "peak": kernels[dom]["peak_TFLOPs"],
-                           "unit": "TFLOP/s", "frac": kernels[dom]["frac"], "traffic": None,
+        default_workload = (args.height, args.width, args.max_seq_len, args.quant, args.cache_config) == (1024, 2048, 512, "fp8", None)
+        out["roofline"] = {"kernel": HIP_KERNEL.get(dom, dom), "span": dom, "bound": "mfma", "achieved": kernels[dom]["achieved_TFLOPs"],
+                           "peak": kernels[dom]["peak_TFLOPs"], "unit": "TFLOP/s", "frac": kernels[dom]["frac"],
+                           "traffic": pmc_traffic(HIP_KERNEL.get(dom, dom)) if default_workload else None,
                            "avg_launch_ms": kernels[dom]["avg_ms"]}
         out["kernels"] = kernels
         flops_step = sum(s["work"] for s in summ.values()) / args.steps
