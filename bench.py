@@ -158,6 +158,7 @@ def main():
     assert torch.isfinite(final.float()).all(), "non-finite latents"
 
     if rank != 0:
+        D.shutdown()
         return
     ms_per_step = elapsed / args.steps * 1e3
     skipped = 0
@@ -204,7 +205,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline_leg(args.height, args.width, args.max_seq_len, args.quant)
         except Exception as e:  # noqa: BLE001  -- the baseline leg must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e}"}
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    D.shutdown()
 
 
 if __name__ == "__main__":

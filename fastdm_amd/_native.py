@@ -19,6 +19,7 @@ P, I64, I32, U32, F32 = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_float
 SIGNATURES = {
     "fdm_version": (I32, []),
     "fdm_error_string": (C.c_char_p, [I32]),
+    "fdm_last_hip_error_string": (C.c_char_p, []),
     "fdm_rms_norm": (I32, [P, P, P, F32, I64, I32, P]),
     "fdm_rope_inplace": (I32, [P, P, P, I64, I64, I32, I32, I32, I32, I64, I64, I32, P]),
     "fdm_quant_fp8_rowwise": (I32, [P, P, P, I64, I32, I64, P]),
@@ -57,16 +58,31 @@ class NativeLibraryError(ImportError):
     pass
 
 
+def _source_digest(srcs) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(srcs):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False) -> str:
-    """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU).  The library is rebuilt only
+    when the sources' content digest changed (file times do not survive a copy to another machine)."""
     srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))
             if f.endswith((".hip", ".h", ".sh"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "fastdm_amd.h"))
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+    digest = _source_digest(srcs)
+    stamp = LIB_PATH + ".srcdigest"
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
         return LIB_PATH
     res = subprocess.run(["bash", BUILD_SCRIPT], capture_output=True, text=True)
     if res.returncode != 0 or not os.path.exists(LIB_PATH):
         raise NativeLibraryError(f"building libfastdm_amd.so failed:\n{res.stdout}\n{res.stderr}")
+    with open(stamp, "w") as f:
+        f.write(digest)
     return LIB_PATH
 
 
@@ -85,6 +101,10 @@ def lib():
                 raise NativeLibraryError(
                     f"fastdm_amd: HIP library {LIB_PATH} is missing and could not be built ({e}). "
                     "This package has no CPU / eager fallback.") from e
+        # torch bundles its own libamdhip64; it must be the HIP runtime of the process.  Loading our library first
+        # would pull in /opt/rocm's copy, and kernels launched through that second runtime fail with
+        # "no ROCm-capable device is detected" once torch has claimed the GPU.
+        import torch  # noqa: F401
         try:
             handle = C.CDLL(LIB_PATH)
         except OSError as e:
@@ -99,6 +119,8 @@ def lib():
 def check(rc: int, what: str):
     if rc != 0:
         msg = lib().fdm_error_string(rc).decode()
+        if rc == -3:
+            msg += ": " + lib().fdm_last_hip_error_string().decode()
         raise RuntimeError(f"{what} failed: {msg} (code {rc})")
 
 

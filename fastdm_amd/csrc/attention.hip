@@ -391,6 +391,7 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
                             int q_heads, int kv_heads, int head_dim, int64_t q_tok_stride, int64_t k_tok_stride,
                             int64_t v_tok_stride, int64_t o_tok_stride, float scale, const int8_t* block_mask, int block_q,
                             int block_k, void* workspace, int64_t workspace_bytes, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!o || !q || !k || !v || batch <= 0 || sq <= 0 || sk <= 0 || q_heads <= 0 || kv_heads <= 0 || q_heads % kv_heads)
     return FDM_ERR_INVALID;
   if (head_dim != 64 && head_dim != 128) return FDM_ERR_UNSUPPORTED;

@@ -3,6 +3,10 @@
 #include <cstring>
 #include "common.h"
 
+namespace fdm {
+int g_last_hip_error = 0;
+}
+
 namespace {
 struct Init {
   Init() {
@@ -25,5 +29,7 @@ const char* fdm_error_string(int code) {
     default: return "unknown error";
   }
 }
+
+const char* fdm_last_hip_error_string(void) { return hipGetErrorString((hipError_t)fdm::g_last_hip_error); }
 
 }  // extern "C"

@@ -7,10 +7,15 @@
 #define FDM_CHECK_LAUNCH()                                         \
   do {                                                             \
     hipError_t e_ = hipGetLastError();                             \
-    if (e_ != hipSuccess) return FDM_ERR_LAUNCH;                   \
+    if (e_ != hipSuccess) {                                        \
+      fdm::g_last_hip_error = (int)e_;                             \
+      return FDM_ERR_LAUNCH;                                       \
+    }                                                              \
   } while (0)
 
 namespace fdm {
+
+extern int g_last_hip_error;  // HIP error code behind the most recent FDM_ERR_LAUNCH (fdm_last_hip_error_string)
 
 typedef uint16_t bf16_t;  // raw bf16 bits
 typedef short s16x8 __attribute__((ext_vector_type(8)));

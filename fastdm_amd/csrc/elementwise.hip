@@ -555,6 +555,7 @@ static int launch_ln(void* out_bf16, void* out_q, float* out_scale, int32_t* out
 extern "C" {
 
 int fdm_rms_norm(void* out, const void* in, const void* weight, float eps, int64_t rows, int hidden, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (rows == 0 && hidden > 0 && !(hidden & 7)) return FDM_OK;
   if (!out || !in || !weight || rows < 0 || hidden <= 0 || (hidden & 7) || !aligned16(out) || !aligned16(in) || !aligned16(weight))
     return FDM_ERR_INVALID;
@@ -589,6 +590,7 @@ int fdm_rms_norm(void* out, const void* in, const void* weight, float eps, int64
 int fdm_rope_inplace(void* q, void* k, const void* cos_sin_cache, int64_t tokens, int64_t seq_len, int q_heads,
                      int k_heads, int head_size, int rot_dim, int64_t q_row_stride, int64_t k_row_stride, int is_neox,
                      fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!q || !k || !cos_sin_cache || tokens < 0 || seq_len <= 0 || q_heads < 0 || k_heads < 0 || rot_dim > head_size)
     return FDM_ERR_INVALID;
   if ((head_size & 7) || (q_row_stride & 7) || (k_row_stride & 7) || !aligned16(q) || !aligned16(k)) return FDM_ERR_INVALID;
@@ -610,6 +612,7 @@ int fdm_rope_inplace(void* q, void* k, const void* cos_sin_cache, int64_t tokens
 
 int fdm_quant_rowwise_cat2(void* q_out, float* scale_out, int32_t* azp_out, int quant_mode, const void* src0, int w0,
                            int64_t stride0, const void* src1, int w1, int64_t stride1, int64_t rows, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (rows == 0 && w0 > 0 && !(w0 & 7) && w1 >= 0 && !(w1 & 7)) return FDM_OK;
   if (!q_out || !scale_out || !src0 || w0 <= 0 || (w0 & 7) || (w1 & 7) || w1 < 0 || (stride0 & 7) || (stride1 & 7) || rows < 0)
     return FDM_ERR_INVALID;
@@ -630,16 +633,19 @@ int fdm_quant_rowwise_cat2(void* q_out, float* scale_out, int32_t* azp_out, int 
 
 int fdm_quant_fp8_rowwise(void* q_out, float* scale_out, const void* in, int64_t rows, int hidden, int64_t in_row_stride,
                           fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   return fdm_quant_rowwise_cat2(q_out, scale_out, nullptr, 1, in, hidden, in_row_stride, nullptr, 0, 0, rows, stream);
 }
 
 int fdm_quant_int8_rowwise(void* q_out, float* scale_out, int32_t* azp_out, const void* in, int64_t rows, int hidden,
                            int64_t in_row_stride, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   return fdm_quant_rowwise_cat2(q_out, scale_out, azp_out, azp_out ? 2 : 3, in, hidden, in_row_stride, nullptr, 0, 0, rows,
                                 stream);
 }
 
 int fdm_gelu_and_mul(void* out, const void* in, int64_t rows, int d, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!out || !in || rows < 0 || d <= 0 || (d & 7) || !aligned16(out) || !aligned16(in)) return FDM_ERR_INVALID;
   if (rows == 0) return FDM_OK;
   gelu_and_mul_kernel<<<grid_for(rows * (d / 8), 256), 256, 0, to_stream(stream)>>>((bf16_t*)out, (const bf16_t*)in, rows, d);
@@ -648,6 +654,7 @@ int fdm_gelu_and_mul(void* out, const void* in, int64_t rows, int d, fdm_stream_
 }
 
 int fdm_gelu(void* out, const void* in, int64_t n, int mode, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!out || !in || n < 0 || (n & 7) || !aligned16(out) || !aligned16(in)) return FDM_ERR_INVALID;
   if (mode != 1 && mode != 2) return FDM_ERR_UNSUPPORTED;
   if (n == 0) return FDM_OK;
@@ -659,6 +666,7 @@ int fdm_gelu(void* out, const void* in, int64_t n, int mode, fdm_stream_t stream
 
 int fdm_gate_residual(void* out, const void* res, const void* y, const void* gate, int64_t gate_batch_stride, int64_t rows,
                       int hidden, int64_t rows_per_batch, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!out || !res || !y || !gate || rows < 0 || hidden <= 0 || (hidden & 7) || rows_per_batch <= 0 || (gate_batch_stride & 7))
     return FDM_ERR_INVALID;
   if (!aligned16(out) || !aligned16(res) || !aligned16(y) || !aligned16(gate)) return FDM_ERR_INVALID;
@@ -674,6 +682,7 @@ int fdm_gate_residual(void* out, const void* res, const void* y, const void* gat
 int fdm_ln_modulate(void* out_bf16, void* out_q, float* out_scale, int32_t* out_azp, int quant_mode, const void* x,
                     const void* scale, const void* shift, int64_t mod_batch_stride, const void* res, const void* gate,
                     void* x_out, int64_t rows, int hidden, int64_t rows_per_batch, float eps, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!x || !scale || !shift || rows < 0 || hidden <= 0 || (hidden & 7) || rows_per_batch <= 0 || (mod_batch_stride & 7))
     return FDM_ERR_INVALID;
   if (quant_mode != 0 && (!out_q || !out_scale)) return FDM_ERR_INVALID;
@@ -695,6 +704,7 @@ int fdm_ln_modulate(void* out_bf16, void* out_q, float* out_scale, int32_t* out_
 int fdm_qk_norm_rope(void* q_out, void* k_out, void* v_out, const void* qkv, const void* wq, const void* wk,
                      const void* cos_sin_cache, int64_t rows, int64_t rows_per_batch, int64_t seq_total, int64_t seq_offset,
                      int heads, int head_dim, float eps, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!q_out || !k_out || !v_out || !qkv || !wq || !wk || rows < 0 || rows_per_batch <= 0 || heads <= 0) return FDM_ERR_INVALID;
   if (seq_offset < 0 || seq_offset + rows_per_batch > seq_total) return FDM_ERR_INVALID;
   if (!aligned16(q_out) || !aligned16(k_out) || !aligned16(v_out) || !aligned16(qkv) || !aligned16(wq) || !aligned16(wk))
@@ -718,6 +728,7 @@ int fdm_qk_norm_rope(void* q_out, void* k_out, void* v_out, const void* qkv, con
 }
 
 int fdm_absdiff_sums(float* out2, const void* a, const void* b, int64_t n, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!out2 || !a || !b || n < 0 || (n & 7) || !aligned16(a) || !aligned16(b)) return FDM_ERR_INVALID;
   if (n == 0) return FDM_OK;
   absdiff_sums_kernel<<<grid_for(n / 8, 256, 1024), 256, 0, to_stream(stream)>>>(out2, (const bf16_t*)a, (const bf16_t*)b, n / 8);
@@ -726,6 +737,7 @@ int fdm_absdiff_sums(float* out2, const void* a, const void* b, int64_t n, fdm_s
 }
 
 int fdm_synth_fill_bf16(void* out, int64_t n, uint32_t seed, int kind, float scale, float offset, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!out || n < 0 || (kind != 0 && kind != 1)) return FDM_ERR_INVALID;
   if (n == 0) return FDM_OK;
   synth_fill_kernel<<<grid_for(n, 256, 256 * 16), 256, 0, to_stream(stream)>>>((bf16_t*)out, n, seed, kind, scale, offset);
@@ -734,6 +746,7 @@ int fdm_synth_fill_bf16(void* out, int64_t n, uint32_t seed, int kind, float sca
 }
 
 int fdm_debug_cvt_fp8(void* out_u8, const float* in, int64_t n, int use_sw, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!out_u8 || !in || n < 0) return FDM_ERR_INVALID;
   if (n == 0) return FDM_OK;
   const unsigned grid = (unsigned)((n + 255) / 256);

@@ -71,7 +71,10 @@ struct GemmGroup {
   GemmProblem p[2];
   int n;            // 1 or 2 problems
   int total_tiles;
-  int debug;        // bring-up ablations (env FDM_GEMM_DEBUG): 1 = no steady-state DMA, 2 = no fragment reads, 4 = no stores
+  int debug;        // bring-up ablation (env FDM_GEMM_DEBUG): 4 = no stores
+#ifdef FDM_GEMM_STAMPS
+  unsigned long long* stamps;  // [block][4] shader-clock stamps: start / prologue landed / main loop done / epilogue done
+#endif
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -190,6 +193,10 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
     n0 = (rem / gsz) * BN;
   }
   const GemmProblem& p = grp.p[prob];
+#ifdef FDM_GEMM_STAMPS
+  unsigned long long* stamp = grp.stamps + (size_t)blockIdx.x * 4;
+  if (tid == 0) stamp[0] = __builtin_readcyclecounter();
+#endif
 
   // ---- staging: thread t, round i moves the 16-byte chunk that lands at (row = i*128 + t/4, slot = t%4)
   const int srow = tid >> 2;
@@ -273,6 +280,9 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
 #pragma unroll
   for (int i = 0; i < 4; ++i) read_a(0, i);
   read_b(fb0, 0);
+#ifdef FDM_GEMM_STAMPS
+  if (tid == 0) stamp[1] = __builtin_readcyclecounter();
+#endif
 
   // One step: wait for DMA(t+1) (leaving DMA(t+2) in flight), barrier, issue DMA(t+3), then MFMA(t) with the
   // fragments of step t+1 streaming in behind it.
@@ -298,6 +308,9 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // retire the padding DMAs and the dead fragment reads
   __builtin_amdgcn_s_barrier();                                  // every wave is done with the ring: reuse it below
 
+#ifdef FDM_GEMM_STAMPS
+  if (tid == 0) stamp[2] = __builtin_readcyclecounter();
+#endif
   // ---- epilogue
   // MFMA layout (swapped operands): lane holds row m = wm*128 + i*32 + (lane&31) and columns
   // n = wn*64 + j*32 + 8*q + 4*(lane>>5) + (0..3) for register quad q = e>>2, i.e. 8-byte pieces [m][chunk j*4+q][half g].
@@ -435,10 +448,21 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
     else if (p.epi == FDM_EPI_GELU_ERF) epilogue(std::integral_constant<int, FDM_EPI_GELU_ERF>{});
     else epilogue(std::integral_constant<int, FDM_EPI_NONE>{});
   }
+#ifdef FDM_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) stamp[3] = __builtin_readcyclecounter();
+#endif
 }
+
+#ifdef FDM_GEMM_STAMPS
+unsigned long long* g_gemm_stamps = nullptr;  // >= 4 * grid words, set by the micro-benchmark
+#endif
 
 template <int DT>
 static int launch_gemm(const GemmGroup& grp, hipStream_t s) {
+#ifdef FDM_GEMM_STAMPS
+  const_cast<GemmGroup&>(grp).stamps = g_gemm_stamps;
+#endif
   const int grid = grp.total_tiles;
   static int debug = -1;
   if (debug < 0) {
@@ -508,6 +532,7 @@ int fdm_gemm_w8a8_fp8(void* out, const void* a, const void* b, const float* scal
                       int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int epilogue,
                       const void* epi_gate, int64_t epi_gate_stride, const void* epi_res, int64_t epi_rows_per_batch,
                       fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (M == 0 && N > 0 && K > 0) return FDM_OK;
   GemmGroup g;
   int rc = fill_problem(g.p[0], out, a, b, M, N, K, lda, ldb, ldc, 1, epilogue, epi_gate, epi_gate_stride, epi_res, epi_rows_per_batch);
@@ -521,6 +546,7 @@ int fdm_gemm_w8a8_fp8(void* out, const void* a, const void* b, const float* scal
 }
 
 int fdm_gemm_w8a8_fp8_x2(const fdm_gemm_fp8_desc* d0, const fdm_gemm_fp8_desc* d1, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!d0 || !d1) return FDM_ERR_INVALID;
   const fdm_gemm_fp8_desc* ds[2] = {d0, d1};
   GemmGroup g;
@@ -546,6 +572,7 @@ int fdm_gemm_w8a8_int8(void* out, const void* a, const void* b, const float* sca
                        const int32_t* azp_adj, const int32_t* azp, const void* bias, int64_t M, int64_t N, int64_t K,
                        int64_t lda, int64_t ldb, int64_t ldc, int epilogue, const void* epi_gate, int64_t epi_gate_stride,
                        const void* epi_res, int64_t epi_rows_per_batch, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (M == 0 && N > 0 && K > 0) return FDM_OK;
   GemmGroup g;
   int rc = fill_problem(g.p[0], out, a, b, M, N, K, lda, ldb, ldc, 1, epilogue, epi_gate, epi_gate_stride, epi_res, epi_rows_per_batch);
@@ -564,6 +591,7 @@ int fdm_gemm_w8a8_int8(void* out, const void* a, const void* b, const float* sca
 int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
                   int64_t ldb, int64_t ldc, int epilogue, const void* epi_gate, int64_t epi_gate_stride, const void* epi_res,
                   int64_t epi_rows_per_batch, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (M == 0 && N > 0 && K > 0) return FDM_OK;
   GemmGroup g;
   int rc = fill_problem(g.p[0], out, a, b, M, N, K, lda, ldb, ldc, 2, epilogue, epi_gate, epi_gate_stride, epi_res, epi_rows_per_batch);

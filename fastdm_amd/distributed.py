@@ -19,7 +19,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # FDM_FORCE_DIST=1 initialises the process group for a single rank too (exercises the RCCL path on a 1-GPU box)
+    if (world > 1 or os.environ.get("FDM_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -40,7 +41,7 @@ def gather_latents(local: torch.Tensor, n_items: int, rank: int, world: int) -> 
 
     Ranks may own different counts (n_items not divisible by world): shorter shards are padded to the
     longest so a single fixed-size all_gather suffices."""
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return local
     per = -(-n_items // world)
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -56,7 +57,15 @@ def gather_latents(local: torch.Tensor, n_items: int, rank: int, world: int) -> 
 
 def barrier():
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def max_over_ranks(x: float, device) -> float:

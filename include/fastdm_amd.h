@@ -37,6 +37,8 @@ enum {
 
 int fdm_version(void);
 const char* fdm_error_string(int code);
+/* HIP runtime message behind the most recent FDM_ERR_LAUNCH returned to this process. */
+const char* fdm_last_hip_error_string(void);
 
 /* ---- replaces cuda_ops.rms_norm_ (ops.h:17-20; csrc/elmwise_ops.cu:56-84,433-449) -------------
  * out[r,:] = bf16(bf16(x[r,:] * rsqrt(mean(x^2)+eps)) * w[:]);  rows x hidden, contiguous.   */
