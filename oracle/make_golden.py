@@ -321,6 +321,83 @@ def gen_teacache():
     save("teacache.npz", d)
 
 
+# ------------------------------------------------------------------ Qwen-Image
+def ref_qwen_core(cfg, quant, sd, cache=None):
+    from fastdm.model.qwenimage import QwenImageTransformer2DModelCore
+    core = QwenImageTransformer2DModelCore(
+        patch_size=cfg.patch_size, in_channels=cfg.in_channels, out_channels=cfg.out_channels, num_layers=cfg.num_layers,
+        attention_head_dim=cfg.attention_head_dim, num_attention_heads=cfg.num_attention_heads,
+        joint_attention_dim=cfg.joint_attention_dim, axes_dims_rope=cfg.axes_dims_rope, data_type=torch.bfloat16,
+        quant_dtype=quant, cache=cache)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        core.weight_loading(dict(sd), device_type="cpu")
+    return core
+
+
+def gen_tiny_qwen():
+    """Tiny Qwen-Image core (3 blocks) through the reference in bf16 / int8 / fp8 at two timesteps, the rope table
+    and timestep embedding it builds, and a TeaCache trace with the negative-prompt cache (two forwards per step,
+    xcaching.py:66-76) over a 10-step trajectory."""
+    import_reference()
+    from fastdm.caching.xcaching import AutoCache
+    from oracle import qwen as OQ
+    cfg = OQ.TINY
+    sd = OQ.synth_state_dict(cfg, seed=11)
+    inp = OQ.synth_inputs(cfg, batch=2, img_h=6, img_w=4, n_txt=7, seed=11)
+    d = {"seed": 11, "batch": 2, "img_h": 6, "img_w": 4, "n_txt": 7}
+    for tag, qt in (("bf16", None), ("int8", torch.int8), ("fp8", torch.float8_e4m3fn)):
+        use_backend("cpu_fp8" if qt == torch.float8_e4m3fn else "torch")
+        core = ref_qwen_core(cfg, qt, sd)
+        for ti, t in enumerate((1.0, 0.62)):
+            out = core.forward(timestep=torch.tensor([t, t]), **inp)[0]
+            d[f"out_{tag}_t{ti}"] = out
+    use_backend("torch")
+    core = ref_qwen_core(cfg, None, sd)
+    img_f, txt_f = core.pos_embed.forward(inp["img_shapes"], inp["txt_seq_lens"], device=torch.device("cpu"))
+    d["rope"] = torch.cat([torch.cat([txt_f.real, txt_f.imag], -1), torch.cat([img_f.real, img_f.imag], -1)], 0).to(torch.bfloat16)
+    d["temb_t062"] = core.time_text_embed.forward(torch.tensor([0.62]).to(torch.bfloat16), torch.zeros(1, 1, dtype=torch.bfloat16))
+    # TeaCache with negative cache: cond and uncond forwards alternate within a step
+    coeffs = json.load(open(os.path.join(REF, "examples/xcaching/configs/teacache_qwenimage.json")))
+    inp1 = OQ.synth_inputs(cfg, batch=1, img_h=6, img_w=4, n_txt=7, seed=12)
+    neg = OQ.synth_inputs(cfg, batch=1, img_h=6, img_w=4, n_txt=7, seed=13)["encoder_hidden_states"]
+    state = {"step": 0}
+    cfgd = dict(coeffs)
+    cfgd["negtive_cache"] = True
+    cfgd["threshold"] = 0.25         # between one and two per-step increments on this tiny random net: both branches are taken
+    cache = AutoCache.from_dict(cfgd)
+    cache.config.current_steps_callback = lambda: state["step"]
+    core = ref_qwen_core(cfg, torch.int8, sd, cache=cache)
+    lat = inp1["hidden_states"].clone()
+    sig = torch.linspace(1.0, 0.1, 10)
+    decisions, outs = [], []
+    import contextlib
+    import io
+    for i in range(10):
+        state["step"] = i
+        row = []
+        for enc in (inp1["encoder_hidden_states"], neg):
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                out = core.forward(hidden_states=lat, encoder_hidden_states=enc, encoder_hidden_states_mask=inp1["encoder_hidden_states_mask"],
+                                   timestep=sig[i:i + 1], img_shapes=inp1["img_shapes"], txt_seq_lens=inp1["txt_seq_lens"])[0]
+            row.append(out)
+            decisions.append(0 if "Skipping" in buf.getvalue() else 1)
+        outs.append(torch.stack(row))
+        comb = row[1].float() + 4.0 * (row[0].float() - row[1].float())          # true-CFG combine, scale 4
+        dt = (sig[i + 1] - sig[i]) if i + 1 < 10 else -sig[i]
+        lat = (lat.float() + dt * comb[..., : cfg.in_channels]).to(torch.bfloat16)
+    d["tc_threshold"] = 0.25
+    d["tc_coefficients"] = np.array(coeffs["coefficients"])
+    d["tc_negtive_coefficients"] = np.array(coeffs["negtive_coefficients"])
+    d["tc_should_calc"] = np.array(decisions, dtype=np.int8)
+    d["tc_outs"] = torch.stack(outs)
+    d["tc_final"] = lat
+    save("tiny_qwen.npz", d)
+
+
+
 # ------------------------------------------------------------------ full-width C3 fixture
 def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=0, sub=64):
     """Full-width FLUX.1-dev at 1024x2048 (S = 8192 + 512) through the reference's own block
@@ -415,7 +492,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "c3"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "c3"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     args = ap.parse_args()
@@ -428,6 +505,8 @@ def main():
         gen_tiny_flux()
     if args.what in ("small", "teacache"):
         gen_teacache()
+    if args.what in ("small", "qwen"):
+        gen_tiny_qwen()
     if args.what == "c3":
         gen_c3(args.blocks[0], args.blocks[1], args.quant)
 

@@ -19,6 +19,8 @@ class TeaCacheConfig:
     threshold: float = 0.2
     coefficients: List[float] = field(default_factory=lambda: list(FLUX_COEFFICIENTS))
     current_steps_callback: Optional[Callable] = None
+    negtive_cache: bool = False                                   # sic (fastdm/caching/config.py:16)
+    negtive_coefficients: Optional[List[float]] = None
 
 
 def poly(coeffs, x: float) -> float:
@@ -69,4 +71,48 @@ class TeaCache:
             return hidden + self.prev_residual
         out = core.run_blocks(hidden, encoder, temb, rope)
         self.prev_residual = out - hidden
+        return out
+
+
+class TeaCacheQwen:
+    """fastdm/caching/xcaching.py:156-276, Qwen-Image branch: the modulated input is the TEXT stream of block 0
+    (xcaching.py:171-180) and, with `negtive_cache`, cond / uncond forwards alternate between two cache keys with
+    their own coefficients (xcaching.py:66-76,160-163)."""
+
+    def __init__(self, config: TeaCacheConfig):
+        self.config = config
+        keys = ("positive", "negative")
+        coeffs = {"positive": config.coefficients, "negative": config.negtive_coefficients}
+        self.decision = {k: TeaCacheDecision(coeffs[k], config.threshold) for k in keys}
+        self.prev_modulated = {k: None for k in keys}
+        self.prev_residual = {k: None for k in keys}
+        self.cache_status = {"positive": True, "negative": False}
+        self.trace = []
+
+    def get_cache_key(self):
+        if not self.config.negtive_cache:
+            return "positive"
+        key = None
+        for k in self.cache_status:
+            if self.cache_status[k] and key is None:
+                key = k
+            self.cache_status[k] = not self.cache_status[k]
+        return key
+
+    def apply_cache_qwen(self, core, hidden, encoder, temb, rope):
+        step = self.config.current_steps_callback()
+        step = 0 if step is None else step
+        modulated = core.transformer_blocks[0].modulated_inputs(hidden.clone(), encoder.clone(), temb.clone())[3]
+        key = self.get_cache_key()
+        rel = None
+        if step != 0:
+            prev = self.prev_modulated[key]
+            rel = ((modulated - prev).abs().mean() / prev.abs().mean()).cpu().item()
+        should_calc = self.decision[key].step(step, rel)
+        self.trace.append((step, key, rel, float(self.decision[key].acc), should_calc))
+        self.prev_modulated[key] = modulated
+        if not should_calc:
+            return hidden + self.prev_residual[key]
+        out = core.run_blocks(hidden, encoder, temb, rope)
+        self.prev_residual[key] = out - hidden
         return out

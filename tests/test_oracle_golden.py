@@ -157,3 +157,66 @@ def test_teacache_poly_and_trace():
         err = (lat.float() - g[f"{tag}_final"].float()).abs()
         assert err.max() < 5e-2, err.max()
     assert 0 in g["loose_should_calc"].tolist() and 1 in g["loose_should_calc"].tolist()[1:]
+
+
+# ------------------------------------------------------------------ Qwen-Image
+def test_qwen_rope_and_timestep_embedding_match_reference():
+    from oracle import qwen as OQ
+    g = load("tiny_qwen.npz")
+    cfg = OQ.TINY
+    rope = OQ.qwen_rope_cache([(1, int(g["img_h"]), int(g["img_w"]))], int(g["n_txt"]), cfg.axes_dims_rope)
+    assert torch.equal(rope, g["rope"])
+    sd = OQ.synth_state_dict(cfg, seed=int(g["seed"]))
+    core = OQ.QwenCore(sd, cfg, None)
+    t = torch.tensor([0.62]).to(torch.bfloat16)
+    temb = core.t2(torch.nn.functional.silu(core.t1(OQ.qwen_timestep_embedding(t).to(torch.bfloat16))))
+    assert torch.equal(temb, g["temb_t062"])
+
+
+@pytest.mark.parametrize("tag,qt", [("bf16", None), ("int8", torch.int8), ("fp8", torch.float8_e4m3fn)])
+def test_qwen_tiny_core_matches_reference(tag, qt):
+    from oracle import qwen as OQ
+    g = load("tiny_qwen.npz")
+    cfg = OQ.TINY
+    sd = OQ.synth_state_dict(cfg, seed=int(g["seed"]))
+    inp = OQ.synth_inputs(cfg, int(g["batch"]), int(g["img_h"]), int(g["img_w"]), int(g["n_txt"]), seed=int(g["seed"]))
+    core = OQ.QwenCore(sd, cfg, qt)
+    for ti, t in enumerate((1.0, 0.62)):
+        out = core.forward(timestep=torch.tensor([t, t]), **inp)[0]
+        ref = g[f"out_{tag}_t{ti}"]
+        d = (out.float() - ref.float()).abs()
+        # the restatement's attention is an explicit fp32 softmax, the reference's torch SDPA (bf16 flash-style on CPU)
+        assert d.max() <= 3e-2 and d.mean() <= 4e-3, (tag, ti, d.max().item(), d.mean().item())
+
+
+def test_qwen_teacache_negative_cache_trace():
+    from oracle import qwen as OQ
+    g = load("tiny_qwen.npz")
+    cfg = OQ.TINY
+    sd = OQ.synth_state_dict(cfg, seed=int(g["seed"]))
+    inp1 = OQ.synth_inputs(cfg, 1, int(g["img_h"]), int(g["img_w"]), int(g["n_txt"]), seed=12)
+    neg = OQ.synth_inputs(cfg, 1, int(g["img_h"]), int(g["img_w"]), int(g["n_txt"]), seed=13)["encoder_hidden_states"]
+    state = {"step": 0}
+    tcfg = TC.TeaCacheConfig(threshold=float(g["tc_threshold"]), coefficients=list(g["tc_coefficients"]), negtive_cache=True,
+                             negtive_coefficients=list(g["tc_negtive_coefficients"]), current_steps_callback=lambda: state["step"])
+    cache = TC.TeaCacheQwen(tcfg)
+    core = OQ.QwenCore(sd, cfg, torch.int8, cache=cache)
+    lat = inp1["hidden_states"].clone()
+    sig = torch.linspace(1.0, 0.1, 10)
+    decisions = []
+    for i in range(10):
+        state["step"] = i
+        row = []
+        for enc in (inp1["encoder_hidden_states"], neg):
+            row.append(core.forward(hidden_states=lat, encoder_hidden_states=enc, timestep=sig[i:i + 1],
+                                    img_shapes=inp1["img_shapes"], txt_seq_lens=inp1["txt_seq_lens"])[0])
+            decisions.append(int(cache.trace[-1][-1]))
+        comb = row[1].float() + 4.0 * (row[0].float() - row[1].float())
+        dt = (sig[i + 1] - sig[i]) if i + 1 < 10 else -sig[i]
+        lat = (lat.float() + dt * comb[..., : cfg.in_channels]).to(torch.bfloat16)
+    want = [int(x) for x in g["tc_should_calc"]]
+    assert 0 in want and 1 in want[2:], "fixture must exercise both branches"
+    assert decisions == want
+    d = (lat.float() - g["tc_final"].float()).abs()
+    # 20 forwards, each implementation-vs-implementation difference amplified by the CFG scale of 4
+    assert d.max() <= 1e-1 and d.mean() <= 1.5e-2, (d.max().item(), d.mean().item())

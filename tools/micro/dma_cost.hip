@@ -9,10 +9,11 @@
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int MODE, int NLOAD, bool BARRIER>
+template <int MODE, int NLOAD, bool BARRIER, bool M16 = false>
 __global__ void __launch_bounds__(512, 2) k(const uint8_t* __restrict__ src, float* __restrict__ out, int iters) {
   __shared__ __attribute__((aligned(1024))) uint8_t smem[128 * 1024];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -51,9 +52,19 @@ __global__ void __launch_bounds__(512, 2) k(const uint8_t* __restrict__ src, flo
 #pragma unroll
       for (int i = 0; i < 12; ++i) fr[i] = *reinterpret_cast<const i32x4*>(smem + (((it + 1) & 3) * 32768) + i * 1024 + ((lane * 16) ^ ((i & 3) << 4)));
     }
+    if constexpr (!M16) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      for (int j = 0; j < 8; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
+    } else {
+      // same flops per step with 16x16x128: 16 MFMAs on 4-register accumulators (32 of them live in acc[8][16])
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        f32x4 c = {acc[j >> 1][(j & 1) * 8 + 0], acc[j >> 1][(j & 1) * 8 + 1], acc[j >> 1][(j & 1) * 8 + 2], acc[j >> 1][(j & 1) * 8 + 3]};
+        c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        acc[j >> 1][(j & 1) * 8 + 0] = c[0]; acc[j >> 1][(j & 1) * 8 + 1] = c[1]; acc[j >> 1][(j & 1) * 8 + 2] = c[2]; acc[j >> 1][(j & 1) * 8 + 3] = c[3];
+      }
     }
     if constexpr (MODE == 3) {
 #pragma unroll
@@ -72,15 +83,15 @@ __global__ void __launch_bounds__(512, 2) k(const uint8_t* __restrict__ src, flo
   out[blockIdx.x * 512 + tid] = s + smem[tid];
 }
 
-template <int MODE, int NLOAD, bool BARRIER>
+template <int MODE, int NLOAD, bool BARRIER, bool M16 = false>
 void run(const char* name, const uint8_t* src, float* out) {
   const int iters = 4000;
   hipEvent_t s, e;
   hipEventCreate(&s); hipEventCreate(&e);
-  k<MODE, NLOAD, BARRIER><<<256, 512>>>(src, out, 500);
+  k<MODE, NLOAD, BARRIER, M16><<<256, 512>>>(src, out, 500);
   hipDeviceSynchronize();
   hipEventRecord(s);
-  k<MODE, NLOAD, BARRIER><<<256, 512>>>(src, out, iters);
+  k<MODE, NLOAD, BARRIER, M16><<<256, 512>>>(src, out, iters);
   hipEventRecord(e);
   hipEventSynchronize(e);
   float ms; hipEventElapsedTime(&ms, s, e);
@@ -110,5 +121,10 @@ int main() {
   run<3, 0, false>("12 ds_read_b128 only", src, out);
   run<3, 4, false>("LDS-DMA + 12 ds_read_b128", src, out);
   run<3, 4, true>("LDS-DMA + 12 ds_read_b128", src, out);
+  run<0, 0, false, true>("16x16x128: MFMA only", src, out);
+  run<0, 4, true, true>("16x16x128: LDS-DMA", src, out);
+  run<3, 4, true, true>("16x16x128: LDS-DMA + 12 ds_read_b128", src, out);
+  run<3, 4, true>("32x32x64: LDS-DMA + 12 ds_read_b128", src, out);
+  run<3, 4, true, true>("16x16x128: LDS-DMA + 12 ds_read_b128", src, out);
   return 0;
 }
