@@ -78,10 +78,13 @@ class TeaCache(AutoCache):
         super().__init__(config)
         self.coefficients = {"positive": config.coefficients, "negative": config.negtive_coefficients}
 
-    def _get_modulated_input(self, model_type, hidden_states, temb, transformer_blocks):
-        """xcaching.py:165-183: the first block's norm1 output (bf16 [B,S,D])."""
+    def _get_modulated_input(self, model_type, hidden_states, temb, transformer_blocks, encoder_hidden_states=None):
+        """xcaching.py:165-183: FLUX probes the first block's norm1 output of the IMAGE stream, Qwen-Image the
+        modulated TEXT stream of block 0 (bf16 [B,S,D])."""
+        if model_type == "qwenimage":
+            return transformer_blocks[0].txt_modulated(encoder_hidden_states, temb)
         if model_type not in ("flux", "sd35"):
-            raise ValueError(f"TeaCache unsupported model type: {model_type}. Supported types: flux")
+            raise ValueError(f"TeaCache unsupported model type: {model_type}. Supported types: qwenimage, flux")
         return transformer_blocks[0].norm1.forward(hidden_states, emb=temb)[0]
 
     def rel_distance(self, modulated, previous) -> float:
@@ -93,9 +96,9 @@ class TeaCache(AutoCache):
     def apply_cache(self, model_type: str, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
                     temb: torch.Tensor = None, image_rotary_emb: torch.Tensor = None, attention_kwargs: Optional[Dict[str, Any]] = None,
                     transformer_blocks=None, single_transformer_blocks=None, core=None, **_):
-        """xcaching.py:187-276 (FLUX branch)."""
+        """xcaching.py:187-276 (FLUX and Qwen-Image branches; the blocks run through `core.run_blocks`)."""
         current_step = self.get_current_step()
-        modulated_inp = self._get_modulated_input(model_type, hidden_states, temb, transformer_blocks)
+        modulated_inp = self._get_modulated_input(model_type, hidden_states, temb, transformer_blocks, encoder_hidden_states)
         cache_key = self.get_cache_key()
         rel = None
         if current_step == 0:
@@ -110,7 +113,7 @@ class TeaCache(AutoCache):
             else:
                 should_calc = True
                 self.accumulated_rel_l1_distance_dict[cache_key] = 0
-        self.trace.append((current_step, rel, float(self.accumulated_rel_l1_distance_dict[cache_key]), should_calc))
+        self.trace.append((current_step, rel, float(self.accumulated_rel_l1_distance_dict[cache_key]), should_calc, cache_key))
         self.previous_modulated_input_dict[cache_key] = modulated_inp
         if not should_calc:
             return hidden_states + self.previous_residual_dict[cache_key]

@@ -123,3 +123,66 @@ class FluxPosEmbed:
             cos_out.append(cos)
             sin_out.append(sin)
         return torch.cat(cos_out, dim=-1).to(dev), torch.cat(sin_out, dim=-1).to(dev)
+
+
+class QwenTimestepProjEmbeddings:
+    """embeddings.py:746-760: Timesteps(256, flip_sin_to_cos, shift 0, scale=1000) -> TimestepEmbedding."""
+
+    def __init__(self, embedding_dim, data_type=BF16):
+        self.time_proj = Timesteps(num_channels=256, flip_sin_to_cos=True, downscale_freq_shift=0, scale=1000)
+        self.timestep_embedder = TimestepEmbedding(in_features=256, out_features=embedding_dim, data_type=data_type)
+
+    def forward(self, timestep, hidden_states):
+        timesteps_proj = self.time_proj.forward(timestep)
+        return self.timestep_embedder.forward(timesteps_proj.to(dtype=hidden_states.dtype))
+
+
+class QwenEmbedRope:
+    """embeddings.py:762-857.  Complex unit-vector tables for 4096 positive and 4096 negative positions per axis;
+    `forward` returns (video_freqs [frame*h*w, hd/2], text_freqs [max_txt, hd/2]) as complex64.  Built on the CPU
+    (tables are tiny and only rebuilt when the image shape changes), moved to `device`."""
+
+    def __init__(self, theta: int, axes_dim: List[int], scale_rope=False):
+        self.theta, self.axes_dim, self.scale_rope = theta, axes_dim, scale_rope
+        pos_index = torch.arange(4096)
+        neg_index = torch.arange(4096).flip(0) * -1 - 1
+        self.pos_freqs = torch.cat([self.rope_params(pos_index, d, theta) for d in axes_dim], dim=1)
+        self.neg_freqs = torch.cat([self.rope_params(neg_index, d, theta) for d in axes_dim], dim=1)
+        self.rope_cache = {}
+
+    @staticmethod
+    def rope_params(index, dim, theta=10000):
+        assert dim % 2 == 0
+        freqs = torch.outer(index, 1.0 / torch.pow(theta, torch.arange(0, dim, 2).to(torch.float32).div(dim)))
+        return torch.polar(torch.ones_like(freqs), freqs)
+
+    def _compute_video_freqs(self, frame, height, width, idx=0):
+        seq_lens = frame * height * width
+        freqs_pos = self.pos_freqs.split([x // 2 for x in self.axes_dim], dim=1)
+        freqs_neg = self.neg_freqs.split([x // 2 for x in self.axes_dim], dim=1)
+        freqs_frame = freqs_pos[0][idx: idx + frame].view(frame, 1, 1, -1).expand(frame, height, width, -1)
+        if self.scale_rope:
+            freqs_height = torch.cat([freqs_neg[1][-(height - height // 2):], freqs_pos[1][: height // 2]], dim=0)
+            freqs_width = torch.cat([freqs_neg[2][-(width - width // 2):], freqs_pos[2][: width // 2]], dim=0)
+        else:
+            freqs_height, freqs_width = freqs_pos[1][:height], freqs_pos[2][:width]
+        freqs_height = freqs_height.view(1, height, 1, -1).expand(frame, height, width, -1)
+        freqs_width = freqs_width.view(1, 1, width, -1).expand(frame, height, width, -1)
+        return torch.cat([freqs_frame, freqs_height, freqs_width], dim=-1).reshape(seq_lens, -1).clone().contiguous()
+
+    def forward(self, video_fhw, txt_seq_lens, device):
+        if isinstance(video_fhw, list):
+            video_fhw = video_fhw[0]
+        if not isinstance(video_fhw, list):
+            video_fhw = [video_fhw]
+        vid_freqs, max_vid_index = [], 0
+        for idx, fhw in enumerate(video_fhw):
+            frame, height, width = fhw
+            key = (idx, frame, height, width)
+            if key not in self.rope_cache:
+                self.rope_cache[key] = self._compute_video_freqs(frame, height, width, idx)
+            vid_freqs.append(self.rope_cache[key])
+            max_vid_index = max(height // 2, width // 2, max_vid_index) if self.scale_rope else max(height, width, max_vid_index)
+        max_len = max(txt_seq_lens)
+        txt_freqs = self.pos_freqs[max_vid_index: max_vid_index + max_len, ...]
+        return torch.cat(vid_freqs, dim=0).to(device), txt_freqs.to(device)

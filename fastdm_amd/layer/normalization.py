@@ -15,6 +15,18 @@ from fastdm_amd.layer.qlinear import QLinear
 BF16 = torch.bfloat16
 
 
+class RMSNorm:
+    """normalization.py:16-43 with elementwise_affine=True: the rms_norm operator over the last dimension."""
+
+    def __init__(self, dim, eps: float, elementwise_affine: bool = True):
+        assert elementwise_affine
+        self.dim, self.eps, self.weight = dim, eps, None
+
+    def forward(self, hidden_states):
+        from fastdm_amd.kernel.operators_set import rms_norm
+        return rms_norm(hidden_states.contiguous(), self.weight, self.eps)
+
+
 class _AdaLNBase:
     chunks = 0
 

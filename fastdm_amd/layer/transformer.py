@@ -124,3 +124,12 @@ class Attention:
         if not self.pre_only:
             img_o = self.to_out.forward(img_o)
         return img_o, enc_o
+
+    def forward_qwen(self, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None, attention_mask=None,
+                     **cross_attention_kwargs):
+        """transformer.py:319-391: the same joint [text ; image] attention as `forward` (the text mask is accepted and
+        unused there too); returns (img_attn_output, txt_attn_output)."""
+        if encoder_hidden_states is None:
+            raise ValueError("QwenAttn forward requires encoder_hidden_states (text stream)")
+        cross_attention_kwargs.pop("encoder_hidden_states_mask", None)
+        return self.forward(hidden_states, encoder_hidden_states, attention_mask, **cross_attention_kwargs)

@@ -73,36 +73,45 @@ class FluxTransformerBlock:
 
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, temb: torch.Tensor,
                 image_rotary_emb=None, joint_attention_kwargs=None):
-        B, s_img, D = hidden_states.shape
-        s_txt = encoder_hidden_states.shape[1]
-        quant = self.attn.qkv.quant_type
-        x = hidden_states.reshape(B * s_img, D)
-        e = encoder_hidden_states.reshape(B * s_txt, D)
-        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1.modulation(temb).chunk(6, dim=1)
-        c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.norm1_context.modulation(temb).chunk(6, dim=1)
+        return fused_double_stream(self.attn, self.ff, self.ff_context, self.norm1.modulation(temb), self.norm1_context.modulation(temb),
+                                   hidden_states, encoder_hidden_states, image_rotary_emb)
 
-        def pick(t):
-            return t[1] if quant is not None else t[0]
 
-        xin = pick(fused.ln_modulate(x, scale_msa, shift_msa, s_img, quant=quant))
-        ein = pick(fused.ln_modulate(e, c_scale_msa, c_shift_msa, s_txt, quant=quant))
-        o = self.attn.attend(xin, B, s_img, image_rotary_emb, ein, s_txt).view(B, s_txt + s_img, D)
+def fused_double_stream(attn, ff_img, ff_txt, mod_img, mod_txt, hidden_states, encoder_hidden_states, image_rotary_emb):
+    """One double-stream (MMDiT) block on the fused kernels; `mod_*` are the [B, 6*D] modulation projections in the
+    order (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp).  Shared by the FLUX double block
+    (flux.py:130-178) and the Qwen-Image block (qwenimage.py:58-124), whose arithmetic is identical.
+    Returns (encoder_hidden_states, hidden_states)."""
+    B, s_img, D = hidden_states.shape
+    s_txt = encoder_hidden_states.shape[1]
+    quant = attn.qkv.quant_type
+    x = hidden_states.reshape(B * s_img, D)
+    e = encoder_hidden_states.reshape(B * s_txt, D)
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mod_img.chunk(6, dim=1)
+    c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = mod_txt.chunk(6, dim=1)
 
-        # attention rows of a stream are a strided slice of the joint output: quantise / project per batch element;
-        # the image and text projections of one batch element share a launch
-        x_new, e_new = torch.empty_like(x), torch.empty_like(e)
-        to_o, to_ao = self.attn.to_out, self.attn.to_add_out
-        for b in range(B):
-            ai, at = o[b, s_txt:], o[b, :s_txt]
-            aqi = to_o.quantize_input(ai) if to_o.quant_type is not None else ai
-            aqt = to_ao.quantize_input(at) if to_ao.quant_type is not None else at
-            QLinear.forward_q_pair(to_o, aqi, to_ao, aqt, epilogue=N.EPI_GATE_RESIDUAL,
-                                   gate0=gate_msa[b:b + 1], res0=x[b * s_img:(b + 1) * s_img], rpb0=s_img, out0=x_new[b * s_img:(b + 1) * s_img],
-                                   gate1=c_gate_msa[b:b + 1], res1=e[b * s_txt:(b + 1) * s_txt], rpb1=s_txt, out1=e_new[b * s_txt:(b + 1) * s_txt])
-        fin_x = pick(fused.ln_modulate(x_new, scale_mlp, shift_mlp, s_img, quant=quant))
-        fin_e = pick(fused.ln_modulate(e_new, c_scale_mlp, c_shift_mlp, s_txt, quant=quant))
-        x, e = FeedForward.forward_fused_pair(self.ff, fin_x, gate_mlp, x_new, s_img, self.ff_context, fin_e, c_gate_mlp, e_new, s_txt)
-        return e.view(B, s_txt, D), x.view(B, s_img, D)
+    def pick(t):
+        return t[1] if quant is not None else t[0]
+
+    xin = pick(fused.ln_modulate(x, scale_msa, shift_msa, s_img, quant=quant))
+    ein = pick(fused.ln_modulate(e, c_scale_msa, c_shift_msa, s_txt, quant=quant))
+    o = attn.attend(xin, B, s_img, image_rotary_emb, ein, s_txt).view(B, s_txt + s_img, D)
+
+    # attention rows of a stream are a strided slice of the joint output: quantise / project per batch element;
+    # the image and text projections of one batch element share a launch
+    x_new, e_new = torch.empty_like(x), torch.empty_like(e)
+    to_o, to_ao = attn.to_out, attn.to_add_out
+    for b in range(B):
+        ai, at = o[b, s_txt:], o[b, :s_txt]
+        aqi = to_o.quantize_input(ai) if to_o.quant_type is not None else ai
+        aqt = to_ao.quantize_input(at) if to_ao.quant_type is not None else at
+        QLinear.forward_q_pair(to_o, aqi, to_ao, aqt, epilogue=N.EPI_GATE_RESIDUAL,
+                               gate0=gate_msa[b:b + 1], res0=x[b * s_img:(b + 1) * s_img], rpb0=s_img, out0=x_new[b * s_img:(b + 1) * s_img],
+                               gate1=c_gate_msa[b:b + 1], res1=e[b * s_txt:(b + 1) * s_txt], rpb1=s_txt, out1=e_new[b * s_txt:(b + 1) * s_txt])
+    fin_x = pick(fused.ln_modulate(x_new, scale_mlp, shift_mlp, s_img, quant=quant))
+    fin_e = pick(fused.ln_modulate(e_new, c_scale_mlp, c_shift_mlp, s_txt, quant=quant))
+    x, e = FeedForward.forward_fused_pair(ff_img, fin_x, gate_mlp, x_new, s_img, ff_txt, fin_e, c_gate_mlp, e_new, s_txt)
+    return e.view(B, s_txt, D), x.view(B, s_img, D)
 
 
 class FluxTransformer2DModelCore(BaseModelCore):

@@ -19,6 +19,7 @@ import torch.nn as nn
 from fastdm_amd.caching.xcaching import AutoCache
 from fastdm_amd.kernel.utils import set_global_backend
 from fastdm_amd.model.flux import FluxTransformer2DModelCore
+from fastdm_amd.model.qwenimage import QwenImageTransformer2DModelCore
 
 
 class ConfigMixin:
@@ -82,10 +83,34 @@ class FluxTransformerWrapper(BaseModelWrapper):
         return self.core_model.forward(hidden_states, **kwargs)
 
 
+class QwenTransformerWrapper(BaseModelWrapper):
+    """model_entry.py:148-189.  NB the reference's defaults (out_channels=64) are what its pipelines pass; the
+    Qwen-Image checkpoint itself has out_channels=16 with patch_size 2 (proj_out -> 64)."""
+
+    def __init__(self, ckpt_path=None, in_channels: int = 64, out_channels: int = 64, dtype: torch.dtype = torch.bfloat16,
+                 quant_type: Optional[torch.dtype] = None, kernel_backend: str = "hip", need_resolve_oom=False,
+                 cache: AutoCache = None, **kwargs):
+        super().__init__(kernel_backend)
+        self.config = self._create_diffusers_config(in_channels=in_channels, out_channels=out_channels, guidance_embeds=False, dtype=dtype)
+        self.dtype = dtype
+        self.need_resolve_oom = need_resolve_oom
+        self.core_model = QwenImageTransformer2DModelCore(in_channels=in_channels, out_channels=out_channels, guidance_embeds=False,
+                                                          data_type=dtype, quant_dtype=quant_type, cache=cache,
+                                                          oom_ressolve=need_resolve_oom, **kwargs)
+        if isinstance(ckpt_path, dict) or (ckpt_path and os.path.exists(ckpt_path)):
+            self.core_model.weight_loading(ckpt_path, data_type=dtype, device_type="cuda")
+        elif ckpt_path:
+            print(f"Warning: Checkpoint path {ckpt_path} does not exist")
+
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, **kwargs):
+        return self.core_model.forward(hidden_states, **kwargs)
+
+
 class ModelWrapperFactory:
     """model_entry.py:463-497."""
-    _WRAPPER_MAPPING = {"flux": FluxTransformerWrapper}
-    _NOT_BUILT = ("sdxl", "sd35", "qwen", "wan", "sdxl-controlnet", "flux-controlnet")
+    _WRAPPER_MAPPING = {"flux": FluxTransformerWrapper, "qwen": QwenTransformerWrapper}
+    _NOT_BUILT = ("sdxl", "sd35", "wan", "sdxl-controlnet", "flux-controlnet")
 
     @classmethod
     def create_wrapper(cls, model_type: str, **kwargs) -> BaseModelWrapper:

@@ -1,0 +1,117 @@
+"""GPU parity of the Qwen-Image path: the tiny core in bf16 / int8 / fp8 against outputs of the
+reference itself (tests/golden/tiny_qwen.npz), its RoPE table and timestep embedding, TeaCache with the
+negative-prompt cache, and the block / wrapper surface."""
+import pytest
+import torch
+
+from oracle import qwen as OQ
+from oracle.make_golden import load
+
+pytestmark = pytest.mark.gpu
+BF16, FP8 = torch.bfloat16, torch.float8_e4m3fn
+
+
+def close(got, ref, max_abs, mean_abs, what):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite"
+    d = (got - ref).abs()
+    assert d.max() <= max_abs and d.mean() <= mean_abs, f"{what}: max {d.max().item():.4g} (<= {max_abs}), mean {d.mean().item():.4g} (<= {mean_abs})"
+
+
+def tiny_core(quant, cache=None, seed=11):
+    from fastdm_amd.model_entry import create_model
+    cfg = OQ.TINY
+    sd = OQ.synth_state_dict(cfg, seed=seed)
+    return create_model("qwen", ckpt_path=sd, dtype=BF16, quant_type=quant, kernel_backend="hip", cache=cache,
+                        in_channels=cfg.in_channels, out_channels=cfg.out_channels, num_layers=cfg.num_layers,
+                        attention_head_dim=cfg.attention_head_dim, num_attention_heads=cfg.num_attention_heads,
+                        joint_attention_dim=cfg.joint_attention_dim, axes_dims_rope=cfg.axes_dims_rope).eval()
+
+
+def dev_inputs(inp):
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+
+
+def test_qwen_rope_table_and_timestep_embedding_bitwise():
+    g = load("tiny_qwen.npz")
+    model = tiny_core(None, seed=int(g["seed"]))
+    core = model.core_model
+    rope = core._rope_cache([[(1, int(g["img_h"]), int(g["img_w"]))]], [int(g["n_txt"])], torch.device("cuda"), BF16)
+    assert torch.equal(rope.cpu(), g["rope"])
+    t = torch.tensor([0.62]).to(BF16).cuda()
+    temb = core.time_text_embed.forward(t, torch.zeros(1, 1, dtype=BF16, device="cuda"))
+    # sin/cos of the GPU's libm vs the CPU's can differ in the last fp32 bit before the bf16 cast: allow 1 bf16 ulp through the MLP
+    close(temb, g["temb_t062"], 2e-2, 2e-3, "qwen temb")
+
+
+@pytest.mark.parametrize("tag,qt", [("bf16", None), ("int8", torch.int8), ("fp8", FP8)])
+def test_tiny_qwen_against_reference_golden(tag, qt):
+    g = load("tiny_qwen.npz")
+    cfg = OQ.TINY
+    model = tiny_core(qt, seed=int(g["seed"]))
+    assert model.config.in_channels == cfg.in_channels and not model.config.guidance_embeds and model.dtype == BF16
+    inp = dev_inputs(OQ.synth_inputs(cfg, int(g["batch"]), int(g["img_h"]), int(g["img_w"]), int(g["n_txt"]), seed=int(g["seed"])))
+    for ti, t in enumerate((1.0, 0.62)):
+        with model.cache_context("cond"):
+            out = model(timestep=torch.tensor([t, t]).cuda(), return_dict=False, **inp)
+        assert isinstance(out, tuple) and out[0].shape == (2, 24, cfg.proj_out_dim)
+        # same envelope as the tiny FLUX core (reference torch SDPA on CPU vs flash attention + MFMA accumulation order)
+        close(out[0], g[f"out_{tag}_t{ti}"], 6e-2, 1e-2, f"tiny qwen {tag} t{ti}")
+
+
+def test_qwen_block_signature_and_unfused_helpers():
+    model = tiny_core(torch.int8)
+    core = model.core_model
+    cfg = OQ.TINY
+    blk = core.transformer_blocks[0]
+    for name in ("img_mod_proj", "txt_mod_proj", "attn", "img_mlp", "txt_mlp"):
+        assert hasattr(blk, name)
+    assert len(core.transformer_blocks) == cfg.num_layers and blk.attn.qkv.quant_type == torch.int8 and blk.img_mod_proj.quant_type is None
+    g = torch.Generator().manual_seed(0)
+    hidden = torch.randn(1, 24, cfg.inner_dim, generator=g).to(BF16).cuda()
+    enc = torch.randn(1, 7, cfg.inner_dim, generator=g).to(BF16).cuda()
+    temb = torch.randn(1, cfg.inner_dim, generator=g).to(BF16).cuda()
+    rope = core._rope_cache([[(1, 6, 4)]], [7], torch.device("cuda"), BF16)
+    e2, h2 = blk.forward(hidden_states=hidden.clone(), encoder_hidden_states=enc.clone(), encoder_hidden_states_mask=None, temb=temb,
+                         image_rotary_emb=rope)
+    assert e2.shape == enc.shape and h2.shape == hidden.shape
+    sd = OQ.synth_state_dict(cfg, seed=11)
+    want_e, want_h = OQ.QwenImageTransformerBlock(sd, 0, cfg, torch.int8)(hidden.cpu(), enc.cpu(), temb.cpu(), rope.cpu())
+    close(h2, want_h, 6e-2, 6e-3, "qwen block image stream")
+    close(e2, want_e, 6e-2, 6e-3, "qwen block text stream")
+    # forward_qwen keeps the reference's (img, txt) return order
+    img_o, txt_o = blk.attn.forward_qwen(hidden_states=hidden, encoder_hidden_states=enc, encoder_hidden_states_mask=None, image_rotary_emb=rope)
+    assert img_o.shape == hidden.shape and txt_o.shape == enc.shape
+    with pytest.raises(ValueError):
+        blk.attn.forward_qwen(hidden_states=hidden)
+
+
+def test_qwen_teacache_negative_cache_matches_reference_trace():
+    from fastdm_amd.caching import AutoCache
+    g = load("tiny_qwen.npz")
+    cfg = OQ.TINY
+    state = {"step": 0}
+    cache = AutoCache.from_dict({"cache_algorithm": "teacache", "enable_caching": True, "threshold": float(g["tc_threshold"]),
+                                 "negtive_cache": True, "coefficients": g["tc_coefficients"].tolist(),
+                                 "negtive_coefficients": g["tc_negtive_coefficients"].tolist()})
+    cache.config.current_steps_callback = lambda: state["step"]
+    model = tiny_core(torch.int8, cache=cache, seed=int(g["seed"]))
+    inp1 = dev_inputs(OQ.synth_inputs(cfg, 1, int(g["img_h"]), int(g["img_w"]), int(g["n_txt"]), seed=12))
+    neg = OQ.synth_inputs(cfg, 1, int(g["img_h"]), int(g["img_w"]), int(g["n_txt"]), seed=13)["encoder_hidden_states"].cuda()
+    lat = inp1["hidden_states"].clone()
+    sig = torch.linspace(1.0, 0.1, 10)
+    for i in range(10):
+        state["step"] = i
+        row = []
+        for enc in (inp1["encoder_hidden_states"], neg):
+            row.append(model(hidden_states=lat, encoder_hidden_states=enc, encoder_hidden_states_mask=inp1["encoder_hidden_states_mask"],
+                             timestep=sig[i:i + 1].cuda(), img_shapes=inp1["img_shapes"], txt_seq_lens=inp1["txt_seq_lens"])[0])
+        comb = row[1].float() + 4.0 * (row[0].float() - row[1].float())
+        dt = (sig[i + 1] - sig[i]) if i + 1 < 10 else -sig[i]
+        lat = (lat.float() + float(dt) * comb[..., : cfg.in_channels]).to(BF16)
+    decisions = [int(t[3]) for t in cache.trace]
+    keys = [t[4] for t in cache.trace]
+    assert keys == ["positive", "negative"] * 10
+    assert decisions == g["tc_should_calc"].tolist(), (decisions, cache.trace)
+    close(lat, g["tc_final"], 1e-1, 1.5e-2, "qwen teacache final latents")
