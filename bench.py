@@ -84,14 +84,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=IMAGE_STEPS)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--width", type=int, default=2048)
-    ap.add_argument("--max-seq-len", type=int, default=512)
-    ap.add_argument("--quant", choices=["fp8", "int8", "bf16"], default="fp8")
+    ap.add_argument("--model", choices=["flux", "qwen"], default="flux",
+                    help="flux = the headline workload; qwen = Qwen-Image (BASELINE.json configs[3]): a step is a cond + uncond forward pair (true CFG)")
+    ap.add_argument("--height", type=int, default=None, help="default 1024 (flux) / 1328 (qwen)")
+    ap.add_argument("--width", type=int, default=None, help="default 2048 (flux) / 1328 (qwen)")
+    ap.add_argument("--max-seq-len", type=int, default=None, help="text tokens: default 512 (flux) / 128 (qwen)")
+    ap.add_argument("--quant", choices=["fp8", "int8", "bf16"], default=None, help="default fp8 (flux) / int8 (qwen)")
     ap.add_argument("--cache-config", default=None, help="TeaCache JSON (changes the metric: reported as a different workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event spans")
     args = ap.parse_args()
+    dflt = {"flux": (1024, 2048, 512, "fp8"), "qwen": (1328, 1328, 128, "int8")}[args.model]
+    args.height, args.width = args.height or dflt[0], args.width or dflt[1]
+    args.max_seq_len, args.quant = args.max_seq_len or dflt[2], args.quant or dflt[3]
 
     from fastdm_amd import distributed as D
     rank, world, local_rank = D.init_from_env()
@@ -103,20 +108,25 @@ def main():
     from fastdm_amd.caching import AutoCache
     from fastdm_amd.kernel import timing
     from fastdm_amd.model_entry import create_model
-    from fastdm_amd.pipeline import SyntheticFluxPipeline, flow_match_sigmas
-    from fastdm_amd.synthetic import SyntheticFluxStateDict
+    from fastdm_amd.pipeline import SyntheticFluxPipeline, SyntheticQwenPipeline, flow_match_sigmas
+    from fastdm_amd.synthetic import SyntheticFluxStateDict, SyntheticQwenStateDict
 
     quant = {"fp8": torch.float8_e4m3fn, "int8": torch.int8, "bf16": None}[args.quant]
     cache = AutoCache.from_json(args.cache_config) if args.cache_config else None
-    model = create_model("flux", ckpt_path=SyntheticFluxStateDict(seed=0), dtype=torch.bfloat16, quant_type=quant,
-                         kernel_backend="hip", cache=cache).eval()
-    pipe = SyntheticFluxPipeline(model, seed=0)
+    if args.model == "flux":
+        model = create_model("flux", ckpt_path=SyntheticFluxStateDict(seed=0), dtype=torch.bfloat16, quant_type=quant,
+                             kernel_backend="hip", cache=cache).eval()
+        pipe = SyntheticFluxPipeline(model, seed=0)
+    else:
+        model = create_model("qwen", ckpt_path=SyntheticQwenStateDict(seed=0), dtype=torch.bfloat16, quant_type=quant,
+                             kernel_backend="hip", cache=cache, out_channels=16).eval()
+        pipe = SyntheticQwenPipeline(model, seed=0)
     if cache:
         cache.config.current_steps_callback = lambda: pipe.scheduler_step_index
     # rank r denoises image r of the global batch (different latents/prompt per image)
     inp = pipe.prepare(1, args.height, args.width, args.max_seq_len, seed=rank)
     n_img = inp["hidden_states"].shape[1]
-    sig = flow_match_sigmas(IMAGE_STEPS, n_img)
+    sig = flow_match_sigmas(IMAGE_STEPS, n_img) if args.model == "flux" else flow_match_sigmas(IMAGE_STEPS, n_img, max_seq_len=8192, max_shift=0.9)
     guidance = torch.full((1,), 3.5, device=dev, dtype=torch.float32)
 
     state = {"lat": inp["hidden_states"].clone(), "i": 0}
@@ -126,6 +136,10 @@ def main():
         if i == 0:
             state["lat"] = inp["hidden_states"].clone()
         pipe.scheduler_step_index = i
+        if args.model == "qwen":
+            state["lat"] = pipe.step(state["lat"], inp, sig[i], sig[i + 1], 4.0)    # cond + uncond forward, CFG combine, Euler update
+            state["i"] += 1
+            return
         t = torch.full((1,), float(sig[i]), device=dev, dtype=torch.bfloat16)
         with model.cache_context("cond"):
             v = model(hidden_states=state["lat"], timestep=t, guidance=guidance, pooled_projections=inp["pooled_projections"],
@@ -163,11 +177,18 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     skipped = 0
     if cache is not None:
-        skipped = sum(1 for t in cache.trace[-args.steps:] if not t[3])
-    workload = (f"FLUX.1-dev {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step flow-match schedule, "
-                f"batch 1 per GPU, 19 double + 38 single blocks" + (f", TeaCache ({skipped}/{args.steps} steps skipped)" if cache else ""))
+        skipped = sum(1 for t in cache.trace[-(args.steps * (2 if args.model == "qwen" else 1)):] if not t[3])
+    if args.model == "flux":
+        workload = (f"FLUX.1-dev {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step flow-match schedule, "
+                    f"batch 1 per GPU, 19 double + 38 single blocks" + (f", TeaCache ({skipped}/{args.steps} steps skipped)" if cache else ""))
+    else:
+        nfw = 2 * args.steps
+        workload = (f"Qwen-Image {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step schedule, true CFG "
+                    f"(2 forwards per step), batch 1 per GPU, 60 double-stream blocks"
+                    + (f", TeaCache ({skipped}/{nfw} forwards skipped)" if cache else ""))
     out = {
-        "metric": "denoise it/s (sec/image = 25 / (value / n_gpus)), FLUX 1024x2048 fp8 @25 steps",
+        "metric": ("denoise it/s (sec/image = 25 / (value / n_gpus)), FLUX 1024x2048 fp8 @25 steps" if args.model == "flux" else
+                   "denoise it/s (sec/image = 25 / (value / n_gpus)), Qwen-Image 1328x1328 int8 @25 steps, true CFG"),
         "value": world * args.steps / elapsed,
         "unit": "it/s",
         "n_gpus": world,
@@ -191,7 +212,7 @@ def main():
             kernels[name] = {"launches_per_step": s["launches"] / args.steps, "avg_ms": s["avg_ms"], "ms_per_step": s["total_ms"] / args.steps,
                              "achieved_TFLOPs": tf, "peak_TFLOPs": PEAK_TFLOPS[dt], "frac": tf / PEAK_TFLOPS[dt]}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        default_workload = (args.height, args.width, args.max_seq_len, args.quant, args.cache_config) == (1024, 2048, 512, "fp8", None)
+        default_workload = (args.model, args.height, args.width, args.max_seq_len, args.quant, args.cache_config) == ("flux", 1024, 2048, 512, "fp8", None)
         out["roofline"] = {"kernel": HIP_KERNEL.get(dom, dom), "span": dom, "bound": "mfma", "achieved": kernels[dom]["achieved_TFLOPs"],
                            "peak": kernels[dom]["peak_TFLOPs"], "unit": "TFLOP/s", "frac": kernels[dom]["frac"],
                            "traffic": pmc_traffic(HIP_KERNEL.get(dom, dom)) if default_workload else None,
@@ -200,7 +221,7 @@ def main():
         flops_step = sum(s["work"] for s in summ.values()) / args.steps
         out["step_TFLOP"] = flops_step / 1e12
         out["step_achieved_TFLOPs"] = flops_step / (ms_per_step * 1e-3) / 1e12
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.model == "flux":
         try:
             out["cpu_baseline"] = cpu_baseline_leg(args.height, args.width, args.max_seq_len, args.quant)
         except Exception as e:  # noqa: BLE001  -- the baseline leg must never take the GPU number down with it

@@ -32,7 +32,8 @@ if __name__ == "__main__":
     def run():
         return engine.generate(prompt=args.prompts, negative_prompt=args.negative_prompts, steps=args.steps,
                                guidance_scale=args.guidance_scale, gen_seed=args.seed, gen_width=args.width,
-                               gen_height=args.height, max_seq_len=args.max_seq_len)
+                               gen_height=args.height, max_seq_len=args.max_seq_len,
+                               true_cfg_scale=args.true_cfg_scale if args.architecture == "qwen" else None)
 
     for i in range(args.num_warmup_runs):
         print(f"warmup {i + 1}/{args.num_warmup_runs}")

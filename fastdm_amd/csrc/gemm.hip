@@ -588,6 +588,32 @@ int fdm_gemm_w8a8_int8(void* out, const void* a, const void* b, const float* sca
   return launch_gemm<DT_INT8>(g, to_stream(stream));
 }
 
+int fdm_gemm_w8a8_int8_x2(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_desc* d1, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (!d0 || !d1) return FDM_ERR_INVALID;
+  const fdm_gemm_int8_desc* ds[2] = {d0, d1};
+  GemmGroup g;
+  int n = 0;
+  for (int i = 0; i < 2; ++i) {
+    const fdm_gemm_int8_desc* d = ds[i];
+    if (d->M == 0 && d->N > 0 && d->K > 0) continue;
+    int rc = fill_problem(g.p[n], d->out, d->a, d->b, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, 1, (int)d->epilogue, d->epi_gate,
+                          d->epi_gate_stride, d->epi_res, d->epi_rows_per_batch);
+    if (rc != FDM_OK) return rc;
+    if (!d->scale_a || !d->scale_b || ((d->azp == nullptr) != (d->azp_adj == nullptr))) return FDM_ERR_INVALID;
+    if (d->azp_adj && (reinterpret_cast<uintptr_t>(d->azp_adj) & 15)) return FDM_ERR_INVALID;
+    g.p[n].sa = d->scale_a;
+    g.p[n].sb = d->scale_b;
+    g.p[n].bias = (const bf16_t*)d->bias;
+    g.p[n].azp = d->azp;
+    g.p[n].azp_adj = d->azp_adj;
+    ++n;
+  }
+  if (n == 0) return FDM_OK;
+  finish_group(g, n);
+  return launch_gemm<DT_INT8>(g, to_stream(stream));
+}
+
 int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
                   int64_t ldb, int64_t ldc, int epilogue, const void* epi_gate, int64_t epi_gate_stride, const void* epi_res,
                   int64_t epi_rows_per_batch, fdm_stream_t stream) {

@@ -104,7 +104,12 @@ class QLinear:
         M = a.shape[0]
         if out is None:
             out = torch.empty((M, Nn), device=a.device, dtype=self.dtype)
-        d = N.GemmFp8Desc()
+        if self.quant_type == torch.int8:
+            d = N.GemmInt8Desc()
+            d.azp_adj = N.ptr(self.weight_asym_sumcol) if x.azp is not None else None
+            d.azp = N.ptr(x.azp)
+        else:
+            d = N.GemmFp8Desc()
         d.out, d.a, d.b = N.ptr(out), N.ptr(a), N.ptr(wt)
         d.scale_a, d.scale_b, d.bias = N.ptr(x.scale), N.ptr(self.weight_quant_scale), N.ptr(self.bias)
         d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, Nn, K, a.stride(0), wt.stride(1), out.stride(0)
@@ -124,6 +129,13 @@ class QLinear:
             d1, o1, f1 = lin1._desc(x1, epilogue, gate1, res1, rpb1, out1)
             with span("gemm_w8a8_fp8_res" if epilogue == N.EPI_GATE_RESIDUAL else "gemm_w8a8_fp8", f0 + f1):
                 N.check(N.lib().fdm_gemm_w8a8_fp8_x2(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "fp8 linear pair")
+            return o0, o1
+        if lin0.quant_type == torch.int8 and lin1.quant_type == torch.int8:
+            import ctypes
+            d0, o0, f0 = lin0._desc(x0, epilogue, gate0, res0, rpb0, out0)
+            d1, o1, f1 = lin1._desc(x1, epilogue, gate1, res1, rpb1, out1)
+            with span("gemm_w8a8_int8_res" if epilogue == N.EPI_GATE_RESIDUAL else "gemm_w8a8_int8", f0 + f1):
+                N.check(N.lib().fdm_gemm_w8a8_int8_x2(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "int8 linear pair")
             return o0, o1
         return (lin0.forward_q(x0, epilogue, gate0, res0, rpb0, out0), lin1.forward_q(x1, epilogue, gate1, res1, rpb1, out1))
 

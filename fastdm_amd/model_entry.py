@@ -150,7 +150,7 @@ class FastDMEngine:
     def __init__(self, model_path, architecture="flux", device=0, data_type="bfloat16", use_fp8=False, use_int8=False,
                  kernel_backend="hip", cache_config=None, oom_resolve=False, use_diffusers=True, task="t2i",
                  sparse_attn_config=None, synthetic_seed=0, **model_kwargs):
-        if architecture != "flux":
+        if architecture not in ("flux", "qwen"):
             raise NotImplementedError(f"architecture '{architecture}' is not built yet (SURVEY.md §8f)")
         if data_type != "bfloat16":
             raise NotImplementedError("bfloat16 activations only in this build")
@@ -173,9 +173,21 @@ class FastDMEngine:
             if self.cache:
                 self.cache.config.current_steps_callback = lambda: self.pipe.scheduler.step_index
                 self.cache.config.total_steps_callback = lambda: self.pipe.scheduler.timesteps.shape[0]
-            self.pipe.transformer = create_model("flux", ckpt_path=self.pipe.transformer.state_dict(), dtype=self.dtype,
+            self.pipe.transformer = create_model(architecture, ckpt_path=self.pipe.transformer.state_dict(), dtype=self.dtype,
                                                  quant_type=self.quant_type, kernel_backend=kernel_backend, cache=self.cache).eval()
             self.pipe.to("cuda")
+        elif architecture == "qwen":
+            from fastdm_amd.pipeline import SyntheticQwenPipeline
+            from fastdm_amd.synthetic import SyntheticQwenStateDict
+            keys = ("patch_size", "num_layers", "attention_head_dim", "num_attention_heads", "joint_attention_dim", "in_channels", "out_channels")
+            sd = SyntheticQwenStateDict(seed=synthetic_seed, **{k: v for k, v in model_kwargs.items() if k in keys})
+            model_kwargs.setdefault("out_channels", 16)      # the checkpoint's value (proj_out = patch^2 * 16 = 64 = in_channels)
+            transformer = create_model("qwen", ckpt_path=sd, dtype=self.dtype, quant_type=self.quant_type, kernel_backend=kernel_backend,
+                                       cache=self.cache, **model_kwargs).eval()
+            self.pipe = SyntheticQwenPipeline(transformer, seed=synthetic_seed)
+            if self.cache:
+                self.cache.config.current_steps_callback = lambda: self.pipe.scheduler_step_index
+                self.cache.config.total_steps_callback = lambda: self.pipe.num_steps
         else:
             from fastdm_amd.pipeline import SyntheticFluxPipeline
             from fastdm_amd.synthetic import SyntheticFluxStateDict
@@ -191,12 +203,17 @@ class FastDMEngine:
 
     def generate(self, prompt=None, negative_prompt=None, src_image=None, num_frames=None, steps=50, guidance_scale=3.5,
                  true_cfg_scale=None, gen_seed=42, gen_width=512, gen_height=512, max_seq_len=512):
-        from fastdm_amd.pipeline import SyntheticFluxPipeline
+        from fastdm_amd.pipeline import SyntheticFluxPipeline, SyntheticQwenPipeline
+        if isinstance(self.pipe, SyntheticQwenPipeline):
+            return self.pipe(num_inference_steps=steps, true_cfg_scale=true_cfg_scale, width=gen_width, height=gen_height,
+                             max_sequence_length=max_seq_len, seed=gen_seed)
         if isinstance(self.pipe, SyntheticFluxPipeline):
             return self.pipe(num_inference_steps=steps, guidance_scale=guidance_scale, width=gen_width, height=gen_height,
                              max_sequence_length=max_seq_len, seed=gen_seed)
         gen = torch.Generator().manual_seed(gen_seed)
         kwargs = {"prompt": prompt, "negative_prompt": negative_prompt, "num_inference_steps": steps, "generator": gen,
                   "max_sequence_length": max_seq_len, "width": gen_width, "height": gen_height, "guidance_scale": guidance_scale}
+        if true_cfg_scale is not None and self.architecture == "qwen":
+            kwargs["true_cfg_scale"] = true_cfg_scale
         with torch.inference_mode():
             return self.pipe(**kwargs).images[0]

@@ -71,3 +71,62 @@ class SyntheticFluxPipeline:
         lat = inp["hidden_states"].clone() if latents is None else latents
         sigmas = flow_match_sigmas(num_inference_steps, lat.shape[1])
         return self.denoise(lat, inp, sigmas, guidance_scale)
+
+
+class SyntheticQwenPipeline:
+    """What diffusers' QwenImagePipeline does around `pipe.transformer` with true CFG: per step a conditional and an
+    unconditional forward (`cache_context("cond")` / `("uncond")`), `comb = uncond + scale * (cond - uncond)` rescaled
+    to the conditional prediction's per-token norm, then the flow-match Euler update.  Latents are packed
+    [B, (H/16)*(W/16), 64]; `timestep = sigma`; prompt / negative-prompt embeddings are synthetic."""
+
+    def __init__(self, transformer, seed: int = 0):
+        self.transformer = transformer
+        self.seed = seed
+        self.scheduler_step_index = None
+        self.num_steps = 0
+        self._inputs_key, self._inputs = None, None
+
+    def prepare(self, batch, height, width, max_sequence_length, seed):
+        key = (batch, height, width, max_sequence_length, seed)
+        if key != self._inputs_key:
+            core = self.transformer.core_model
+            pos = synthetic.qwen_step_inputs(batch, height // 16, width // 16, max_sequence_length, self.transformer.config.in_channels,
+                                             core.txt_in.in_features, seed=seed)
+            neg = synthetic.qwen_step_inputs(batch, height // 16, width // 16, max_sequence_length, self.transformer.config.in_channels,
+                                             core.txt_in.in_features, seed=seed + 7919)
+            pos["negative_encoder_hidden_states"] = neg["encoder_hidden_states"]
+            self._inputs, self._inputs_key = pos, key
+        return self._inputs
+
+    def _forward(self, name, latents, t, enc, inp):
+        with self.transformer.cache_context(name):
+            return self.transformer(hidden_states=latents, timestep=t, guidance=None, encoder_hidden_states_mask=inp["encoder_hidden_states_mask"],
+                                    encoder_hidden_states=enc, img_shapes=inp["img_shapes"], txt_seq_lens=inp["txt_seq_lens"],
+                                    attention_kwargs=None, return_dict=False)[0]
+
+    @torch.no_grad()
+    def step(self, latents, inp, sigma, sigma_next, true_cfg_scale):
+        t = torch.full((latents.shape[0],), float(sigma), device=latents.device, dtype=latents.dtype)
+        cond = self._forward("cond", latents, t, inp["encoder_hidden_states"], inp)
+        if true_cfg_scale is not None and true_cfg_scale > 1:
+            uncond = self._forward("uncond", latents, t, inp["negative_encoder_hidden_states"], inp)
+            comb = uncond.float() + true_cfg_scale * (cond.float() - uncond.float())
+            cond_norm = torch.norm(cond.float(), dim=-1, keepdim=True)
+            comb = comb * (cond_norm / torch.norm(comb, dim=-1, keepdim=True))
+        else:
+            comb = cond.float()
+        return (latents.float() + float(sigma_next - sigma) * comb).to(latents.dtype)
+
+    @torch.no_grad()
+    def __call__(self, num_inference_steps=25, true_cfg_scale=4.0, width=1328, height=1328, max_sequence_length=128, batch=1, seed=None,
+                 latents=None, **_):
+        seed = self.seed if seed is None else seed
+        inp = self.prepare(batch, height, width, max_sequence_length, seed)
+        lat = inp["hidden_states"].clone() if latents is None else latents
+        sigmas = flow_match_sigmas(num_inference_steps, lat.shape[1], max_seq_len=8192, base_shift=0.5, max_shift=0.9)
+        self.num_steps = num_inference_steps
+        for i in range(num_inference_steps):
+            self.scheduler_step_index = i
+            lat = self.step(lat, inp, sigmas[i], sigmas[i + 1], true_cfg_scale)
+        self.scheduler_step_index = None
+        return lat

@@ -113,3 +113,67 @@ def flux_step_inputs(batch, img_h, img_w, n_txt=512, in_channels=64, joint_atten
         img_ids=ids,
         txt_ids=torch.zeros(n_txt, 3, device=device),
     )
+
+
+class SyntheticQwenStateDict(dict):
+    """Lazily generated diffusers-named Qwen-Image state_dict (same recipe and key hashing as oracle.qwen.synth_state_dict,
+    so the tensors are bit-identical to the oracle's)."""
+
+    def __init__(self, patch_size=2, in_channels=64, out_channels=16, num_layers=60, attention_head_dim=128, num_attention_heads=24,
+                 joint_attention_dim=3584, mlp_ratio=4.0, seed=0, device="cuda"):
+        super().__init__()
+        self.seed, self.device = seed, device
+        D, mlp, hd = attention_head_dim * num_attention_heads, int(attention_head_dim * num_attention_heads * mlp_ratio), attention_head_dim
+        spec = {}
+
+        def lin(name, k, n, kind="w"):
+            spec[f"{name}.weight"] = ((n, k), kind)
+            spec[f"{name}.bias"] = ((n,), "b")
+
+        lin("time_text_embed.timestep_embedder.linear_1", 256, D)
+        lin("time_text_embed.timestep_embedder.linear_2", D, D)
+        spec["txt_norm.weight"] = ((joint_attention_dim,), "rms")
+        lin("img_in", in_channels, D)
+        lin("txt_in", joint_attention_dim, D)
+        for i in range(num_layers):
+            p = f"transformer_blocks.{i}"
+            lin(f"{p}.img_mod.1", D, 6 * D, "w_mod")
+            lin(f"{p}.txt_mod.1", D, 6 * D, "w_mod")
+            for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out"):
+                lin(f"{p}.attn.{n}", D, D)
+            for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+                spec[f"{p}.attn.{n}.weight"] = ((hd,), "rms")
+            for ff in ("img_mlp", "txt_mlp"):
+                lin(f"{p}.{ff}.net.0.proj", D, mlp)
+                lin(f"{p}.{ff}.net.2", mlp, D)
+        lin("norm_out.linear", D, 2 * D, "w_mod")
+        lin("proj_out", D, patch_size * patch_size * out_channels)
+        self.spec = spec
+        for k in spec:
+            dict.__setitem__(self, k, None)
+
+    def _make(self, name):
+        shape, kind = self.spec[name]
+        key = "qwen." + name
+        if kind == "w":
+            return normal(key, shape, (1.0 / shape[1]) ** 0.5, 0.0, self.seed, self.device)
+        if kind in ("w_mod", "b"):
+            return normal(key, shape, 0.02, 0.0, self.seed, self.device)
+        return normal(key, shape, 0.1, 1.0, self.seed, self.device)
+
+    def __getitem__(self, name):
+        return self._make(name)
+
+    def get(self, name, default=None):
+        return self._make(name) if name in self.spec else default
+
+
+def qwen_step_inputs(batch, img_h, img_w, n_txt=128, in_channels=64, joint_attention_dim=3584, seed=0, device="cuda"):
+    """Same tensors as oracle.qwen.synth_inputs (bit-identical), created on the GPU (examples/profiling/qwenimg_profiling.py:31-37)."""
+    return dict(
+        hidden_states=uniform("qwen.input.latents", (batch, img_h * img_w, in_channels), seed, device),
+        encoder_hidden_states=uniform("qwen.input.prompt_embeds", (batch, n_txt, joint_attention_dim), seed, device),
+        encoder_hidden_states_mask=torch.ones(batch, n_txt, dtype=torch.int64, device=device),
+        img_shapes=[[(1, img_h, img_w)]] * batch,
+        txt_seq_lens=[n_txt] * batch,
+    )

@@ -113,6 +113,25 @@ int fdm_gemm_w8a8_int8(void* out, const void* a, const void* b, const float* sca
                        int epilogue, const void* epi_gate, int64_t epi_gate_stride,
                        const void* epi_res, int64_t epi_rows_per_batch, fdm_stream_t stream);
 
+/* Two independent int8 problems in one launch (as fdm_gemm_w8a8_fp8_x2).  Fields as in fdm_gemm_w8a8_int8.   */
+typedef struct fdm_gemm_int8_desc {
+  void* out;
+  const void* a;
+  const void* b;
+  const float* scale_a;
+  const float* scale_b;
+  const int32_t* azp_adj;
+  const int32_t* azp;
+  const void* bias;
+  int64_t M, N, K, lda, ldb, ldc;
+  int64_t epilogue;
+  const void* epi_gate;
+  int64_t epi_gate_stride;
+  const void* epi_res;
+  int64_t epi_rows_per_batch;
+} fdm_gemm_int8_desc;
+int fdm_gemm_w8a8_int8_x2(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_desc* d1, fdm_stream_t stream);
+
 /* ---- bf16 GEMM (QLinear's un-quantised branch: torch.addmm, layer/qlinear.py:76) --------------
  * out[M,N] = bf16(acc_f32(A[M,K] bf16 row-major x B[K,N] bf16 column-major) + bias[N])          */
 int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias,

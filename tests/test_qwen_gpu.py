@@ -115,3 +115,33 @@ def test_qwen_teacache_negative_cache_matches_reference_trace():
     assert keys == ["positive", "negative"] * 10
     assert decisions == g["tc_should_calc"].tolist(), (decisions, cache.trace)
     close(lat, g["tc_final"], 1e-1, 1.5e-2, "qwen teacache final latents")
+
+
+def test_engine_qwen_synthetic_pipeline_true_cfg():
+    """FastDMEngine(architecture='qwen') without a checkpoint: synthetic weights, cond + uncond forward per step."""
+    from fastdm_amd.model_entry import FastDMEngine
+    cfg = OQ.TINY
+    eng = FastDMEngine("", architecture="qwen", use_int8=True, kernel_backend="hip", in_channels=cfg.in_channels, out_channels=cfg.out_channels,
+                       num_layers=cfg.num_layers, attention_head_dim=cfg.attention_head_dim, num_attention_heads=cfg.num_attention_heads,
+                       joint_attention_dim=cfg.joint_attention_dim, axes_dims_rope=cfg.axes_dims_rope)
+    lat = eng.generate(steps=3, true_cfg_scale=4.0, gen_seed=5, gen_width=64, gen_height=96, max_seq_len=7)
+    assert lat.shape == (1, 24, cfg.in_channels) and torch.isfinite(lat.float()).all()
+    # the same loop on the oracle core (weights are bit-identical: same generator, same keys)
+    from fastdm_amd.pipeline import flow_match_sigmas
+    sd = OQ.synth_state_dict(cfg, seed=0)
+    core = OQ.QwenCore(sd, cfg, torch.int8)
+    pos = OQ.synth_inputs(cfg, 1, 6, 4, 7, seed=5)
+    neg = OQ.synth_inputs(cfg, 1, 6, 4, 7, seed=5 + 7919)["encoder_hidden_states"]
+    x = pos["hidden_states"].clone()
+    sig = flow_match_sigmas(3, 24, max_seq_len=8192, max_shift=0.9)
+    with torch.no_grad():
+        for i in range(3):
+            t = torch.full((1,), float(sig[i])).to(BF16)
+            c = core.forward(hidden_states=x, encoder_hidden_states=pos["encoder_hidden_states"], timestep=t, img_shapes=pos["img_shapes"],
+                             txt_seq_lens=pos["txt_seq_lens"])[0].float()
+            u = core.forward(hidden_states=x, encoder_hidden_states=neg, timestep=t, img_shapes=pos["img_shapes"],
+                             txt_seq_lens=pos["txt_seq_lens"])[0].float()
+            comb = u + 4.0 * (c - u)
+            comb = comb * (torch.norm(c, dim=-1, keepdim=True) / torch.norm(comb, dim=-1, keepdim=True))
+            x = (x.float() + float(sig[i + 1] - sig[i]) * comb).to(BF16)
+    close(lat, x, 0.15, 2.5e-2, "3-step synthetic Qwen pipeline latents")
