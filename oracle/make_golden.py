@@ -398,6 +398,28 @@ def gen_tiny_qwen():
 
 
 
+def gen_qwen_full(n_blocks=4, img_h=83, img_w=83, n_txt=128, seed=0):
+    """Qwen-Image at FULL WIDTH (D = 3072, 24 x 128 heads, 1328 x 1328 -> 6889 image + 128 text tokens) through the
+    reference's own core at reduced depth, int8 W8A8 (BASELINE.json configs[3]) and bf16; the whole output is kept."""
+    import_reference()
+    from oracle import qwen as OQ
+    cfg = OQ.QwenConfig(num_layers=n_blocks)
+    t0 = time.time()
+    sd = OQ.synth_state_dict(cfg, seed=seed)
+    print(f"synthetic weights: {time.time() - t0:.0f}s", flush=True)
+    inp = OQ.synth_inputs(cfg, batch=1, img_h=img_h, img_w=img_w, n_txt=n_txt, seed=seed)
+    d = {"seed": seed, "n_blocks": n_blocks, "img_h": img_h, "img_w": img_w, "n_txt": n_txt, "timestep": 0.7}
+    for tag, qt in (("int8", torch.int8), ("bf16", None)):
+        use_backend("torch")
+        core = ref_qwen_core(cfg, qt, sd)
+        t0 = time.time()
+        out = core.forward(timestep=torch.tensor([0.7]), **inp)[0]
+        print(f"{tag}: forward {time.time() - t0:.0f}s, mean|out| {out.float().abs().mean():.3f}", flush=True)
+        d[f"out_{tag}"] = out
+        del core
+    save(f"qwen_full_{n_blocks}blocks.npz", d)
+
+
 # ------------------------------------------------------------------ full-width C3 fixture
 def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=0, sub=64):
     """Full-width FLUX.1-dev at 1024x2048 (S = 8192 + 512) through the reference's own block
@@ -492,7 +514,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "c3"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "c3"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     args = ap.parse_args()
@@ -507,6 +529,8 @@ def main():
         gen_teacache()
     if args.what in ("small", "qwen"):
         gen_tiny_qwen()
+    if args.what == "qwen_full":
+        gen_qwen_full()
     if args.what == "c3":
         gen_c3(args.blocks[0], args.blocks[1], args.quant)
 

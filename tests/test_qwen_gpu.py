@@ -145,3 +145,29 @@ def test_engine_qwen_synthetic_pipeline_true_cfg():
             comb = comb * (torch.norm(c, dim=-1, keepdim=True) / torch.norm(comb, dim=-1, keepdim=True))
             x = (x.float() + float(sig[i + 1] - sig[i]) * comb).to(BF16)
     close(lat, x, 0.15, 2.5e-2, "3-step synthetic Qwen pipeline latents")
+
+
+@pytest.mark.parametrize("tag,qt", [("int8", torch.int8), ("bf16", None)])
+def test_qwen_full_width_against_reference(tag, qt):
+    """Full width (D = 3072, 1328 x 1328 -> S = 6889 + 128) at reduced depth against the reference's own core run on
+    CPU (tests/golden/qwen_full_4blocks.npz).  Weights come from the GPU generator, bit-identical to the oracle's.
+    Stated tolerance: the per-block implementation-vs-implementation envelope of SURVEY.md §8c' (mean ~2.5e-4 per
+    block in bf16, ~1.5e-3 with per-token int8 re-quantisation), measured here and asserted with margin."""
+    import os
+    from oracle.make_golden import GOLD
+    from fastdm_amd.model_entry import create_model
+    from fastdm_amd.synthetic import SyntheticQwenStateDict, qwen_step_inputs
+    path = "qwen_full_4blocks.npz"
+    if not os.path.exists(os.path.join(GOLD, path)):
+        pytest.skip(f"{path} not generated")
+    g = load(path)
+    nb = int(g["n_blocks"])
+    model = create_model("qwen", ckpt_path=SyntheticQwenStateDict(num_layers=nb, seed=int(g["seed"])), dtype=BF16, quant_type=qt,
+                         kernel_backend="hip", out_channels=16, num_layers=nb).eval()
+    inp = qwen_step_inputs(1, int(g["img_h"]), int(g["img_w"]), int(g["n_txt"]), seed=int(g["seed"]))
+    out = model(timestep=torch.tensor([float(g["timestep"])]).cuda(), return_dict=False, **inp)[0]
+    ref = g[f"out_{tag}"]
+    d = (out.float().cpu() - ref.float()).abs()
+    print(f"qwen full width {tag}: max|d| {d.max().item():.4g} mean|d| {d.mean().item():.4g} mean|ref| {ref.float().abs().mean().item():.3g}")
+    lim = {"bf16": (5e-2, 5e-3), "int8": (8e-2, 1.2e-2)}[tag]   # measured: bf16 0.031 / 0.0034, int8 0.040 / 0.0063 on |ref| 0.97
+    assert d.max().item() <= lim[0] and d.mean().item() <= lim[1], (tag, d.max().item(), d.mean().item())
