@@ -33,6 +33,7 @@ SIGNATURES = {
     "fdm_attn_fwd": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I32, I32, P, I64, P]),
     "fdm_attn_fwd_workspace_bytes": (I64, [I32]),
     "fdm_ln_modulate": (I32, [P, P, P, P, I32, P, P, P, I64, P, P, P, I64, I32, I64, F32, P]),
+    "fdm_ln_modulate_f32": (I32, [P, P, P, P, I32, P, P, P, I64, I64, I32, I64, F32, P]),
     "fdm_gate_residual": (I32, [P, P, P, P, I64, I64, I32, I64, P]),
     "fdm_gelu": (I32, [P, P, I64, I32, P]),
     "fdm_quant_rowwise_cat2": (I32, [P, P, P, I32, P, I32, I64, P, I32, I64, I64, P]),
@@ -42,7 +43,7 @@ SIGNATURES = {
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
 }
 
-EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL = 0, 1, 2, 3
+EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL, EPI_GATE_RESIDUAL_F32 = 0, 1, 2, 3, 4
 
 
 class GemmFp8Desc(C.Structure):

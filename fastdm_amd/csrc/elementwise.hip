@@ -353,6 +353,58 @@ __global__ void __launch_bounds__(THREADS) ln_modulate_kernel(
   }
 }
 
+// fp32 modulation (Wan): y = bf16(((x - mean) * rstd) * (1 + scale_f32) + shift_f32), one rounding.
+template <int THREADS, int QMODE, bool SW>
+__global__ void __launch_bounds__(THREADS) ln_modulate_f32_kernel(
+    bf16_t* __restrict__ out_bf16, uint8_t* __restrict__ out_q, float* __restrict__ out_scale, int32_t* __restrict__ out_azp,
+    const bf16_t* __restrict__ xin, const float* __restrict__ scale, const float* __restrict__ shift, int64_t mod_bstride,
+    int hidden, int64_t rows_per_batch, float eps) {
+  __shared__ float smem[THREADS / 64 + 1];
+  const int64_t row = blockIdx.x;
+  const int64_t b = row / rows_per_batch;
+  const int nvec = hidden >> 3;
+  Vec8 x[MAXV];
+  load_row<THREADS>(x, xin + row * hidden, nvec);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if ((int)threadIdx.x + i * THREADS < nvec)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += x[i].v[j];
+  const float mean = block_reduce<THREADS>(s, OpSum(), smem) / (float)hidden;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if ((int)threadIdx.x + i * THREADS < nvec)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float d = x[i].v[j] - mean;
+        ss += d * d;
+      }
+  const float var = block_reduce<THREADS>(ss, OpSum(), smem) / (float)hidden;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int v = threadIdx.x + i * THREADS;
+    if (v < nvec) {
+      const float* sc = scale + b * mod_bstride + (size_t)v * 8;
+      const float* sh = shift + b * mod_bstride + (size_t)v * 8;
+      const f32x4 sc0 = *reinterpret_cast<const f32x4*>(sc), sc1 = *reinterpret_cast<const f32x4*>(sc + 4);
+      const f32x4 sh0 = *reinterpret_cast<const f32x4*>(sh), sh1 = *reinterpret_cast<const f32x4*>(sh + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float n = (x[i].v[j] - mean) * rstd;
+        const float scj = j < 4 ? sc0[j & 3] : sc1[j & 3], shj = j < 4 ? sh0[j & 3] : sh1[j & 3];
+        x[i].v[j] = rbf(n * (1.0f + scj) + shj);
+      }
+      if (out_bf16 != nullptr) store8(out_bf16 + row * hidden + (size_t)v * 8, x[i]);
+    }
+  }
+  if constexpr (QMODE != 0) {
+    quant_row_cached<THREADS, QMODE, SW>(x, nvec, out_q + row * (int64_t)hidden, out_scale, out_azp, row, smem);
+  }
+}
+
 // ------------------------------------------------------------------------------------ simple element-wise
 __global__ void __launch_bounds__(256) gate_residual_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ res,
                                                             const bf16_t* __restrict__ y, const bf16_t* __restrict__ gate,
@@ -552,7 +604,43 @@ static int launch_ln(void* out_bf16, void* out_q, float* out_scale, int32_t* out
   return FDM_OK;
 }
 
+template <int THREADS>
+static int launch_ln_f32(void* out_bf16, void* out_q, float* out_scale, int32_t* out_azp, int qm, const void* x, const float* scale,
+                         const float* shift, int64_t mbs, int64_t rows, int hidden, int64_t rpb, float eps, hipStream_t s) {
+  const bool sw = g_fp8_sw_cvt;
+#define FDM_LNF(QM, SWV)                                                                                        \
+  ln_modulate_f32_kernel<THREADS, QM, SWV><<<(unsigned)rows, THREADS, 0, s>>>(                                   \
+      (bf16_t*)out_bf16, (uint8_t*)out_q, out_scale, out_azp, (const bf16_t*)x, scale, shift, mbs, hidden, rpb, eps)
+  if (qm == 0) FDM_LNF(0, false);
+  else if (qm == 1) { if (sw) FDM_LNF(1, true); else FDM_LNF(1, false); }
+  else if (qm == 2) FDM_LNF(2, false);
+  else return FDM_ERR_UNSUPPORTED;
+#undef FDM_LNF
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
 extern "C" {
+
+int fdm_ln_modulate_f32(void* out_bf16, void* out_q, float* out_scale, int32_t* out_azp, int quant_mode, const void* x,
+                        const float* scale, const float* shift, int64_t mod_batch_stride, int64_t rows, int hidden,
+                        int64_t rows_per_batch, float eps, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (!x || !scale || !shift || rows < 0 || hidden <= 0 || (hidden & 7) || rows_per_batch <= 0 || (mod_batch_stride & 3))
+    return FDM_ERR_INVALID;
+  if (quant_mode != 0 && (!out_q || !out_scale)) return FDM_ERR_INVALID;
+  if (quant_mode == 2 && !out_azp) return FDM_ERR_INVALID;
+  if (!aligned16(x) || !aligned16(scale) || !aligned16(shift) || !aligned16(out_bf16) || (reinterpret_cast<uintptr_t>(out_q) & 7))
+    return FDM_ERR_INVALID;
+  if (hidden > MAXV * 256 * 8) return FDM_ERR_UNSUPPORTED;
+  if (rows == 0) return FDM_OK;
+  hipStream_t s = to_stream(stream);
+  if (hidden <= 4096)
+    return launch_ln_f32<64>(out_bf16, out_q, out_scale, out_azp, quant_mode, x, scale, shift, mod_batch_stride, rows, hidden,
+                             rows_per_batch, eps, s);
+  return launch_ln_f32<256>(out_bf16, out_q, out_scale, out_azp, quant_mode, x, scale, shift, mod_batch_stride, rows, hidden,
+                            rows_per_batch, eps, s);
+}
 
 int fdm_rms_norm(void* out, const void* in, const void* weight, float eps, int64_t rows, int hidden, fdm_stream_t stream) {
   (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours

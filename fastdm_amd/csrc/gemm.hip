@@ -64,7 +64,8 @@ struct GemmProblem {
   int64_t lda, ldb;  // bytes
   int64_t ldc;       // elements
   int tiles_m, tiles_n;
-  int epi;           // FDM_EPI_* (uniform per problem)
+  int epi;           // FDM_EPI_* (uniform per problem); FDM_EPI_GATE_RESIDUAL_F32 is stored as GATE_RESIDUAL + gate_f32
+  int gate_f32;      // the gate vector is fp32 and the epilogue rounds once
 };
 
 struct GemmGroup {
@@ -386,15 +387,21 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
       const int m = m0 + wm * 128 + it * 8 + rsub;
       if (n_ok && (full || m < p.M) && !(grp.debug & 4)) *reinterpret_cast<i32x4*>(p.C + (int64_t)m * p.ldc + ncc) = v;
     };
-    auto combine = [&](const i32x4& yv, const i32x4& gv, const i32x4& rv) -> i32x4 {
+    // out = res + gate * y.  bf16 gates (FLUX / Qwen-Image): the product is rounded to bf16 before the add, as the
+    // reference's two bf16 ops do; fp32 gates (Wan: `(x.float() + y * gate).type_as(x)`, wan.py:102,113): one rounding.
+    auto combine = [&](auto f32_c, const i32x4& yv, const float (&g8)[8], const i32x4& rv) -> i32x4 {
+      constexpr bool F32 = decltype(f32_c)::value;
       i32x4 o;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        const uint32_t yw = (uint32_t)yv[w], gw = (uint32_t)gv[w], rw = (uint32_t)rv[w];
-        const float lo = __builtin_bit_cast(float, rw << 16) + rbf(__builtin_bit_cast(float, gw << 16) * __builtin_bit_cast(float, yw << 16));
-        const float hi = __builtin_bit_cast(float, rw & 0xffff0000u) +
-                         rbf(__builtin_bit_cast(float, gw & 0xffff0000u) * __builtin_bit_cast(float, yw & 0xffff0000u));
-        o[w] = (int)pack2bf(lo, hi);
+        const uint32_t yw = (uint32_t)yv[w], rw = (uint32_t)rv[w];
+        float plo = g8[2 * w] * __builtin_bit_cast(float, yw << 16);
+        float phi = g8[2 * w + 1] * __builtin_bit_cast(float, yw & 0xffff0000u);
+        if constexpr (!F32) {
+          plo = rbf(plo);
+          phi = rbf(phi);
+        }
+        o[w] = (int)pack2bf(__builtin_bit_cast(float, rw << 16) + plo, __builtin_bit_cast(float, rw & 0xffff0000u) + phi);
       }
       return o;
     };
@@ -405,14 +412,33 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
         const int mc = min(m0 + wm * 128 + it * 8 + rsub, p.M - 1);
         return *reinterpret_cast<const i32x4*>(p.res + (int64_t)mc * p.ldc + ncc);
       };
-      if (one_batch) {
+      auto load_gate = [&](int64_t batch, float (&g8)[8]) {
+        if (p.gate_f32) {
+          const float* gp = reinterpret_cast<const float*>(p.gate) + batch * p.gate_stride + ncc;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(gp), c = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            g8[i] = a[i];
+            g8[4 + i] = c[i];
+          }
+        } else {
+          const i32x4 gv = *reinterpret_cast<const i32x4*>(p.gate + batch * p.gate_stride + ncc);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            g8[2 * w] = __builtin_bit_cast(float, (uint32_t)gv[w] << 16);
+            g8[2 * w + 1] = __builtin_bit_cast(float, (uint32_t)gv[w] & 0xffff0000u);
+          }
+        }
+      };
+      auto pipelined = [&](auto f32_c) {
         // loads(h0) | combine(h0) | loads(h1) | stores(h0) | combine(h1) | stores(h1): every load precedes every store
-        const i32x4 gv = *reinterpret_cast<const i32x4*>(p.gate + (m_first / p.rows_per_batch) * p.gate_stride + ncc);
+        float g8[8];
+        load_gate(m_first / p.rows_per_batch, g8);
         i32x4 r0[8], o0[8], r1[8], o1[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) r0[it] = res_row(it);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) o0[it] = combine(lds_row(it), gv, r0[it]);
+        for (int it = 0; it < 8; ++it) o0[it] = combine(f32_c, lds_row(it), g8, r0[it]);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -422,15 +448,21 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
 #pragma unroll
         for (int it = 0; it < 8; ++it) store_row(it, o0[it]);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) o1[it] = combine(lds_row(8 + it), gv, r1[it]);
+        for (int it = 0; it < 8; ++it) o1[it] = combine(f32_c, lds_row(8 + it), g8, r1[it]);
 #pragma unroll
         for (int it = 0; it < 8; ++it) store_row(8 + it, o1[it]);
+      };
+      if (one_batch) {
+        if (p.gate_f32) pipelined(std::true_type{});
+        else pipelined(std::false_type{});
       } else {
         // the wave's 128 rows straddle a batch boundary (rare): per-row gate vector, unpipelined
         for (int it = 0; it < 16; ++it) {
           const int mc = min(m0 + wm * 128 + it * 8 + rsub, p.M - 1);
-          const i32x4 gv = *reinterpret_cast<const i32x4*>(p.gate + (mc / p.rows_per_batch) * p.gate_stride + ncc);
-          store_row(it, combine(lds_row(it), gv, res_row(it)));
+          float g8[8];
+          load_gate(mc / p.rows_per_batch, g8);
+          const i32x4 rr = res_row(it);
+          store_row(it, p.gate_f32 ? combine(std::true_type{}, lds_row(it), g8, rr) : combine(std::false_type{}, lds_row(it), g8, rr));
         }
       }
     } else {
@@ -482,13 +514,15 @@ static int fill_problem(GemmProblem& p, void* out, const void* a, const void* b,
                         int64_t rpb) {
   if (!out || !a || !b || M <= 0 || N <= 0 || K <= 0) return FDM_ERR_INVALID;
   if (M > 0x7fffffff || N > 0x7fffffff) return FDM_ERR_UNSUPPORTED;
-  if (epi < FDM_EPI_NONE || epi > FDM_EPI_GATE_RESIDUAL) return FDM_ERR_UNSUPPORTED;
+  if (epi < FDM_EPI_NONE || epi > FDM_EPI_GATE_RESIDUAL_F32) return FDM_ERR_UNSUPPORTED;
+  const int gate_f32 = epi == FDM_EPI_GATE_RESIDUAL_F32;
+  if (gate_f32) epi = FDM_EPI_GATE_RESIDUAL;
   if ((K * elem_bytes) % 16 || (lda * elem_bytes) % 16 || (ldb * elem_bytes) % 16 || lda < K || ldb < K || ldc < N)
     return FDM_ERR_INVALID;
   if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(b) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) || (ldc & 7) || (N & 7))
     return FDM_ERR_INVALID;
   if (epi == FDM_EPI_GATE_RESIDUAL && (!gate || !res || rpb <= 0 || (reinterpret_cast<uintptr_t>(gate) & 15) ||
-                                       (reinterpret_cast<uintptr_t>(res) & 15) || (gate_stride & 7)))
+                                       (reinterpret_cast<uintptr_t>(res) & 15) || (gate_stride & (gate_f32 ? 3 : 7))))
     return FDM_ERR_INVALID;
   p.A = (const uint8_t*)a;
   p.B = (const uint8_t*)b;
@@ -506,6 +540,7 @@ static int fill_problem(GemmProblem& p, void* out, const void* a, const void* b,
   p.tiles_m = (int)((M + BM - 1) / BM);
   p.tiles_n = (int)((N + BN - 1) / BN);
   p.epi = epi;
+  p.gate_f32 = gate_f32;
   p.sa = p.sb = nullptr;
   p.bias = nullptr;
   p.azp = p.azp_adj = nullptr;

@@ -52,6 +52,24 @@ def ln_modulate(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, rows_
     return out, qz, x_new
 
 
+def ln_modulate_f32(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, rows_per_batch: int, quant=None,
+                    want_bf16: bool = False, eps: float = 1e-6) -> Tuple[Optional[torch.Tensor], Optional[Quantized]]:
+    """Wan's fp32 modulation: y = bf16(LN_f32(x) * (1 + scale) + shift), scale/shift fp32 [B, width] (or [1, width]
+    broadcast over the batch: an affine FP32LayerNorm with scale = weight - 1, shift = bias), one rounding."""
+    rows, width = x.shape
+    assert x.is_contiguous() and scale.dtype == torch.float32 and shift.dtype == torch.float32
+    assert scale.stride(-1) == 1 and shift.stride(-1) == 1 and scale.shape == shift.shape
+    bstride = 0 if scale.shape[0] == 1 else scale.stride(0)
+    assert bstride == (0 if shift.shape[0] == 1 else shift.stride(0))
+    out = torch.empty_like(x) if (want_bf16 or quant is None) else None
+    qz = _alloc_q(rows, width, quant, x.device) if quant is not None else None
+    N.check(N.lib().fdm_ln_modulate_f32(N.ptr(out), N.ptr(qz.q) if qz else None, N.ptr(qz.scale) if qz else None,
+                                        N.ptr(qz.azp) if (qz and qz.azp is not None) else None, QUANT_MODE[quant], N.ptr(x),
+                                        N.ptr(scale), N.ptr(shift), bstride, rows, width, rows_per_batch, eps, N.stream()),
+            "ln_modulate_f32")
+    return out, qz
+
+
 def gate_residual(res: torch.Tensor, y: torch.Tensor, gate: torch.Tensor, rows_per_batch: int) -> torch.Tensor:
     """res + gate[b]*y (model/flux.py:153-154)."""
     rows, width = res.shape

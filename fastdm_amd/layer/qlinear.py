@@ -79,19 +79,19 @@ class QLinear:
         lib = N.lib()
         flops = 2.0 * M * Nn * K
         if self.quant_type == FP8:
-          with span("gemm_w8a8_fp8_res" if epilogue == N.EPI_GATE_RESIDUAL else "gemm_w8a8_fp8", flops):
+          with span("gemm_w8a8_fp8_res" if epilogue >= N.EPI_GATE_RESIDUAL else "gemm_w8a8_fp8", flops):
             N.check(lib.fdm_gemm_w8a8_fp8(N.ptr(out), N.ptr(a), N.ptr(wt), N.ptr(x.scale), N.ptr(self.weight_quant_scale),
                                           N.ptr(self.bias), M, Nn, K, a.stride(0), wt.stride(1), out.stride(0), epilogue,
                                           g_ptr, g_stride, N.ptr(res), rows_per_batch, N.stream()), "fp8 linear")
         elif self.quant_type == torch.int8:
-          with span("gemm_w8a8_int8_res" if epilogue == N.EPI_GATE_RESIDUAL else "gemm_w8a8_int8", flops):
+          with span("gemm_w8a8_int8_res" if epilogue >= N.EPI_GATE_RESIDUAL else "gemm_w8a8_int8", flops):
             N.check(lib.fdm_gemm_w8a8_int8(N.ptr(out), N.ptr(a), N.ptr(wt), N.ptr(x.scale), N.ptr(self.weight_quant_scale),
                                            N.ptr(self.weight_asym_sumcol) if x.azp is not None else None, N.ptr(x.azp),
                                            N.ptr(self.bias), M, Nn, K, a.stride(0), wt.stride(1), out.stride(0), epilogue,
                                            g_ptr, g_stride, N.ptr(res), rows_per_batch, N.stream()), "int8 linear")
         else:
             assert a.dtype == self.dtype and a.stride(1) == 1
-            with span("gemm_bf16_res" if epilogue == N.EPI_GATE_RESIDUAL else "gemm_bf16", flops):
+            with span("gemm_bf16_res" if epilogue >= N.EPI_GATE_RESIDUAL else "gemm_bf16", flops):
               N.check(lib.fdm_gemm_bf16(N.ptr(out), N.ptr(a), N.ptr(wt), N.ptr(self.bias), M, Nn, K, a.stride(0), wt.stride(1),
                                       out.stride(0), epilogue, g_ptr, g_stride, N.ptr(res), rows_per_batch, N.stream()),
                     "bf16 linear")
@@ -127,14 +127,14 @@ class QLinear:
             import ctypes
             d0, o0, f0 = lin0._desc(x0, epilogue, gate0, res0, rpb0, out0)
             d1, o1, f1 = lin1._desc(x1, epilogue, gate1, res1, rpb1, out1)
-            with span("gemm_w8a8_fp8_res" if epilogue == N.EPI_GATE_RESIDUAL else "gemm_w8a8_fp8", f0 + f1):
+            with span("gemm_w8a8_fp8_res" if epilogue >= N.EPI_GATE_RESIDUAL else "gemm_w8a8_fp8", f0 + f1):
                 N.check(N.lib().fdm_gemm_w8a8_fp8_x2(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "fp8 linear pair")
             return o0, o1
         if lin0.quant_type == torch.int8 and lin1.quant_type == torch.int8:
             import ctypes
             d0, o0, f0 = lin0._desc(x0, epilogue, gate0, res0, rpb0, out0)
             d1, o1, f1 = lin1._desc(x1, epilogue, gate1, res1, rpb1, out1)
-            with span("gemm_w8a8_int8_res" if epilogue == N.EPI_GATE_RESIDUAL else "gemm_w8a8_int8", f0 + f1):
+            with span("gemm_w8a8_int8_res" if epilogue >= N.EPI_GATE_RESIDUAL else "gemm_w8a8_int8", f0 + f1):
                 N.check(N.lib().fdm_gemm_w8a8_int8_x2(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "int8 linear pair")
             return o0, o1
         return (lin0.forward_q(x0, epilogue, gate0, res0, rpb0, out0), lin1.forward_q(x1, epilogue, gate1, res1, rpb1, out1))

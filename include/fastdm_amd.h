@@ -32,7 +32,8 @@ enum {
   FDM_EPI_NONE = 0,
   FDM_EPI_GELU_TANH = 1,     /* bf16(gelu_tanh(bf16(y)))  -- layer/activations.py:38-41 */
   FDM_EPI_GELU_ERF = 2,      /* bf16(gelu_erf(bf16(y)))   -- model/flux.py:61            */
-  FDM_EPI_GATE_RESIDUAL = 3  /* bf16(res + bf16(gate[n] * bf16(y))) -- model/flux.py:153-154 */
+  FDM_EPI_GATE_RESIDUAL = 3, /* bf16(res + bf16(gate[n] * bf16(y))) -- model/flux.py:153-154 */
+  FDM_EPI_GATE_RESIDUAL_F32 = 4 /* bf16(res + gate_f32[n] * bf16(y)), fp32 gate, ONE rounding -- model/wan.py:102,113 */
 };
 
 int fdm_version(void);
@@ -164,6 +165,14 @@ int64_t fdm_attn_fwd_workspace_bytes(int head_dim);
  * fp8 (quant_mode 1) or asymmetric int8 (quant_mode 2, also out_azp) quantisation of y.
  * Optional fused residual: if res != NULL, x := bf16(res + bf16(gate[b,:] * x)) first and, when
  * x_out != NULL, that updated x is written there (model/flux.py:153-156).                        */
+/* Wan's fp32 modulation (model/wan.py:99,109-111,362): y = bf16(LN_f32(x) * (1 + scale_f32[b,:]) + shift_f32[b,:]) with ONE
+ * rounding (FP32LayerNorm, then fp32 multiply-add, then type_as).  scale/shift are fp32 [B, hidden] with
+ * mod_batch_stride in floats (0 broadcasts one row: an affine FP32LayerNorm is scale = weight - 1, shift = bias).
+ * Outputs as fdm_ln_modulate.                                                                                        */
+int fdm_ln_modulate_f32(void* out_bf16, void* out_q, float* out_scale, int32_t* out_azp, int quant_mode,
+                        const void* x, const float* scale, const float* shift, int64_t mod_batch_stride,
+                        int64_t rows, int hidden, int64_t rows_per_batch, float eps, fdm_stream_t stream);
+
 int fdm_ln_modulate(void* out_bf16, void* out_q, float* out_scale, int32_t* out_azp, int quant_mode,
                     const void* x, const void* scale, const void* shift, int64_t mod_batch_stride,
                     const void* res, const void* gate, void* x_out,

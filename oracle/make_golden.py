@@ -420,6 +420,60 @@ def gen_qwen_full(n_blocks=4, img_h=83, img_w=83, n_txt=128, seed=0):
     save(f"qwen_full_{n_blocks}blocks.npz", d)
 
 
+# ------------------------------------------------------------------ Wan2.x
+def ref_wan_core(cfg, quant, sd):
+    from fastdm.model.wan import WanTransformer3DModelCore
+    core = WanTransformer3DModelCore(
+        patch_size=cfg.patch_size, num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim,
+        in_channels=cfg.in_channels, out_channels=cfg.out_channels, text_dim=cfg.text_dim, freq_dim=cfg.freq_dim, ffn_dim=cfg.ffn_dim,
+        num_layers=cfg.num_layers, cross_attn_norm=True, eps=cfg.eps, rope_max_seq_len=cfg.rope_max_seq_len,
+        data_type=torch.bfloat16, quant_dtype=quant, cache=None, sparse_attn=None)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        core.weight_loading(dict(sd), device_type="cpu")
+    return core
+
+
+def gen_tiny_wan():
+    """Tiny Wan core (2 blocks, 2 x 64 heads) through the reference in bf16 / fp8 (dense attention: the reference has no
+    CPU sparse kernel), plus radial block-sparse masks from the reference's generator on three geometries."""
+    import_reference()
+    from fastdm.sparse.xsparse import SparseAttn, sparge_mask_convert
+    from oracle import wan as OW
+    cfg = OW.TINY
+    sd = OW.synth_state_dict(cfg, seed=21)
+    inp = OW.synth_inputs(cfg, batch=2, frames=3, height=8, width=8, n_txt=9, seed=21)
+    d = {"seed": 21, "batch": 2, "frames": 3, "height": 8, "width": 8, "n_txt": 9}
+    for tag, qt in (("bf16", None), ("fp8", torch.float8_e4m3fn), ("int8", torch.int8)):
+        use_backend("cpu_fp8" if qt == torch.float8_e4m3fn else "torch")
+        core = ref_wan_core(cfg, qt, sd)
+        for ti, t in enumerate((999.0, 500.0)):
+            out = core.forward(hidden_states=inp["hidden_states"], timestep=torch.tensor([t, t]),
+                               encoder_hidden_states=inp["encoder_hidden_states"], return_dict=False)
+            out = out[0] if isinstance(out, (tuple, list)) else out
+            d[f"out_{tag}_t{ti}"] = out
+    use_backend("torch")
+    core = ref_wan_core(cfg, None, sd)
+    cos, sin = core.rope.forward(inp["hidden_states"])
+    d["rope"] = torch.cat((cos.squeeze()[:, 0::2], sin.squeeze()[:, 1::2]), dim=-1).to(torch.bfloat16)
+    save("tiny_wan.npz", d)
+    m = {}
+    import contextlib
+    import io
+    for gi, (frames, tpf, bs, decay) in enumerate(((6, 320, 64, 0.3), (4, 480, 64, 0.5), (9, 256, 128, 0.3))):
+        sa = SparseAttn.from_dict({"sparse_algorithm": "radial", "model_type": "wan", "block_size": bs, "enable_sparse": True,
+                                   "decay_factor": decay, "dense_layers": 1, "dense_steps": 2})
+        sa.post_init(video_token_num=frames * tpf, num_frame=frames)
+        with contextlib.redirect_stdout(io.StringIO()):
+            lm = sa.gen_log_mask_shrinked(frames * tpf, torch.device("cpu"))
+        m[f"g{gi}_geom"] = np.array([frames, tpf, bs], dtype=np.int64)
+        m[f"g{gi}_decay"] = decay
+        m[f"g{gi}_log_mask"] = lm.to(torch.uint8)
+        m[f"g{gi}_kernel_mask"] = sparge_mask_convert(lm, block_size=bs, arch="sm80").to(torch.uint8)
+    save("wan_radial_mask.npz", m)
+
+
 # ------------------------------------------------------------------ full-width C3 fixture
 def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=0, sub=64):
     """Full-width FLUX.1-dev at 1024x2048 (S = 8192 + 512) through the reference's own block
@@ -514,7 +568,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "c3"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "c3"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     args = ap.parse_args()
@@ -529,6 +583,8 @@ def main():
         gen_teacache()
     if args.what in ("small", "qwen"):
         gen_tiny_qwen()
+    if args.what in ("small", "wan"):
+        gen_tiny_wan()
     if args.what == "qwen_full":
         gen_qwen_full()
     if args.what == "c3":

@@ -3,6 +3,7 @@
 //   tools/micro/gemm_bench.hip -o tools/micro/gemm_bench[_variant] [-DFDM_...]
 #include "../../fastdm_amd/csrc/gemm.hip"
 #include <cstdio>
+namespace fdm { int g_last_hip_error = 0; }
 #include <vector>
 
 static uint64_t rng = 0x9E3779B97F4A7C15ull;
