@@ -21,6 +21,7 @@ SIGNATURES = {
     "fdm_error_string": (C.c_char_p, [I32]),
     "fdm_last_hip_error_string": (C.c_char_p, []),
     "fdm_rms_norm": (I32, [P, P, P, F32, I64, I32, P]),
+    "fdm_rms_norm_strided": (I32, [P, P, P, F32, I64, I32, I64, I64, P]),
     "fdm_rope_inplace": (I32, [P, P, P, I64, I64, I32, I32, I32, I32, I64, I64, I32, P]),
     "fdm_quant_fp8_rowwise": (I32, [P, P, P, I64, I32, I64, P]),
     "fdm_quant_int8_rowwise": (I32, [P, P, P, P, I64, I32, I64, P]),

@@ -51,11 +51,12 @@ __global__ void __launch_bounds__(256) rms_norm_small_kernel(bf16_t* __restrict_
 
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) rms_norm_row_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ in,
-                                                               const bf16_t* __restrict__ w, float eps, int hidden) {
+                                                               const bf16_t* __restrict__ w, float eps, int hidden,
+                                                               int64_t in_stride, int64_t out_stride) {
   __shared__ float smem[THREADS / 64];
   const int64_t row = blockIdx.x;
   const int nvec = hidden >> 3;
-  const bf16_t* src = in + row * hidden;
+  const bf16_t* src = in + row * in_stride;
   Vec8 x[MAXV];
   float ss = 0.f;
   const bool cached = nvec <= MAXV * THREADS;
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(THREADS) rms_norm_row_kernel(bf16_t* __restric
   }
   ss = block_reduce<THREADS>(ss, OpSum(), smem);
   const float rs = rsqrtf(ss / (float)hidden + eps);
-  bf16_t* dst = out + row * hidden;
+  bf16_t* dst = out + row * out_stride;
   if (cached) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -667,10 +668,28 @@ int fdm_rms_norm(void* out, const void* in, const void* weight, float eps, int64
       default: rms_norm_small_kernel<64><<<grid, 256, 0, s>>>(o, i, w, eps, rows, hidden); break;
     }
   } else if (hidden <= 4096) {
-    rms_norm_row_kernel<64><<<(int)rows, 64, 0, s>>>(o, i, w, eps, hidden);
+    rms_norm_row_kernel<64><<<(int)rows, 64, 0, s>>>(o, i, w, eps, hidden, hidden, hidden);
   } else {
-    rms_norm_row_kernel<256><<<(int)rows, 256, 0, s>>>(o, i, w, eps, hidden);
+    rms_norm_row_kernel<256><<<(int)rows, 256, 0, s>>>(o, i, w, eps, hidden, hidden, hidden);
   }
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+int fdm_rms_norm_strided(void* out, const void* in, const void* weight, float eps, int64_t rows, int hidden, int64_t in_row_stride,
+                         int64_t out_row_stride, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (rows == 0 && hidden > 0 && !(hidden & 7)) return FDM_OK;
+  if (!out || !in || !weight || rows < 0 || hidden <= 0 || (hidden & 7) || !aligned16(out) || !aligned16(in) || !aligned16(weight) ||
+      in_row_stride < hidden || out_row_stride < hidden || (in_row_stride & 7) || (out_row_stride & 7))
+    return FDM_ERR_INVALID;
+  hipStream_t s = to_stream(stream);
+  if (hidden <= 4096)
+    rms_norm_row_kernel<64><<<(int)rows, 64, 0, s>>>((bf16_t*)out, (const bf16_t*)in, (const bf16_t*)weight, eps, hidden, in_row_stride,
+                                                     out_row_stride);
+  else
+    rms_norm_row_kernel<256><<<(int)rows, 256, 0, s>>>((bf16_t*)out, (const bf16_t*)in, (const bf16_t*)weight, eps, hidden, in_row_stride,
+                                                       out_row_stride);
   FDM_CHECK_LAUNCH();
   return FDM_OK;
 }

@@ -70,6 +70,16 @@ def ln_modulate_f32(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, r
     return out, qz
 
 
+def rms_norm_rows(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """rms_norm over the last dim of a [rows, hidden] matrix whose rows may be column slices of a wider matrix."""
+    rows, hidden = x.shape
+    assert x.stride(1) == 1 and weight.is_contiguous() and weight.numel() == hidden
+    out = torch.empty((rows, hidden), device=x.device, dtype=x.dtype)
+    N.check(N.lib().fdm_rms_norm_strided(N.ptr(out), N.ptr(x), N.ptr(weight), eps, rows, hidden, x.stride(0), hidden, N.stream()),
+            "rms_norm_strided")
+    return out
+
+
 def gate_residual(res: torch.Tensor, y: torch.Tensor, gate: torch.Tensor, rows_per_batch: int) -> torch.Tensor:
     """res + gate[b]*y (model/flux.py:153-154)."""
     rows, width = res.shape

@@ -186,3 +186,67 @@ class QwenEmbedRope:
         max_len = max(txt_seq_lens)
         txt_freqs = self.pos_freqs[max_vid_index: max_vid_index + max_len, ...]
         return torch.cat(vid_freqs, dim=0).to(device), txt_freqs.to(device)
+
+
+class WanRotaryPosEmbed:
+    """embeddings.py:859-922: per-axis (t, h, w) cos/sin tables in fp64 -> fp32, gathered on the latent grid.
+    `forward` returns (cos, sin) of shape [1, tokens, 1, head_dim] like the reference; `merged` gives the
+    [tokens, head_dim] = [cos[:, 0::2] | sin[:, 1::2]] table the rotary kernel consumes (transformer.py:489-491)."""
+
+    def __init__(self, attention_head_dim: int, patch_size, max_seq_len: int, theta: float = 10000.0):
+        self.attention_head_dim, self.patch_size, self.max_seq_len = attention_head_dim, patch_size, max_seq_len
+        h_dim = w_dim = 2 * (attention_head_dim // 6)
+        t_dim = attention_head_dim - h_dim - w_dim
+        cos_l, sin_l = [], []
+        for dim in (t_dim, h_dim, w_dim):
+            c, s_ = get_1d_rotary_pos_embed(dim, torch.arange(max_seq_len), theta)
+            cos_l.append(c)
+            sin_l.append(s_)
+        self.freqs_cos, self.freqs_sin = torch.cat(cos_l, dim=1), torch.cat(sin_l, dim=1)
+        self._merged = {}
+
+    def _grid(self, table, ppf, pph, ppw):
+        hd = self.attention_head_dim
+        parts = table.split([hd - 2 * (hd // 3), hd // 3, hd // 3], dim=1)
+        a = parts[0][:ppf].view(ppf, 1, 1, -1).expand(ppf, pph, ppw, -1)
+        b = parts[1][:pph].view(1, pph, 1, -1).expand(ppf, pph, ppw, -1)
+        c = parts[2][:ppw].view(1, 1, ppw, -1).expand(ppf, pph, ppw, -1)
+        return torch.cat([a, b, c], dim=-1).reshape(1, ppf * pph * ppw, 1, -1)
+
+    def forward(self, hidden_states: torch.Tensor):
+        _, _, num_frames, height, width = hidden_states.shape
+        p_t, p_h, p_w = self.patch_size
+        ppf, pph, ppw = num_frames // p_t, height // p_h, width // p_w
+        return (self._grid(self.freqs_cos, ppf, pph, ppw).to(hidden_states.device),
+                self._grid(self.freqs_sin, ppf, pph, ppw).to(hidden_states.device))
+
+    def merged(self, num_frames: int, height: int, width: int, device, dtype) -> torch.Tensor:
+        key = (num_frames, height, width, str(device), dtype)
+        if key not in self._merged:
+            p_t, p_h, p_w = self.patch_size
+            ppf, pph, ppw = num_frames // p_t, height // p_h, width // p_w
+            cos = self._grid(self.freqs_cos, ppf, pph, ppw).reshape(ppf * pph * ppw, -1)
+            sin = self._grid(self.freqs_sin, ppf, pph, ppw).reshape(ppf * pph * ppw, -1)
+            self._merged = {key: torch.cat((cos[:, 0::2], sin[:, 1::2]), dim=-1).to(dtype).contiguous().to(device)}
+        return self._merged[key]
+
+
+class WanTimeTextImageEmbedding:
+    """embeddings.py:949-992 (T2V: no image embedder).  The time embedder is an fp32 layer."""
+
+    def __init__(self, dim: int, time_freq_dim: int, time_proj_dim: int, text_embed_dim: int, image_embed_dim=None,
+                 pos_embed_seq_len=None, data_type=BF16):
+        if image_embed_dim is not None:
+            raise NotImplementedError("the I2V image embedder is not built (SURVEY.md §8f)")
+        self.timesteps_proj = Timesteps(num_channels=time_freq_dim, flip_sin_to_cos=True, downscale_freq_shift=0)
+        self.time_embedder = TimestepEmbedding(in_features=time_freq_dim, out_features=dim, data_type=torch.float32)
+        self.time_proj = QLinear(dim, time_proj_dim, data_type=data_type)
+        self.text_embedder = PixArtAlphaTextProjection(text_embed_dim, dim, act_fn="gelu_tanh", data_type=data_type)
+        self.image_embedder = None
+
+    def forward(self, timestep, encoder_hidden_states, encoder_hidden_states_image=None, timestep_seq_len=None):
+        assert timestep_seq_len is None, "per-token timesteps (wan2.2 ti2v) are not built"
+        ts = self.timesteps_proj.forward(timestep).to(torch.float32)
+        temb = self.time_embedder.forward(ts).type_as(encoder_hidden_states)
+        timestep_proj = self.time_proj.forward(F.silu(temb))
+        return temb, timestep_proj, self.text_embedder.forward(encoder_hidden_states), None

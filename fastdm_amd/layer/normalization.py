@@ -27,6 +27,26 @@ class RMSNorm:
         return rms_norm(hidden_states.contiguous(), self.weight, self.eps)
 
 
+class FP32LayerNorm:
+    """normalization.py:130-160: LayerNorm evaluated in fp32 whose result STAYS fp32 in the reference.  Here the
+    consumers fuse what follows (modulation or a plain cast) into one kernel: `forward_bf16` = the affine form cast to
+    the input dtype (`norm2(x).type_as(x)`, wan.py:105), `fused.ln_modulate_f32` for the modulated forms."""
+
+    def __init__(self, normalized_shape, eps: float = 1e-5, elementwise_affine: bool = True, bias: bool = True):
+        self.dim = normalized_shape if isinstance(normalized_shape, int) else normalized_shape[0]
+        self.eps, self.elementwise_affine = eps, elementwise_affine
+        self.weight = self.bias = None      # fp32 [dim], set by the loader when elementwise_affine
+        self._sm1 = None
+
+    def forward_bf16(self, x: torch.Tensor, quant=None):
+        """bf16(LN_f32(x) * weight + bias) on a [rows, dim] matrix (optionally also quantised per row)."""
+        if self._sm1 is None:
+            w = self.weight if self.weight is not None else torch.ones(self.dim, device=x.device)
+            b = self.bias if self.bias is not None else torch.zeros(self.dim, device=x.device)
+            self._sm1 = ((w.float() - 1.0).reshape(1, -1).contiguous(), b.float().reshape(1, -1).contiguous())
+        return fused.ln_modulate_f32(x, self._sm1[0], self._sm1[1], x.shape[0], quant=quant, want_bf16=quant is None, eps=self.eps)
+
+
 class _AdaLNBase:
     chunks = 0
 

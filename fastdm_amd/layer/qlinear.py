@@ -35,7 +35,15 @@ class QLinear:
     def weight_loading_and_quant(self, src_weight, src_bias, quant_type=None):
         """fastdm/layer/qlinear.py:18-54.  src_weight: list of [K, N_i] tensors (transposed views of
         the checkpoint's [N_i, K]); fused along N in list order."""
-        assert self.dtype == BF16, "bf16 activations only in this build"
+        if self.dtype == torch.float32:
+            # fp32 layer (Wan's time embedder, embeddings.py:962: one row per batch element): torch.addmm like the
+            # reference (qlinear.py:76); never quantised
+            assert quant_type is None
+            self.quant_type = None
+            self.weight = torch.cat(list(src_weight), dim=1).to(device=self.device, dtype=torch.float32)
+            self.bias = None if src_bias[0] is None else torch.cat(list(src_bias), dim=0).to(device=self.device, dtype=torch.float32)
+            return
+        assert self.dtype == BF16, "bf16 (or fp32 host-size) layers only in this build"
         w_nk = torch.cat([w.transpose(0, 1) for w in src_weight], dim=0).to(device=self.device, dtype=self.dtype).contiguous()
         if src_bias[0] is not None:
             assert self.has_bias, "Bias is not enabled but bias tensor is provided."
@@ -141,6 +149,9 @@ class QLinear:
 
     def forward(self, input_tensor: torch.Tensor) -> torch.Tensor:
         """fastdm/layer/qlinear.py:56-81: quantise per token, scaled GEMM (+bias), restore the leading dims."""
+        if self.dtype == torch.float32:
+            y = input_tensor.float() @ self.weight
+            return y if self.bias is None else y + self.bias
         ori_shape = input_tensor.shape
         x = input_tensor.reshape(-1, ori_shape[-1])
         if self.quant_type is not None:

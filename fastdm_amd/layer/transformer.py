@@ -29,11 +29,12 @@ class FeedForward:
         self.act_fn = _ActProj(dim, inner_dim, bias, data_type)            # keeps the reference attribute path act_fn.proj
         self.ff_out_proj = QLinear(inner_dim, dim_out or dim, bias=bias, data_type=data_type)
 
-    def forward_fused(self, xq, gate: torch.Tensor, res: torch.Tensor, rows_per_batch: int) -> torch.Tensor:
-        """res + gate * W2(gelu(W1 x)); xq = quantised (or bf16) [M, D] input; returns the new residual stream."""
+    def forward_fused(self, xq, gate: torch.Tensor, res: torch.Tensor, rows_per_batch: int, gate_epilogue: int = N.EPI_GATE_RESIDUAL) -> torch.Tensor:
+        """res + gate * W2(gelu(W1 x)); xq = quantised (or bf16) [M, D] input; returns the new residual stream.
+        gate_epilogue = N.EPI_GATE_RESIDUAL_F32 for Wan's fp32 gates."""
         h = self.act_fn.proj.forward_q(xq, epilogue=self.epilogue)
         hq = self.ff_out_proj.quantize_input(h) if self.ff_out_proj.quant_type is not None else h
-        return self.ff_out_proj.forward_q(hq, epilogue=N.EPI_GATE_RESIDUAL, gate=gate, res=res, rows_per_batch=rows_per_batch, out=res)
+        return self.ff_out_proj.forward_q(hq, epilogue=gate_epilogue, gate=gate, res=res, rows_per_batch=rows_per_batch, out=res)
 
     @staticmethod
     def forward_fused_pair(ff0, xq0, gate0, res0, rpb0, ff1, xq1, gate1, res1, rpb1):
@@ -133,3 +134,82 @@ class Attention:
             raise ValueError("QwenAttn forward requires encoder_hidden_states (text stream)")
         cross_attention_kwargs.pop("encoder_hidden_states_mask", None)
         return self.forward(hidden_states, encoder_hidden_states, attention_mask, **cross_attention_kwargs)
+
+
+class WanAttention:
+    """transformer.py:393-534 (T2V: no added image K/V).  q/k RMS-norm runs ACROSS heads (over the whole inner dim),
+    RoPE is GPT-J style on the merged [cos | sin] table, self-attention may be block-sparse (radial)."""
+
+    def __init__(self, dim: int, heads: int = 8, dim_head: int = 64, eps: float = 1e-5, dropout: float = 0.0,
+                 added_kv_proj_dim: Optional[int] = None, cross_attention_dim_head: Optional[int] = None, processor=None,
+                 is_cross_attention=None, is_causal: bool = False, data_type=BF16):
+        if added_kv_proj_dim is not None:
+            raise NotImplementedError("the I2V image K/V branch is not built (SURVEY.md §8f)")
+        self.inner_dim = dim_head * heads
+        self.heads, self.head_dim, self.eps = heads, dim_head, eps
+        self.added_kv_proj_dim = None
+        self.cross_attention_dim_head = cross_attention_dim_head
+        self.kv_inner_dim = self.inner_dim if cross_attention_dim_head is None else cross_attention_dim_head * heads
+        self.is_causal = is_causal
+        self.scale = dim_head ** -0.5
+        self.sdpa_kv_heads, self.sdpa_head_dim = heads, dim_head
+        self.norm_q_weight = self.norm_k_weight = None
+        if cross_attention_dim_head is not None:
+            self.to_q = QLinear(dim, self.inner_dim, bias=True, data_type=data_type)
+            self.to_kv = QLinear(dim, 2 * self.kv_inner_dim, bias=True, data_type=data_type)
+        else:
+            self.qkv = QLinear(dim, self.inner_dim + 2 * self.kv_inner_dim, bias=True, data_type=data_type)
+        self.to_out = QLinear(self.inner_dim, dim, bias=True, data_type=data_type)
+        self.add_k_proj = self.add_v_proj = None
+        self.is_cross_attention = cross_attention_dim_head is not None
+
+    # ---- fused path: x is a [B*S, D] matrix (Quantized or bf16); returns the attention result [B*S, inner] (before to_out)
+    def attend(self, xq, batch: int, seq: int, rope=None, enc_q=None, enc_len: int = 0, sparse_attn=None, layer_index: int = 0):
+        D = self.inner_dim
+        if self.is_cross_attention:
+            q = fused.rms_norm_rows(self.to_q.forward_q(xq), self.norm_q_weight, self.eps)
+            kv = self.to_kv.forward_q(enc_q)
+            k = fused.rms_norm_rows(kv[:, :D], self.norm_k_weight, self.eps)
+            v, sk = kv[:, D:], enc_len
+        else:
+            qkv = self.qkv.forward_q(xq)
+            q = fused.rms_norm_rows(qkv[:, :D], self.norm_q_weight, self.eps)
+            k = fused.rms_norm_rows(qkv[:, D:2 * D], self.norm_k_weight, self.eps)
+            v, sk = qkv[:, 2 * D:], seq
+            if rope is not None:
+                from fastdm_amd.kernel.operators_set import rotary_pos_embedding
+                rotary_pos_embedding(q.view(batch, seq, D), k.view(batch, seq, D), self.head_dim, rope, is_neox=False)
+        use_sparse = False
+        if sparse_attn is not None and not self.is_cross_attention:
+            cb = sparse_attn.config.current_steps_callback
+            step = cb() if cb is not None else None
+            step = 0 if step is None else step
+            use_sparse = not (step < sparse_attn.config.dense_steps or layer_index < sparse_attn.config.dense_layers)
+        if use_sparse:
+            outs = []
+            for b in range(batch):       # the reference flattens (b s) and its kernel call is per sample as well
+                sl = slice(b * seq, (b + 1) * seq)
+                outs.append(sparse_attn.apply(query=q[sl].view(seq, self.heads, self.head_dim), key=k[sl].view(seq, self.heads, self.head_dim),
+                                              value=v[sl].reshape(seq, self.heads, self.head_dim)).reshape(seq, D))
+            return outs[0] if batch == 1 else torch.cat(outs, dim=0)
+        return fused.attention(q, k, v, batch, self.heads, self.head_dim, self.scale)
+
+    # ---- reference signature
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None, attention_mask=None,
+                rotary_emb=None, sparse_attn=None, **kwargs) -> torch.Tensor:
+        B, S, Dm = hidden_states.shape
+        x = hidden_states.reshape(B * S, Dm)
+        first = self.to_q if self.is_cross_attention else self.qkv
+        xq = first.quantize_input(x.contiguous()) if first.quant_type is not None else x.contiguous()
+        rope = None
+        if rotary_emb is not None:
+            rope = rotary_emb if torch.is_tensor(rotary_emb) else \
+                torch.cat((rotary_emb[0].squeeze()[:, 0::2], rotary_emb[1].squeeze()[:, 1::2]), dim=-1).to(hidden_states.dtype).contiguous()
+        enc_q, enc_len = None, 0
+        if self.is_cross_attention:
+            enc_len = encoder_hidden_states.shape[1]
+            e = encoder_hidden_states.reshape(B * enc_len, -1).contiguous()
+            enc_q = self.to_kv.quantize_input(e) if self.to_kv.quant_type is not None else e
+        o = self.attend(xq, B, S, rope, enc_q, enc_len, sparse_attn, kwargs.get("layer_index", 0))
+        oq = self.to_out.quantize_input(o) if self.to_out.quant_type is not None else o
+        return self.to_out.forward_q(oq).view(B, S, -1)

@@ -1,0 +1,196 @@
+"""Wan2.x video transformer core on the HIP library (mirror of fastdm/model/wan.py:20-379), T2V path.
+
+Same classes, constructor arguments, diffusers weight names and `forward` signature/returns as the reference.
+Block wiring on gfx950 (rounding order of the reference's fp32 modulation kept, wan.py:80-115):
+
+  mods = scale_shift_table + temb.float()                                       (fp32 [B, 6, D], host-size)
+  LN_f32 + (1+scale)*x+shift + one rounding + per-token quant   (fdm_ln_modulate_f32)
+  -> qkv GEMM -> q/k RMS-norm across heads (strided rows of the fused projection) -> RoPE in place
+  -> dense or radial block-sparse attention (v read in place from the fused projection)
+  -> row quant -> to_out GEMM with the fp32-gate residual epilogue  x = bf16(x + y * gate)   (one rounding)
+  -> affine LN_f32 (norm2) + quant -> cross-attention to the text (to_q / fused to_kv GEMMs, RMS-norms, dense
+     attention Sq x 512) -> to_out GEMM with residual epilogue (gate = 1: a plain bf16 add)
+  -> LN_f32 modulate + quant -> FFN (tanh-GELU epilogue) -> fp32-gate residual epilogue.
+
+The 3-D patch embedding is a strided convolution with kernel == stride, i.e. a GEMM over non-overlapping patches:
+the latent is unfolded once (torch view ops) and goes through the bf16 GEMM kernel.
+"""
+import math
+from typing import Any, Dict, Optional, Tuple, Union
+
+import torch
+
+from fastdm_amd import _native as N
+from fastdm_amd.kernel import fused
+from fastdm_amd.layer.embeddings import WanRotaryPosEmbed, WanTimeTextImageEmbedding
+from fastdm_amd.layer.normalization import FP32LayerNorm
+from fastdm_amd.layer.qlinear import QLinear
+from fastdm_amd.layer.transformer import FeedForward, WanAttention
+from fastdm_amd.model.basemodel import BaseModelCore
+
+BF16 = torch.bfloat16
+
+
+class WanTransformerBlock:
+    """fastdm/model/wan.py:20-115."""
+
+    def __init__(self, dim: int, ffn_dim: int, num_heads: int, qk_norm: str = "rms_norm_across_heads", cross_attn_norm: bool = False,
+                 eps: float = 1e-6, added_kv_proj_dim: Optional[int] = None, data_type=BF16):
+        self.dim, self.eps, self.cross_attn_norm = dim, eps, cross_attn_norm
+        self.norm1 = FP32LayerNorm(dim, eps, elementwise_affine=False)
+        self.attn1 = WanAttention(dim=dim, heads=num_heads, dim_head=dim // num_heads, eps=eps, cross_attention_dim_head=None, data_type=data_type)
+        self.attn2 = WanAttention(dim=dim, heads=num_heads, dim_head=dim // num_heads, eps=eps, added_kv_proj_dim=added_kv_proj_dim,
+                                  cross_attention_dim_head=dim // num_heads, data_type=data_type)
+        if cross_attn_norm:
+            self.norm2 = FP32LayerNorm(dim, eps, elementwise_affine=True)
+        self.ffn = FeedForward(dim, inner_dim=ffn_dim, activation_fn="gelu-approximate", data_type=data_type)
+        self.norm3 = FP32LayerNorm(dim, eps, elementwise_affine=False)
+        self.scale_shift_table = None      # [1, 6, dim], loaded
+        self._ones = None
+
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, temb: torch.Tensor, rotary_emb,
+                sparse_attn=None, layer_index: Optional[int] = None, encoder_q=None) -> torch.Tensor:
+        """hidden_states [B, S, D] bf16; temb [B, 6, D]; rotary_emb: the merged [S, head_dim] table (or the reference's
+        (cos, sin) pair); encoder_q: optional pre-quantised text rows shared by all blocks."""
+        assert temb.ndim == 3, "per-token modulation (wan2.2 ti2v) is not built"
+        B, S, D = hidden_states.shape
+        x = hidden_states.reshape(B * S, D)
+        shift_msa, scale_msa, gate_msa, c_shift, c_scale, c_gate = [t.squeeze(1).contiguous() for t in
+                                                                    (self.scale_shift_table + temb.float()).chunk(6, dim=1)]
+        rope = rotary_emb
+        if rope is not None and not torch.is_tensor(rope):
+            rope = torch.cat((rope[0].squeeze()[:, 0::2], rope[1].squeeze()[:, 1::2]), dim=-1).to(hidden_states.dtype).contiguous()
+        a1, a2 = self.attn1, self.attn2
+        quant = a1.qkv.quant_type
+
+        def pick(pair):
+            return pair[1] if quant is not None else pair[0]
+
+        # 1. self-attention
+        n = pick(fused.ln_modulate_f32(x, scale_msa, shift_msa, S, quant=quant, eps=self.eps))
+        o = a1.attend(n, B, S, rope, sparse_attn=sparse_attn, layer_index=layer_index or 0)
+        oq = a1.to_out.quantize_input(o) if a1.to_out.quant_type is not None else o
+        x1 = torch.empty_like(x)
+        a1.to_out.forward_q(oq, epilogue=N.EPI_GATE_RESIDUAL_F32, gate=gate_msa, res=x, rows_per_batch=S, out=x1)
+        # 2. cross-attention (plain bf16 residual add = gate 1)
+        if self.cross_attn_norm:
+            n = pick(self.norm2.forward_bf16(x1, quant=quant))
+        else:
+            n = a2.to_q.quantize_input(x1) if quant is not None else x1
+        s_txt = encoder_hidden_states.shape[1]
+        if encoder_q is None:
+            e = encoder_hidden_states.reshape(B * s_txt, -1).contiguous()
+            encoder_q = a2.to_kv.quantize_input(e) if a2.to_kv.quant_type is not None else e
+        o = a2.attend(n, B, S, None, encoder_q, s_txt)
+        oq = a2.to_out.quantize_input(o) if a2.to_out.quant_type is not None else o
+        if self._ones is None:
+            self._ones = torch.ones((1, D), device=x.device, dtype=BF16)
+        x2 = torch.empty_like(x)
+        a2.to_out.forward_q(oq, epilogue=N.EPI_GATE_RESIDUAL, gate=self._ones, res=x1, rows_per_batch=B * S, out=x2)
+        # 3. feed-forward
+        n = pick(fused.ln_modulate_f32(x2, c_scale, c_shift, S, quant=quant, eps=self.eps))
+        x3 = self.ffn.forward_fused(n, c_gate, x2, S, gate_epilogue=N.EPI_GATE_RESIDUAL_F32)
+        return x3.view(B, S, D)
+
+
+class WanTransformer3DModelCore(BaseModelCore):
+    """fastdm/model/wan.py:117-379."""
+
+    def __init__(self, patch_size: Tuple[int] = (1, 2, 2), num_attention_heads: int = 40, attention_head_dim: int = 128,
+                 in_channels: int = 16, out_channels: int = 16, text_dim: int = 4096, freq_dim: int = 256, ffn_dim: int = 13824,
+                 num_layers: int = 40, cross_attn_norm: bool = True, qk_norm: Optional[str] = "rms_norm_across_heads", eps: float = 1e-6,
+                 image_dim: Optional[int] = None, added_kv_proj_dim: Optional[int] = None, rope_max_seq_len: int = 1024,
+                 pos_embed_seq_len: Optional[int] = None, data_type=BF16, quant_dtype: Optional[torch.dtype] = torch.float8_e4m3fn,
+                 cache=None, sparse_attn=None) -> None:
+        super().__init__("DiT")
+        if cache is not None and cache.config.enable_caching:
+            raise NotImplementedError("step caching for Wan is not built (SURVEY.md §8f)")
+        self.quant_dtype = quant_dtype
+        inner_dim = num_attention_heads * attention_head_dim
+        self.inner_dim, self.eps = inner_dim, eps
+        self.out_channels = out_channels or in_channels
+        self.rope = WanRotaryPosEmbed(attention_head_dim, patch_size, rope_max_seq_len)
+        self.patch_embedding_kernel_size = self.patch_embedding_stride = tuple(patch_size)
+        self.patch_embedding = QLinear(in_channels * math.prod(patch_size), inner_dim, data_type=data_type)   # conv3d(kernel == stride) as a GEMM
+        self.condition_embedder = WanTimeTextImageEmbedding(dim=inner_dim, time_freq_dim=freq_dim, time_proj_dim=inner_dim * 6,
+                                                            text_embed_dim=text_dim, image_embed_dim=image_dim,
+                                                            pos_embed_seq_len=pos_embed_seq_len, data_type=data_type)
+        self.blocks = [WanTransformerBlock(inner_dim, ffn_dim, num_attention_heads, qk_norm, cross_attn_norm, eps, added_kv_proj_dim,
+                                           data_type=data_type) for _ in range(num_layers)]
+        self.norm_out = FP32LayerNorm(inner_dim, eps, elementwise_affine=False)
+        self.proj_out = QLinear(inner_dim, self.out_channels * math.prod(patch_size), data_type=data_type)
+        self.scale_shift_table = None
+        self.cache, self.cache_config, self.enable_caching = cache, None, False
+        self.sparse_attn = sparse_attn
+
+    # ------------------------------------------------------------------ loading (wan.py:225-281)
+    def _pre_part_loading(self):
+        w = self.init_weight(["patch_embedding.weight"])                  # [D, C, pt, ph, pw]
+        b = self.init_weight(["patch_embedding.bias"])
+        self.patch_embedding.device = self.device
+        self.patch_embedding.bias = b
+        self.patch_embedding.set_weight_nk(w.reshape(w.shape[0], -1).contiguous(), None)
+        ce = self.condition_embedder
+        self.init_weight(["condition_embedder.time_embedder.linear_1"], ce.time_embedder.linear1)
+        self.init_weight(["condition_embedder.time_embedder.linear_2"], ce.time_embedder.linear2)
+        self.init_weight(["condition_embedder.time_proj"], ce.time_proj)
+        self.init_weight(["condition_embedder.text_embedder.linear_1"], ce.text_embedder.linear1)
+        self.init_weight(["condition_embedder.text_embedder.linear_2"], ce.text_embedder.linear2)
+
+    def _major_parts_loading(self):
+        q = self.quant_dtype
+        for i, blk in enumerate(self.blocks):
+            p = f"blocks.{i}"
+            blk.attn1.norm_q_weight = self.init_weight([f"{p}.attn1.norm_q.weight"])
+            blk.attn1.norm_k_weight = self.init_weight([f"{p}.attn1.norm_k.weight"])
+            self.init_weight([f"{p}.attn1.to_q", f"{p}.attn1.to_k", f"{p}.attn1.to_v"], blk.attn1.qkv, q)
+            self.init_weight([f"{p}.attn1.to_out.0"], blk.attn1.to_out, q)
+            blk.attn2.norm_q_weight = self.init_weight([f"{p}.attn2.norm_q.weight"])
+            blk.attn2.norm_k_weight = self.init_weight([f"{p}.attn2.norm_k.weight"])
+            self.init_weight([f"{p}.attn2.to_q"], blk.attn2.to_q, q)
+            self.init_weight([f"{p}.attn2.to_k", f"{p}.attn2.to_v"], blk.attn2.to_kv, q)
+            self.init_weight([f"{p}.attn2.to_out.0"], blk.attn2.to_out, q)
+            if blk.cross_attn_norm:
+                blk.norm2.weight = self.init_weight([f"{p}.norm2.weight"]).to(torch.float32)
+                blk.norm2.bias = self.init_weight([f"{p}.norm2.bias"]).to(torch.float32)
+            self.init_weight([f"{p}.ffn.net.0.proj"], blk.ffn.act_fn.proj, q)
+            self.init_weight([f"{p}.ffn.net.2"], blk.ffn.ff_out_proj, q)
+            blk.scale_shift_table = self.init_weight([f"{p}.scale_shift_table"])
+
+    def _post_part_loading(self):
+        self.init_weight(["proj_out"], self.proj_out)
+        self.scale_shift_table = self.init_weight(["scale_shift_table"])
+
+    # ------------------------------------------------------------------ forward (wan.py:283-379)
+    def forward(self, hidden_states: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                encoder_hidden_states_image: Optional[torch.Tensor] = None, return_dict: bool = True,
+                attention_kwargs: Optional[Dict[str, Any]] = None) -> Union[torch.Tensor, Tuple[torch.Tensor]]:
+        assert encoder_hidden_states_image is None, "I2V conditioning is not built"
+        dev = self.proj_out.weight.device
+        hidden_states, timestep, encoder_hidden_states = hidden_states.to(dev), timestep.to(dev), encoder_hidden_states.to(dev)
+        B, C, Fr, H, W = hidden_states.shape
+        p_t, p_h, p_w = self.patch_embedding_kernel_size
+        ppf, pph, ppw = Fr // p_t, H // p_h, W // p_w
+        S = ppf * pph * ppw
+        if self.sparse_attn and self.sparse_attn.config.sparse_algorithm == "radial":
+            self.sparse_attn.post_init(video_token_num=S, num_frame=ppf)
+        rope = self.rope.merged(Fr, H, W, dev, hidden_states.dtype)
+        # patchify: [B, C, F, H, W] -> [B*S, C*pt*ph*pw] rows in (f, h, w) token order, columns in the conv weight's (c, t, h, w) order
+        patches = hidden_states.reshape(B, C, ppf, p_t, pph, p_h, ppw, p_w).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * S, -1).contiguous()
+        x = self.patch_embedding.forward_q(patches).view(B, S, self.inner_dim)
+        temb, timestep_proj, enc, _ = self.condition_embedder.forward(timestep, encoder_hidden_states)
+        timestep_proj = timestep_proj.unflatten(1, (6, -1))
+        a2 = self.blocks[0].attn2
+        e2 = enc.reshape(B * enc.shape[1], -1).contiguous()
+        # every block quantises the same text rows for its to_kv projection: do it once
+        enc_q = a2.to_kv.quantize_input(e2) if a2.to_kv.quant_type is not None else e2
+        for layer_index, block in enumerate(self.blocks):
+            x = block.forward(x, enc, timestep_proj, rope, self.sparse_attn, layer_index, encoder_q=enc_q)
+        # output norm: (scale_shift_table + temb) in bf16, `1 + scale` rounded to bf16 by the reference's type promotion (wan.py:353-362)
+        shift, scale = (self.scale_shift_table + temb.unsqueeze(1)).chunk(2, dim=1)
+        scale_f = (1 + scale.squeeze(1)).float() - 1.0
+        y, _ = fused.ln_modulate_f32(x.reshape(B * S, -1), scale_f.contiguous(), shift.squeeze(1).float().contiguous(), S, quant=None, eps=self.eps)
+        y = self.proj_out.forward_q(y)
+        y = y.reshape(B, ppf, pph, ppw, p_t, p_h, p_w, -1).permute(0, 7, 1, 4, 2, 5, 3, 6)
+        output = y.flatten(6, 7).flatten(4, 5).flatten(2, 3)
+        return (output,)

@@ -20,6 +20,7 @@ from fastdm_amd.caching.xcaching import AutoCache
 from fastdm_amd.kernel.utils import set_global_backend
 from fastdm_amd.model.flux import FluxTransformer2DModelCore
 from fastdm_amd.model.qwenimage import QwenImageTransformer2DModelCore
+from fastdm_amd.model.wan import WanTransformer3DModelCore
 
 
 class ConfigMixin:
@@ -107,10 +108,46 @@ class QwenTransformerWrapper(BaseModelWrapper):
         return self.core_model.forward(hidden_states, **kwargs)
 
 
+_WAN_A14B_CONFIG = dict(patch_size=(1, 2, 2), num_attention_heads=40, attention_head_dim=128, in_channels=16, out_channels=16, text_dim=4096,
+                        freq_dim=256, ffn_dim=13824, num_layers=40, qk_norm="rms_norm_across_heads", eps=1e-6, rope_max_seq_len=1024,
+                        image_dim=None)
+
+
+class WanTransformer3DWrapper(BaseModelWrapper):
+    """model_entry.py:410-462.  The architecture comes from the checkpoint's config.json (`config_json`), or from
+    `model_config` (a dict with the same keys), defaulting to Wan2.2-T2V-A14B."""
+
+    def __init__(self, ckpt_path=None, in_channels: int = 16, out_channels: int = 16, dtype: torch.dtype = torch.bfloat16,
+                 quant_type: Optional[torch.dtype] = None, kernel_backend: str = "hip", config_json=None, cache: AutoCache = None,
+                 model_config: Optional[Dict] = None, **kwargs):
+        super().__init__(kernel_backend, config_path=config_json)
+        cfg = dict(_WAN_A14B_CONFIG)
+        cfg.update(self.model_config_dict or {})
+        cfg.update(model_config or {})
+        self.model_config_dict = cfg
+        self.config = self._create_diffusers_config(in_channels=cfg["in_channels"], out_channels=cfg["out_channels"], dtype=dtype,
+                                                    image_dim=cfg.get("image_dim"), patch_size=cfg["patch_size"])
+        self.dtype = dtype
+        self.core_model = WanTransformer3DModelCore(
+            patch_size=tuple(cfg["patch_size"]), num_attention_heads=cfg["num_attention_heads"], attention_head_dim=cfg["attention_head_dim"],
+            in_channels=cfg["in_channels"], out_channels=cfg["out_channels"], text_dim=cfg["text_dim"], freq_dim=cfg["freq_dim"],
+            ffn_dim=cfg["ffn_dim"], num_layers=cfg["num_layers"], qk_norm=cfg["qk_norm"], eps=cfg["eps"],
+            rope_max_seq_len=cfg["rope_max_seq_len"], data_type=dtype, quant_dtype=quant_type, cache=cache,
+            sparse_attn=kwargs.get("sparse_attn", None))
+        if isinstance(ckpt_path, dict) or (ckpt_path and os.path.exists(ckpt_path)):
+            self.core_model.weight_loading(ckpt_path, data_type=dtype, device_type="cuda")
+        elif ckpt_path:
+            print(f"Warning: Checkpoint path {ckpt_path} does not exist")
+
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, **kwargs):
+        return self.core_model.forward(hidden_states, **kwargs)
+
+
 class ModelWrapperFactory:
     """model_entry.py:463-497."""
-    _WRAPPER_MAPPING = {"flux": FluxTransformerWrapper, "qwen": QwenTransformerWrapper}
-    _NOT_BUILT = ("sdxl", "sd35", "wan", "sdxl-controlnet", "flux-controlnet")
+    _WRAPPER_MAPPING = {"flux": FluxTransformerWrapper, "qwen": QwenTransformerWrapper, "wan": WanTransformer3DWrapper}
+    _NOT_BUILT = ("sdxl", "sd35", "sdxl-controlnet", "flux-controlnet")
 
     @classmethod
     def create_wrapper(cls, model_type: str, **kwargs) -> BaseModelWrapper:

@@ -177,3 +177,69 @@ def qwen_step_inputs(batch, img_h, img_w, n_txt=128, in_channels=64, joint_atten
         img_shapes=[[(1, img_h, img_w)]] * batch,
         txt_seq_lens=[n_txt] * batch,
     )
+
+
+class SyntheticWanStateDict(dict):
+    """Lazily generated diffusers-named Wan (T2V) state_dict, bit-identical to oracle.wan.synth_state_dict."""
+
+    def __init__(self, patch_size=(1, 2, 2), num_attention_heads=40, attention_head_dim=128, in_channels=16, out_channels=16, text_dim=4096,
+                 freq_dim=256, ffn_dim=13824, num_layers=40, seed=0, device="cuda", **_):
+        super().__init__()
+        self.seed, self.device = seed, device
+        D = num_attention_heads * attention_head_dim
+        pt, ph, pw = patch_size
+        spec = {}
+
+        def lin(name, k, n, kind="w"):
+            spec[f"{name}.weight"] = ((n, k), kind)
+            spec[f"{name}.bias"] = ((n,), "b")
+
+        spec["patch_embedding.weight"] = ((D, in_channels, pt, ph, pw), "conv")
+        spec["patch_embedding.bias"] = ((D,), "b")
+        lin("condition_embedder.time_embedder.linear_1", freq_dim, D)
+        lin("condition_embedder.time_embedder.linear_2", D, D)
+        lin("condition_embedder.time_proj", D, 6 * D, "w_mod")
+        lin("condition_embedder.text_embedder.linear_1", text_dim, D)
+        lin("condition_embedder.text_embedder.linear_2", D, D)
+        for i in range(num_layers):
+            p = f"blocks.{i}"
+            for a in ("attn1", "attn2"):
+                for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                    lin(f"{p}.{a}.{n}", D, D)
+                spec[f"{p}.{a}.norm_q.weight"] = ((D,), "rms")
+                spec[f"{p}.{a}.norm_k.weight"] = ((D,), "rms")
+            spec[f"{p}.norm2.weight"] = ((D,), "rms")
+            spec[f"{p}.norm2.bias"] = ((D,), "b")
+            lin(f"{p}.ffn.net.0.proj", D, ffn_dim)
+            lin(f"{p}.ffn.net.2", ffn_dim, D)
+            spec[f"{p}.scale_shift_table"] = ((1, 6, D), "table")
+        lin("proj_out", D, out_channels * pt * ph * pw)
+        spec["scale_shift_table"] = ((1, 2, D), "table")
+        self.spec = spec
+        for k in spec:
+            dict.__setitem__(self, k, None)
+
+    def _make(self, name):
+        shape, kind = self.spec[name]
+        key = "wan." + name
+        if kind == "w":
+            return normal(key, shape, (1.0 / shape[1]) ** 0.5, 0.0, self.seed, self.device)
+        if kind == "conv":
+            return normal(key, shape, (1.0 / math.prod(shape[1:])) ** 0.5, 0.0, self.seed, self.device)
+        if kind == "table":
+            return normal(key, shape, (1.0 / shape[-1]) ** 0.5, 0.0, self.seed, self.device)
+        if kind in ("w_mod", "b"):
+            return normal(key, shape, 0.02, 0.0, self.seed, self.device)
+        return normal(key, shape, 0.1, 1.0, self.seed, self.device)
+
+    def __getitem__(self, name):
+        return self._make(name)
+
+    def get(self, name, default=None):
+        return self._make(name) if name in self.spec else default
+
+
+def wan_step_inputs(batch, frames, height, width, n_txt=512, in_channels=16, text_dim=4096, seed=0, device="cuda"):
+    """Same tensors as oracle.wan.synth_inputs (bit-identical): latents [B, C, F, H, W] ~ N(0,1), text [B, n_txt, text_dim]."""
+    return dict(hidden_states=normal("wan.input.latents", (batch, in_channels, frames, height, width), 1.0, 0.0, seed, device),
+                encoder_hidden_states=normal("wan.input.prompt_embeds", (batch, n_txt, text_dim), 1.0, 0.0, seed, device))

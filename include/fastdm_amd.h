@@ -45,6 +45,10 @@ const char* fdm_last_hip_error_string(void);
  * out[r,:] = bf16(bf16(x[r,:] * rsqrt(mean(x^2)+eps)) * w[:]);  rows x hidden, contiguous.   */
 int fdm_rms_norm(void* out, const void* in, const void* weight, float eps,
                  int64_t rows, int hidden, fdm_stream_t stream);
+/* Same arithmetic on rows that are slices of wider matrices (Wan: q / k columns of the fused qkv projection,
+ * layer/transformer.py:478-485): row strides in elements, multiples of 8.                         */
+int fdm_rms_norm_strided(void* out, const void* in, const void* weight, float eps, int64_t rows, int hidden,
+                         int64_t in_row_stride, int64_t out_row_stride, fdm_stream_t stream);
 
 /* ---- replaces cuda_ops.rotary_emb_ (ops.h:22-33; elmwise_ops.cu:86-168,451-522) ---------------
  * In place on q [tokens, q_heads*head_size] and k [tokens, k_heads*head_size] (row strides in
