@@ -27,7 +27,7 @@ import torch  # noqa: E402
 PEAK_TFLOPS = {"fp8": 5000.0, "bf16": 2500.0, "int8": 5000.0}   # dense MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 IMAGE_STEPS = 25
 # timing-span name -> HIP kernel it launches (the name rocprofv3 reports; profiles/*_summary.txt)
-HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd_kernel<128>", "gemm_w8a8_fp8": "fdm::gemm_kernel<0, false>", "gemm_w8a8_fp8_res": "fdm::gemm_kernel<0, true>",
+HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd_kernel<128>", "attn_sparse_bf16": "fdm::attn_fwd_kernel<128>", "gemm_w8a8_fp8": "fdm::gemm_kernel<0, false>", "gemm_w8a8_fp8_res": "fdm::gemm_kernel<0, true>",
               "gemm_w8a8_int8": "fdm::gemm_kernel<1, false>", "gemm_w8a8_int8_res": "fdm::gemm_kernel<1, true>",
               "gemm_bf16": "fdm::gemm_kernel<2, false>", "gemm_bf16_res": "fdm::gemm_kernel<2, true>"}
 
@@ -80,12 +80,18 @@ def cpu_baseline_leg(height, width, n_txt, quant_tag):
 
 
 def main():
+    global IMAGE_STEPS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=IMAGE_STEPS)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", choices=["flux", "qwen"], default="flux",
-                    help="flux = the headline workload; qwen = Qwen-Image (BASELINE.json configs[3]): a step is a cond + uncond forward pair (true CFG)")
+    ap.add_argument("--steps", type=int, default=None, help="default 25 (flux, qwen) / 3 (wan)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 3 (flux, qwen) / 1 (wan)")
+    ap.add_argument("--model", choices=["flux", "qwen", "wan"], default="flux",
+                    help="flux = the headline workload; qwen = Qwen-Image (BASELINE.json configs[3]) and wan = Wan2.2-T2V-A14B "
+                         "(configs[4]): a step is a cond + uncond forward pair (CFG)")
+    ap.add_argument("--frames", type=int, default=81, help="wan: video frames")
+    ap.add_argument("--sparse-config", default=None, help="wan: radial block-sparse attention JSON (examples/sparse/radial_attn_wan.json)")
+    ap.add_argument("--start-step", type=int, default=0, help="schedule index of the first timed step (wan: >= dense_steps exercises the sparse steps)")
+    ap.add_argument("--layers", type=int, default=None, help="wan: number of blocks (default 40; a reduced depth is reported in the workload string)")
     ap.add_argument("--height", type=int, default=None, help="default 1024 (flux) / 1328 (qwen)")
     ap.add_argument("--width", type=int, default=None, help="default 2048 (flux) / 1328 (qwen)")
     ap.add_argument("--max-seq-len", type=int, default=None, help="text tokens: default 512 (flux) / 128 (qwen)")
@@ -94,9 +100,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event spans")
     args = ap.parse_args()
-    dflt = {"flux": (1024, 2048, 512, "fp8"), "qwen": (1328, 1328, 128, "int8")}[args.model]
+    dflt = {"flux": (1024, 2048, 512, "fp8"), "qwen": (1328, 1328, 128, "int8"), "wan": (768, 1280, 512, "fp8")}[args.model]
     args.height, args.width = args.height or dflt[0], args.width or dflt[1]
     args.max_seq_len, args.quant = args.max_seq_len or dflt[2], args.quant or dflt[3]
+    args.steps = args.steps if args.steps is not None else (3 if args.model == "wan" else 25)
+    args.warmup = args.warmup if args.warmup is not None else (1 if args.model == "wan" else 3)
 
     from fastdm_amd import distributed as D
     rank, world, local_rank = D.init_from_env()
@@ -117,25 +125,46 @@ def main():
         model = create_model("flux", ckpt_path=SyntheticFluxStateDict(seed=0), dtype=torch.bfloat16, quant_type=quant,
                              kernel_backend="hip", cache=cache).eval()
         pipe = SyntheticFluxPipeline(model, seed=0)
-    else:
+    elif args.model == "qwen":
         model = create_model("qwen", ckpt_path=SyntheticQwenStateDict(seed=0), dtype=torch.bfloat16, quant_type=quant,
                              kernel_backend="hip", cache=cache, out_channels=16).eval()
         pipe = SyntheticQwenPipeline(model, seed=0)
+    else:
+        from fastdm_amd.pipeline import SyntheticWanPipeline
+        from fastdm_amd.sparse import SparseAttn
+        from fastdm_amd.synthetic import SyntheticWanStateDict
+        sparse = SparseAttn.from_json(args.sparse_config) if args.sparse_config else None
+        mc = {"num_layers": args.layers} if args.layers else {}
+        model = create_model("wan", ckpt_path=SyntheticWanStateDict(seed=0, **mc), dtype=torch.bfloat16, quant_type=quant, kernel_backend="hip",
+                             model_config=mc, sparse_attn=sparse).eval()
+        pipe = SyntheticWanPipeline(model, seed=0)
+        if sparse:
+            sparse.config.current_steps_callback = lambda: pipe.scheduler_step_index
     if cache:
         cache.config.current_steps_callback = lambda: pipe.scheduler_step_index
     # rank r denoises image r of the global batch (different latents/prompt per image)
-    inp = pipe.prepare(1, args.height, args.width, args.max_seq_len, seed=rank)
-    n_img = inp["hidden_states"].shape[1]
-    sig = flow_match_sigmas(IMAGE_STEPS, n_img) if args.model == "flux" else flow_match_sigmas(IMAGE_STEPS, n_img, max_seq_len=8192, max_shift=0.9)
+    if args.model == "wan":
+        IMAGE_STEPS = 40
+        inp = pipe.prepare(1, args.height, args.width, args.frames, args.max_seq_len, seed=rank)
+        n_img = inp["hidden_states"].shape[2] * (inp["hidden_states"].shape[3] // 2) * (inp["hidden_states"].shape[4] // 2)
+        sig = pipe.sigmas(IMAGE_STEPS)
+    else:
+        inp = pipe.prepare(1, args.height, args.width, args.max_seq_len, seed=rank)
+        n_img = inp["hidden_states"].shape[1]
+        sig = flow_match_sigmas(IMAGE_STEPS, n_img) if args.model == "flux" else flow_match_sigmas(IMAGE_STEPS, n_img, max_seq_len=8192, max_shift=0.9)
     guidance = torch.full((1,), 3.5, device=dev, dtype=torch.float32)
 
     state = {"lat": inp["hidden_states"].clone(), "i": 0}
 
     def one_step():
-        i = state["i"] % IMAGE_STEPS
+        i = (state["i"] + args.start_step) % IMAGE_STEPS
         if i == 0:
             state["lat"] = inp["hidden_states"].clone()
         pipe.scheduler_step_index = i
+        if args.model == "wan":
+            state["lat"] = pipe.step(state["lat"], inp, sig[i], sig[i + 1], 5.0)      # cond + uncond forward, CFG combine, Euler update
+            state["i"] += 1
+            return
         if args.model == "qwen":
             state["lat"] = pipe.step(state["lat"], inp, sig[i], sig[i + 1], 4.0)    # cond + uncond forward, CFG combine, Euler update
             state["i"] += 1
@@ -181,14 +210,25 @@ def main():
     if args.model == "flux":
         workload = (f"FLUX.1-dev {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step flow-match schedule, "
                     f"batch 1 per GPU, 19 double + 38 single blocks" + (f", TeaCache ({skipped}/{args.steps} steps skipped)" if cache else ""))
+    elif args.model == "wan":
+        hs = inp["hidden_states"].shape
+        nl = len(model.core_model.blocks)
+        sp = model.core_model.sparse_attn
+        mode = "dense attention" if sp is None else (f"radial block-sparse attention (block {sp.config.block_size}, decay {sp.config.decay_factor}, "
+                                                     f"dense layers {sp.config.dense_layers}, dense steps {sp.config.dense_steps}; timed steps "
+                                                     f"{args.start_step}..{args.start_step + args.steps - 1})")
+        workload = (f"Wan2.2-T2V-A14B {args.quant} {args.height}x{args.width}x{args.frames}f (latents {tuple(hs[1:])}, S={n_img}+{args.max_seq_len}), "
+                    f"40-step schedule, CFG (2 forwards per step), batch 1 per GPU, {nl} blocks"
+                    + ("" if nl == 40 else " [REDUCED DEPTH]") + f", {mode}")
     else:
         nfw = 2 * args.steps
         workload = (f"Qwen-Image {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step schedule, true CFG "
                     f"(2 forwards per step), batch 1 per GPU, 60 double-stream blocks"
                     + (f", TeaCache ({skipped}/{nfw} forwards skipped)" if cache else ""))
     out = {
-        "metric": ("denoise it/s (sec/image = 25 / (value / n_gpus)), FLUX 1024x2048 fp8 @25 steps" if args.model == "flux" else
-                   "denoise it/s (sec/image = 25 / (value / n_gpus)), Qwen-Image 1328x1328 int8 @25 steps, true CFG"),
+        "metric": {"flux": "denoise it/s (sec/image = 25 / (value / n_gpus)), FLUX 1024x2048 fp8 @25 steps",
+                   "qwen": "denoise it/s (sec/image = 25 / (value / n_gpus)), Qwen-Image 1328x1328 int8 @25 steps, true CFG",
+                   "wan": "denoise it/s (sec/video = 40 / (value / n_gpus)), Wan2.2-T2V-A14B 768x1280x81f fp8 @40 steps, CFG"}[args.model],
         "value": world * args.steps / elapsed,
         "unit": "it/s",
         "n_gpus": world,

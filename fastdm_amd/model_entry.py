@@ -187,11 +187,11 @@ class FastDMEngine:
     def __init__(self, model_path, architecture="flux", device=0, data_type="bfloat16", use_fp8=False, use_int8=False,
                  kernel_backend="hip", cache_config=None, oom_resolve=False, use_diffusers=True, task="t2i",
                  sparse_attn_config=None, synthetic_seed=0, **model_kwargs):
-        if architecture not in ("flux", "qwen"):
+        if architecture not in ("flux", "qwen", "wan"):
             raise NotImplementedError(f"architecture '{architecture}' is not built yet (SURVEY.md §8f)")
         if data_type != "bfloat16":
             raise NotImplementedError("bfloat16 activations only in this build")
-        if sparse_attn_config:
+        if sparse_attn_config and architecture != "wan":
             raise ValueError("Sparse attention is only supported for Wan models")
         self.architecture, self.device, self.task = architecture, device, task
         torch.cuda.set_device(device)
@@ -213,6 +213,17 @@ class FastDMEngine:
             self.pipe.transformer = create_model(architecture, ckpt_path=self.pipe.transformer.state_dict(), dtype=self.dtype,
                                                  quant_type=self.quant_type, kernel_backend=kernel_backend, cache=self.cache).eval()
             self.pipe.to("cuda")
+        elif architecture == "wan":
+            from fastdm_amd.pipeline import SyntheticWanPipeline
+            from fastdm_amd.sparse import SparseAttn
+            from fastdm_amd.synthetic import SyntheticWanStateDict
+            self.sparse_attn = SparseAttn.from_json(sparse_attn_config) if sparse_attn_config else None
+            sd = SyntheticWanStateDict(seed=synthetic_seed, **model_kwargs)
+            transformer = create_model("wan", ckpt_path=sd, dtype=self.dtype, quant_type=self.quant_type, kernel_backend=kernel_backend,
+                                       cache=self.cache, model_config=model_kwargs, sparse_attn=self.sparse_attn).eval()
+            self.pipe = SyntheticWanPipeline(transformer, seed=synthetic_seed)
+            if self.sparse_attn:
+                self.sparse_attn.config.current_steps_callback = lambda: self.pipe.scheduler_step_index
         elif architecture == "qwen":
             from fastdm_amd.pipeline import SyntheticQwenPipeline
             from fastdm_amd.synthetic import SyntheticQwenStateDict
@@ -240,7 +251,10 @@ class FastDMEngine:
 
     def generate(self, prompt=None, negative_prompt=None, src_image=None, num_frames=None, steps=50, guidance_scale=3.5,
                  true_cfg_scale=None, gen_seed=42, gen_width=512, gen_height=512, max_seq_len=512):
-        from fastdm_amd.pipeline import SyntheticFluxPipeline, SyntheticQwenPipeline
+        from fastdm_amd.pipeline import SyntheticFluxPipeline, SyntheticQwenPipeline, SyntheticWanPipeline
+        if isinstance(self.pipe, SyntheticWanPipeline):
+            return self.pipe(num_inference_steps=steps, guidance_scale=guidance_scale, width=gen_width, height=gen_height,
+                             num_frames=num_frames or 81, max_sequence_length=max_seq_len, seed=gen_seed)
         if isinstance(self.pipe, SyntheticQwenPipeline):
             return self.pipe(num_inference_steps=steps, true_cfg_scale=true_cfg_scale, width=gen_width, height=gen_height,
                              max_sequence_length=max_seq_len, seed=gen_seed)

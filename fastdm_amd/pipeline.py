@@ -130,3 +130,61 @@ class SyntheticQwenPipeline:
             lat = self.step(lat, inp, sigmas[i], sigmas[i + 1], true_cfg_scale)
         self.scheduler_step_index = None
         return lat
+
+
+class SyntheticWanPipeline:
+    """What diffusers' WanPipeline does around `pipe.transformer` for T2V with classifier-free guidance: latents
+    [B, 16, (frames-1)/4+1, H/8, W/8], `timestep = sigma * 1000`, a conditional and an unconditional forward per step,
+    `noise = uncond + guidance * (cond - uncond)`, flow-match Euler update (shift 5 for 720p-class outputs)."""
+
+    def __init__(self, transformer, seed: int = 0):
+        self.transformer = transformer
+        self.seed = seed
+        self.scheduler_step_index = None
+        self.num_steps = 0
+        self._inputs_key, self._inputs = None, None
+
+    def prepare(self, batch, height, width, num_frames, max_sequence_length, seed):
+        key = (batch, height, width, num_frames, max_sequence_length, seed)
+        if key != self._inputs_key:
+            cfg = self.transformer.model_config_dict
+            lf = (num_frames - 1) // 4 + 1
+            pos = synthetic.wan_step_inputs(batch, lf, height // 8, width // 8, max_sequence_length, cfg["in_channels"], cfg["text_dim"], seed=seed)
+            neg = synthetic.wan_step_inputs(batch, lf, height // 8, width // 8, max_sequence_length, cfg["in_channels"], cfg["text_dim"],
+                                            seed=seed + 7919)
+            pos["negative_encoder_hidden_states"] = neg["encoder_hidden_states"]
+            self._inputs, self._inputs_key = pos, key
+        return self._inputs
+
+    @staticmethod
+    def sigmas(num_steps: int, shift: float = 5.0):
+        s = np.linspace(1.0, 1.0 / num_steps, num_steps)
+        s = shift * s / (1.0 + (shift - 1.0) * s)
+        return np.concatenate([s, [0.0]]).astype(np.float32)
+
+    @torch.no_grad()
+    def step(self, latents, inp, sigma, sigma_next, guidance_scale):
+        t = torch.full((latents.shape[0],), float(sigma) * 1000.0, device=latents.device, dtype=torch.float32)
+        with self.transformer.cache_context("cond"):
+            cond = self.transformer(latents, timestep=t, encoder_hidden_states=inp["encoder_hidden_states"], return_dict=False)[0]
+        if guidance_scale is not None and guidance_scale > 1:
+            with self.transformer.cache_context("uncond"):
+                uncond = self.transformer(latents, timestep=t, encoder_hidden_states=inp["negative_encoder_hidden_states"], return_dict=False)[0]
+            noise = uncond.float() + guidance_scale * (cond.float() - uncond.float())
+        else:
+            noise = cond.float()
+        return (latents.float() + float(sigma_next - sigma) * noise).to(latents.dtype)
+
+    @torch.no_grad()
+    def __call__(self, num_inference_steps=40, guidance_scale=5.0, width=1280, height=768, num_frames=81, max_sequence_length=512, batch=1,
+                 seed=None, latents=None, **_):
+        seed = self.seed if seed is None else seed
+        inp = self.prepare(batch, height, width, num_frames, max_sequence_length, seed)
+        lat = inp["hidden_states"].clone() if latents is None else latents
+        sig = self.sigmas(num_inference_steps)
+        self.num_steps = num_inference_steps
+        for i in range(num_inference_steps):
+            self.scheduler_step_index = i
+            lat = self.step(lat, inp, sig[i], sig[i + 1], guidance_scale)
+        self.scheduler_step_index = None
+        return lat

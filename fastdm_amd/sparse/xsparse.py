@@ -135,12 +135,17 @@ class RadialAttn(SparseAttn):
 
     def apply(self, query, key, value, pre_defined_mask=None):
         """query/key/value: [tokens, heads, head_dim] (batch 1, as the reference's caller flattens it)."""
+        from fastdm_amd.kernel.timing import span
         assert pre_defined_mask is None, "the text-masked variant (HunyuanVideo) is not built"
         t, h, d = query.shape
         km = self.kernel_mask(t, query.device)
-        mask = km[None, None].expand(1, h, -1, -1).contiguous()
+        ck = ("expanded", t, h, str(query.device))
+        if ck not in self._masks:
+            self._masks[ck] = (km[None, None].expand(1, h, -1, -1).contiguous(), float(km.float().mean().item()))
+        mask, density = self._masks[ck]
         v = self.video_token_num
-        out = sparse_scaled_dot_product_attention(query[:v].reshape(1, v, h * d), key[:v].reshape(1, v, h * d), value[:v].reshape(1, v, h * d),
-                                                  num_q_heads=h, num_kv_heads=h, head_dim=d, is_causal=False, scale=1.0 / (d ** 0.5),
-                                                  sparse_mask=mask)
+        with span("attn_sparse_bf16", 4.0 * v * v * h * d * density):     # algorithmic work = the kept blocks only
+            out = sparse_scaled_dot_product_attention(query[:v].reshape(1, v, h * d), key[:v].reshape(1, v, h * d),
+                                                      value[:v].reshape(1, v, h * d), num_q_heads=h, num_kv_heads=h, head_dim=d,
+                                                      is_causal=False, scale=1.0 / (d ** 0.5), sparse_mask=mask)
         return out.reshape(v, h, d)

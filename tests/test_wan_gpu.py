@@ -187,3 +187,25 @@ def test_wan_block_sparse_path_against_oracle_definition():
     again = model(inp["hidden_states"].cuda(), timestep=torch.tensor([600.0]).cuda(), encoder_hidden_states=inp["encoder_hidden_states"].cuda(),
                   return_dict=False)[0]
     assert torch.equal(again, dense_prod)
+
+
+def test_engine_wan_synthetic_pipeline_cfg_and_sparse_steps(tmp_path):
+    """FastDMEngine(architecture='wan') without a checkpoint: CFG loop on synthetic weights; the radial config switches
+    from dense to block-sparse attention at `dense_steps` (driven by the pipeline's step index)."""
+    import json
+    from fastdm_amd.model_entry import FastDMEngine
+    cfg = OW.WanConfig(num_attention_heads=2, attention_head_dim=64, in_channels=16, out_channels=16, text_dim=96, ffn_dim=256, num_layers=2)
+    sp = tmp_path / "radial.json"
+    sp.write_text(json.dumps({"sparse_algorithm": "radial", "model_type": "wan", "block_size": 64, "enable_sparse": True, "decay_factor": 0.3,
+                              "dense_layers": 0, "dense_steps": 1}))
+    kw = dict(patch_size=cfg.patch_size, num_attention_heads=2, attention_head_dim=64, in_channels=16, out_channels=16, text_dim=96,
+              freq_dim=256, ffn_dim=256, num_layers=2, eps=1e-6, rope_max_seq_len=1024)
+    eng = FastDMEngine("", architecture="wan", use_fp8=True, kernel_backend="hip", sparse_attn_config=str(sp), **kw)
+    seen = []
+    orig = eng.sparse_attn.apply
+    eng.sparse_attn.apply = lambda **k: (seen.append(eng.pipe.scheduler_step_index), orig(**k))[1]
+    lat = eng.generate(steps=3, guidance_scale=5.0, gen_seed=2, gen_width=256, gen_height=128, num_frames=21, max_seq_len=9)
+    assert lat.shape == (1, 16, 6, 16, 32) and torch.isfinite(lat.float()).all()
+    assert seen and min(seen) == 1 and set(seen) == {1, 2}, seen          # step 0 dense, steps 1-2 sparse, every layer (dense_layers 0)
+    with pytest.raises(ValueError):
+        FastDMEngine("", architecture="flux", sparse_attn_config=str(sp))
