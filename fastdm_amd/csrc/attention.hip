@@ -73,11 +73,15 @@ __device__ __forceinline__ i32x4 tr_pair(const uint8_t* p0, const uint8_t* p1) {
   return r;
 }
 
-template <int D>
-__global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnParams p) {
+// NT threads = NT/64 waves of 32 query rows: 512 (256-row q-blocks, one block per CU: the dense path) or 256 (128-row
+// q-blocks = exactly one block-mask row, two blocks per CU: the block-sparse path, where the two halves of a 256-row
+// block would carry different masks and wait for each other).
+template <int D, int NT>
+__global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
+  constexpr int QBT = NT / 2;   // query rows per block
   constexpr int CPR = D / 8;
   constexpr int TILE_BYTES = KT * D * 2;               // one K or V tile
-  constexpr int LD_PER_THREAD = KT * CPR / ATT_THREADS;  // 16-B chunks per thread per tile (2 @128, 1 @64)
+  constexpr int LD_PER_THREAD = KT * CPR / NT;  // 16-B chunks per thread per tile (2 @128, 1 @64)
   constexpr int KSTEPS = D / 16;                        // QK^T k-steps
   constexpr int DT = D / 32;                            // 32-wide d tiles of O^T
   __shared__ __attribute__((aligned(1024))) uint8_t smem[4 * TILE_BYTES];
@@ -100,7 +104,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
   const int qb = j % p.n_qblocks;
   const int b = bh / p.heads, head = bh % p.heads;
   const int kvh = head / (p.heads / p.kv_heads);
-  const int64_t q0 = (int64_t)qb * QB;
+  const int64_t q0 = (int64_t)qb * QBT;
 
   const bf16_t* qbase = p.q + ((int64_t)b * p.sq) * p.q_ts + (int64_t)head * D;
   const bf16_t* kbase = p.k + ((int64_t)b * p.sk) * p.k_ts + (int64_t)kvh * D;
@@ -116,25 +120,51 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
     for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *reinterpret_cast<const i32x4*>(qp + 16 * ks);
   }
 
-  // ---- mask bookkeeping (wave-uniform)
+  // ---- block-mask bookkeeping.  Only the 4-wave instantiation (128-row q-blocks = one mask row) reads a mask; the
+  //      host never launches the 8-wave kernel with one.  The row's active KV tiles are compacted once into an LDS
+  //      list (wave 0, ballot + popcount), so the tile loop never chases mask bytes through global memory.
+  constexpr bool MASKED = (NT == 256);
+  constexpr int MAXL = MASKED ? 4096 : 1;
+  __shared__ uint16_t slist[MAXL];
+  __shared__ int s_nlist;
   const int ntiles = (int)((p.sk + KT - 1) / KT);
-  const int8_t* mrow0 = nullptr;
-  const int8_t* mrow1 = nullptr;
-  const int8_t* mrow_w = nullptr;
-  if (p.mask != nullptr) {
-    const int64_t mb = ((int64_t)b * p.heads + head) * p.mask_nq;
-    int r0 = (int)(q0 / p.mask_bq), r1 = (int)((q0 + 128) / p.mask_bq);
-    if (r1 > p.mask_nq - 1) r1 = p.mask_nq - 1;
-    mrow0 = p.mask + (mb + r0) * p.mask_nk;
-    mrow1 = p.mask + (mb + r1) * p.mask_nk;
-    mrow_w = (wave < 4) ? mrow0 : mrow1;
+  const int8_t* mrow = nullptr;
+  bool use_list = false;
+  if constexpr (MASKED) {
+    if (p.mask != nullptr) {
+      const int64_t mb = ((int64_t)b * p.heads + head) * p.mask_nq;
+      mrow = p.mask + (mb + (int)(q0 / p.mask_bq)) * p.mask_nk;
+      use_list = ntiles <= MAXL;
+      if (use_list) {
+        if (wave == 0) {
+          int cnt = 0;
+          for (int base = 0; base < ntiles; base += 64) {
+            const int tt = base + lane;
+            const bool act = tt < ntiles && mrow[(tt * KT) / p.mask_bk] != 0;
+            const unsigned long long bal = __ballot(act);
+            if (act) slist[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)tt;
+            cnt += __popcll(bal);
+          }
+          if (lane == 0) s_nlist = cnt;
+        }
+        __syncthreads();
+      }
+    }
   }
+  int lpos = 0;                                // position in the active list
+  const int n_list = use_list ? s_nlist : 0;
   auto tile_active = [&](int t) -> bool {
-    if (p.mask == nullptr) return true;
-    const int kb = (t * KT) / p.mask_bk;
-    return (mrow0[kb] | mrow1[kb]) != 0;
+    if constexpr (!MASKED) return true;
+    return mrow == nullptr || mrow[(t * KT) / p.mask_bk] != 0;
   };
+  // first active tile at or after t (list mode: the next list entry; the list is consumed in order)
   auto next_active = [&](int t) -> int {
+    if constexpr (MASKED) {
+      if (use_list) {
+        while (lpos < n_list && (int)slist[lpos] < t) ++lpos;
+        return lpos < n_list ? (int)slist[lpos] : ntiles;
+      }
+    }
     while (t < ntiles && !tile_active(t)) ++t;
     return t;
   };
@@ -144,7 +174,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
   auto issue_loads = [&](int t) {
 #pragma unroll
     for (int i = 0; i < LD_PER_THREAD; ++i) {
-      const int c = tid + i * ATT_THREADS;  // chunk id within the tile
+      const int c = tid + i * NT;  // chunk id within the tile
       const int row = c / CPR, ch = c % CPR;
       int64_t key = (int64_t)t * KT + row;
       if (key > p.sk - 1) key = p.sk - 1;
@@ -157,7 +187,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
     uint8_t* sv_ = sk_ + TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < LD_PER_THREAD; ++i) {
-      const int c = tid + i * ATT_THREADS;
+      const int c = tid + i * NT;
       const int row = c / CPR, ch = c % CPR;
       *reinterpret_cast<i32x4*>(sk_ + row * (D * 2) + Swz<D>::k(row, ch) * 16) = kreg[i];
       *reinterpret_cast<i32x4*>(sv_ + row * (D * 2) + Swz<D>::v(row, ch) * 16) = vreg[i];
@@ -292,9 +322,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
     const int tn = next_active(t + 1);
     if (tn < t_end) issue_loads(tn);
 
-    bool active = true;
-    if (p.mask != nullptr) active = mrow_w[(t * KT) / p.mask_bk] != 0;
-    if (active) process_tile(std::false_type{}, t);
+    process_tile(std::false_type{}, t);
     if (tn < t_end) write_lds(cur ^ 1);
     __syncthreads();
     cur ^= 1;
@@ -303,18 +331,14 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
     for (int d = 0; d < DT; ++d) vld[d] ^= 2 * TILE_BYTES;
     t = tn;
   }
-  if (t < t_end) {  // the partial tile is resident in buffer `cur`
-    bool active = true;
-    if (p.mask != nullptr) active = mrow_w[(t * KT) / p.mask_bk] != 0;
-    if (active) process_tile(std::true_type{}, t);
-  }
+  if (t < t_end) process_tile(std::true_type{}, t);  // the partial tile is resident in buffer `cur`
 
   // ---- finalize: l = own half + other half; O = O^T / l
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (is_part) {  // unnormalised partial: O (fp32), m, l -> workspace; attn_combine_kernel merges the parts
     const int64_t slot = (int64_t)(blockIdx.x - p.n_full);
     const int row = wave * 32 + lq;
-    float* wo = p.ws_o + (slot * QB + row) * D;
+    float* wo = p.ws_o + (slot * QBT + row) * D;
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -324,8 +348,8 @@ __global__ void __launch_bounds__(ATT_THREADS, 2) attn_fwd_kernel(const AttnPara
         *reinterpret_cast<f32x4*>(wo + 32 * d + 8 * g4 + 4 * h) = w;
       }
     if (h == 0) {
-      p.ws_ml[(slot * QB + row) * 2] = m_run;
-      p.ws_ml[(slot * QB + row) * 2 + 1] = l_tot;
+      p.ws_ml[(slot * QBT + row) * 2] = m_run;
+      p.ws_ml[(slot * QBT + row) * 2 + 1] = l_tot;
     }
     return;
   }
@@ -422,7 +446,8 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
   p.batch = (int)batch;
   p.heads = q_heads;
   p.kv_heads = kv_heads;
-  p.n_qblocks = (int)((sq + QB - 1) / QB);
+  const int qb_rows = block_mask != nullptr ? 128 : QB;   // block-sparse: 4-wave blocks, one mask row each
+  p.n_qblocks = (int)((sq + qb_rows - 1) / qb_rows);
   p.mask_bq = p.mask_bk = 1;
   p.mask_nq = p.mask_nk = 0;
   if (block_mask != nullptr) {
@@ -479,8 +504,13 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
       }
     }
   }
-  if (head_dim == 128) attn_fwd_kernel<128><<<(unsigned)grid, ATT_THREADS, 0, s>>>(p);
-  else attn_fwd_kernel<64><<<(unsigned)grid, ATT_THREADS, 0, s>>>(p);
+  if (block_mask != nullptr) {
+    if (head_dim == 128) attn_fwd_kernel<128, 256><<<(unsigned)grid, 256, 0, s>>>(p);
+    else attn_fwd_kernel<64, 256><<<(unsigned)grid, 256, 0, s>>>(p);
+  } else {
+    if (head_dim == 128) attn_fwd_kernel<128, 512><<<(unsigned)grid, 512, 0, s>>>(p);
+    else attn_fwd_kernel<64, 512><<<(unsigned)grid, 512, 0, s>>>(p);
+  }
   FDM_CHECK_LAUNCH();
   if (n_tail > 0) {
     const int64_t threads = (int64_t)n_tail * QB * (head_dim / 8);
