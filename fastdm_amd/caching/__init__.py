@@ -1,2 +1,2 @@
-from .config import CacheConfig, TeaCacheConfig  # noqa: F401
-from .xcaching import AutoCache, TeaCache  # noqa: F401
+from .config import CacheConfig, FBCacheConfig, TeaCacheConfig  # noqa: F401
+from .xcaching import AutoCache, FBCache, TeaCache  # noqa: F401

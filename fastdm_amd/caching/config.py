@@ -49,3 +49,11 @@ class CacheConfig:
 class TeaCacheConfig(CacheConfig):
     coefficients: List[float] = field(default_factory=list)
     negtive_coefficients: List[float] = field(default_factory=list)
+
+
+@CacheConfig.register("fbcache")
+@dataclass
+class FBCacheConfig(CacheConfig):
+    """fastdm/caching/config.py:69-72.  (The shipped JSONs spell the key 'wamup_steps', which the loader drops: they run
+    with the default of 6.)"""
+    warmup_steps: int = 6

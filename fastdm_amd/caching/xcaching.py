@@ -68,6 +68,13 @@ class AutoCache:
             self.cache_status[k] = not self.cache_status[k]
         return cache_key
 
+    def rel_distance(self, modulated, previous) -> float:
+        """mean|a - b| / mean|b| with the reference's bf16 roundings (xcaching.py:214-215,343-344); one D2H sync."""
+        sums = fused.absdiff_sums(modulated.contiguous(), previous.contiguous()).cpu()
+        n = float(modulated.numel())
+        mean_diff, mean_prev = _bf16(float(sums[0]) / n), _bf16(float(sums[1]) / n)
+        return _bf16(mean_diff / mean_prev)
+
     def apply_cache(self, *args, **kwargs):
         raise NotImplementedError("Subclasses must implement apply_cache method")
 
@@ -86,12 +93,6 @@ class TeaCache(AutoCache):
         if model_type not in ("flux", "sd35"):
             raise ValueError(f"TeaCache unsupported model type: {model_type}. Supported types: qwenimage, flux")
         return transformer_blocks[0].norm1.forward(hidden_states, emb=temb)[0]
-
-    def rel_distance(self, modulated, previous) -> float:
-        sums = fused.absdiff_sums(modulated.contiguous(), previous.contiguous()).cpu()     # the one D2H sync per step
-        n = float(modulated.numel())
-        mean_diff, mean_prev = _bf16(float(sums[0]) / n), _bf16(float(sums[1]) / n)
-        return _bf16(mean_diff / mean_prev)
 
     def apply_cache(self, model_type: str, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
                     temb: torch.Tensor = None, image_rotary_emb: torch.Tensor = None, attention_kwargs: Optional[Dict[str, Any]] = None,
@@ -120,4 +121,46 @@ class TeaCache(AutoCache):
         ori_hidden_states = hidden_states.clone()     # the fused blocks update the residual stream in place
         out = core.run_blocks(hidden_states, encoder_hidden_states, temb, image_rotary_emb, attention_kwargs)
         self.previous_residual_dict[cache_key] = out - ori_hidden_states
+        return out
+
+
+@AutoCache.register("fbcache")
+class FBCache(AutoCache):
+    """First-block cache (xcaching.py:279-403): block 0 always runs; if its output moved little since the last computed
+    step (accumulated relative L1 below the threshold, after `warmup_steps`), the remaining blocks are skipped and the
+    cached residual `out - in` of the last full evaluation is added instead."""
+
+    def apply_cache(self, model_type: str, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
+                    encoder_hidden_states_mask=None, temb: torch.Tensor = None, image_rotary_emb: torch.Tensor = None,
+                    attention_kwargs: Optional[Dict[str, Any]] = None, transformer_blocks=None, single_transformer_blocks=None,
+                    core=None, **_):
+        if model_type not in ("flux", "qwenimage"):
+            raise ValueError(f"FBCache unsupported model type: {model_type}. Supported types: qwenimage, flux")
+        current_step = self.get_current_step()
+        kw = dict(hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states, temb=temb, image_rotary_emb=image_rotary_emb,
+                  joint_attention_kwargs=attention_kwargs)
+        if model_type == "qwenimage":
+            kw["encoder_hidden_states_mask"] = encoder_hidden_states_mask
+        first_encoder, first_hidden = transformer_blocks[0].forward(**kw)     # returns fresh tensors: the inputs stay intact
+        cache_key = self.get_cache_key()
+        prev = self.previous_modulated_input_dict[cache_key]
+        rel = None
+        if current_step <= self.config.warmup_steps or prev is None:
+            should_calc = True
+            self.accumulated_rel_l1_distance_dict[cache_key] = 0
+        else:
+            rel = self.rel_distance(first_hidden, prev)
+            self.accumulated_rel_l1_distance_dict[cache_key] += rel
+            if self.accumulated_rel_l1_distance_dict[cache_key] < self.config.threshold:
+                should_calc = False
+            else:
+                should_calc = True
+                self.accumulated_rel_l1_distance_dict[cache_key] = 0
+        self.trace.append((current_step, rel, float(self.accumulated_rel_l1_distance_dict[cache_key]), should_calc, cache_key))
+        self.previous_modulated_input_dict[cache_key] = first_hidden.clone()   # later blocks update the stream in place
+        if not should_calc:
+            return hidden_states + self.previous_residual_dict[cache_key]
+        out = core.run_blocks(first_hidden, first_encoder, temb, image_rotary_emb, attention_kwargs, start_block=1,
+                              encoder_hidden_states_mask=encoder_hidden_states_mask)
+        self.previous_residual_dict[cache_key] = out - hidden_states
         return out

@@ -216,9 +216,10 @@ class FluxTransformer2DModelCore(BaseModelCore):
         return self._rope_val
 
     def run_blocks(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb, joint_attention_kwargs=None,
-                   controlnet_block_samples=None, controlnet_single_block_samples=None):
+                   controlnet_block_samples=None, controlnet_single_block_samples=None, start_block: int = 0, **_):
+        """Double blocks [start_block:], then all single blocks (start_block = 1: FBCache already ran block 0)."""
         assert controlnet_block_samples is None and controlnet_single_block_samples is None, "ControlNet residuals are out of scope"
-        for block in self.transformer_blocks:
+        for block in self.transformer_blocks[start_block:]:
             encoder_hidden_states, hidden_states = block.forward(hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states,
                                                                  temb=temb, image_rotary_emb=image_rotary_emb,
                                                                  joint_attention_kwargs=joint_attention_kwargs)

@@ -150,8 +150,8 @@ class QwenImageTransformer2DModelCore(BaseModelCore):
         return self._rope_val
 
     def run_blocks(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb, attention_kwargs=None,
-                   encoder_hidden_states_mask=None, **_):
-        for block in self.transformer_blocks:
+                   encoder_hidden_states_mask=None, start_block: int = 0, **_):
+        for block in self.transformer_blocks[start_block:]:
             encoder_hidden_states, hidden_states = block.forward(hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states,
                                                                  encoder_hidden_states_mask=encoder_hidden_states_mask, temb=temb,
                                                                  image_rotary_emb=image_rotary_emb, joint_attention_kwargs=attention_kwargs)

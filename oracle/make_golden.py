@@ -474,6 +474,59 @@ def gen_tiny_wan():
     save("wan_radial_mask.npz", m)
 
 
+def gen_fbcache():
+    """FBCache decisions + final latents on the tiny FLUX core (bf16) and the tiny Qwen-Image core (int8) over 12-step
+    trajectories, driven through the reference's AutoCache exactly like gen_teacache."""
+    import_reference()
+    use_backend("torch")
+    from fastdm.caching.xcaching import AutoCache
+    from oracle import flux as OF, qwen as OQ
+    import contextlib
+    import io
+    d = {"threshold": 0.41, "warmup_steps": 2}     # threshold with the widest decision margins on these trajectories
+    state = {"step": 0}
+    sig = torch.linspace(1.0, 1.0 / 12, 12)
+    # ---- FLUX
+    cfg = OF.TINY
+    sd = OF.synth_state_dict(cfg, seed=7)
+    inp = OF.synth_inputs(cfg, batch=1, img_h=4, img_w=6, n_txt=8, seed=9)
+    cache = AutoCache.from_dict({"cache_algorithm": "fbcache", "enable_caching": True, "threshold": 0.41, "warmup_steps": 2})
+    cache.config.current_steps_callback = lambda: state["step"]
+    core = ref_flux_core(cfg, None, sd, cache=cache)
+    lat, dec = inp["hidden_states"].clone(), []
+    for i in range(12):
+        state["step"] = i
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            out = core.forward(hidden_states=lat, encoder_hidden_states=inp["encoder_hidden_states"], pooled_projections=inp["pooled_projections"],
+                               timestep=sig[i:i + 1], img_ids=inp["img_ids"], txt_ids=inp["txt_ids"], guidance=torch.tensor([3.5]))[0]
+        dec.append(0 if "Skipping" in buf.getvalue() else 1)
+        dt = (sig[i + 1] - sig[i]) if i + 1 < 12 else -sig[i]
+        lat = (lat.float() + dt * out.float()).to(torch.bfloat16)
+    d["flux_should_calc"], d["flux_final"] = np.array(dec, dtype=np.int8), lat
+    # ---- Qwen-Image (single forward per step, int8)
+    qcfg = OQ.TINY
+    qsd = OQ.synth_state_dict(qcfg, seed=11)
+    qin = OQ.synth_inputs(qcfg, batch=1, img_h=6, img_w=4, n_txt=7, seed=12)
+    cache = AutoCache.from_dict({"cache_algorithm": "fbcache", "enable_caching": True, "threshold": 0.41, "warmup_steps": 2})
+    cache.config.current_steps_callback = lambda: state["step"]
+    core = ref_qwen_core(qcfg, torch.int8, qsd, cache=cache)
+    lat, dec = qin["hidden_states"].clone(), []
+    for i in range(12):
+        state["step"] = i
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            out = core.forward(hidden_states=lat, encoder_hidden_states=qin["encoder_hidden_states"],
+                               encoder_hidden_states_mask=qin["encoder_hidden_states_mask"], timestep=sig[i:i + 1],
+                               img_shapes=qin["img_shapes"], txt_seq_lens=qin["txt_seq_lens"])[0]
+        dec.append(0 if "Skipping" in buf.getvalue() else 1)
+        dt = (sig[i + 1] - sig[i]) if i + 1 < 12 else -sig[i]
+        lat = (lat.float() + dt * out.float()[..., : qcfg.in_channels]).to(torch.bfloat16)
+    d["qwen_should_calc"], d["qwen_final"] = np.array(dec, dtype=np.int8), lat
+    print("flux decisions", d["flux_should_calc"].tolist(), "qwen decisions", d["qwen_should_calc"].tolist())
+    save("fbcache.npz", d)
+
+
 # ------------------------------------------------------------------ full-width C3 fixture
 def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=0, sub=64):
     """Full-width FLUX.1-dev at 1024x2048 (S = 8192 + 512) through the reference's own block
@@ -568,7 +621,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "c3"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "c3"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     args = ap.parse_args()
@@ -585,6 +638,8 @@ def main():
         gen_tiny_qwen()
     if args.what in ("small", "wan"):
         gen_tiny_wan()
+    if args.what in ("small", "fbcache"):
+        gen_fbcache()
     if args.what == "qwen_full":
         gen_qwen_full()
     if args.what == "c3":

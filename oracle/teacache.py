@@ -116,3 +116,58 @@ class TeaCacheQwen:
         out = core.run_blocks(hidden, encoder, temb, rope)
         self.prev_residual[key] = out - hidden
         return out
+
+
+class FBCacheOracle:
+    """fastdm/caching/xcaching.py:279-403 (FLUX and Qwen-Image branches, single cache key): block 0 always runs; after
+    `warmup_steps` the remaining blocks are skipped while the accumulated relative L1 change of block 0's output stays
+    below the threshold (no polynomial rescale)."""
+
+    def __init__(self, threshold: float, warmup_steps: int, current_steps_callback):
+        self.threshold, self.warmup_steps, self.cb = threshold, warmup_steps, current_steps_callback
+        self.acc = 0.0
+        self.prev = None
+        self.prev_residual = None
+        self.trace = []
+        self.config = type("Cfg", (), {"enable_caching": True})()
+
+    def _decide(self, first_hidden):
+        step = self.cb()
+        step = 0 if step is None else step
+        rel = None
+        if step <= self.warmup_steps or self.prev is None:
+            calc, self.acc = True, 0
+        else:
+            rel = ((first_hidden - self.prev).abs().mean() / self.prev.abs().mean()).cpu().item()
+            self.acc += rel
+            if self.acc < self.threshold:
+                calc = False
+            else:
+                calc, self.acc = True, 0
+        self.trace.append((step, rel, float(self.acc), calc))
+        self.prev = first_hidden.clone()
+        return calc
+
+    def apply_cache(self, core, hidden, encoder, temb, rope):          # FLUX core
+        enc1, hid1 = core.transformer_blocks[0](hidden, encoder, temb, rope)
+        if not self._decide(hid1):
+            return hidden + self.prev_residual
+        for blk in core.transformer_blocks[1:]:
+            enc1, hid1 = blk(hid1, enc1, temb, rope)
+        n_txt = enc1.shape[1]
+        import torch
+        x = torch.cat([enc1, hid1], dim=1)
+        for blk in core.single_transformer_blocks:
+            x = blk(x, temb, rope)
+        out = x[:, n_txt:]
+        self.prev_residual = out - hidden
+        return out
+
+    def apply_cache_qwen(self, core, hidden, encoder, temb, rope):     # Qwen-Image core
+        enc1, hid1 = core.transformer_blocks[0](hidden, encoder, temb, rope)
+        if not self._decide(hid1):
+            return hidden + self.prev_residual
+        for blk in core.transformer_blocks[1:]:
+            enc1, hid1 = blk(hid1, enc1, temb, rope)
+        self.prev_residual = hid1 - hidden
+        return hid1

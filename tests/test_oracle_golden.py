@@ -278,3 +278,51 @@ def test_wan_sparse_oracle_reduces_to_dense_with_full_mask():
     sp = OW.WanCore(sd, cfg, None, sparse=(AllOnes(64, 0.3), 0, 0, None)).forward(inp["hidden_states"], torch.tensor([700.0]),
                                                                                    inp["encoder_hidden_states"])[0]
     assert torch.equal(dense, sp)
+
+
+# ------------------------------------------------------------------ FBCache (fastdm/caching/xcaching.py:279-403)
+def _fb_traj(core_forward, lat, n_out, steps=12):
+    sig = torch.linspace(1.0, 1.0 / steps, steps)
+    for i in range(steps):
+        out = core_forward(i, lat, sig[i:i + 1])
+        dt = (sig[i + 1] - sig[i]) if i + 1 < steps else -sig[i]
+        lat = (lat.float() + dt * out.float()[..., :n_out]).to(torch.bfloat16)
+    return lat
+
+
+def test_fbcache_trace_flux_and_qwen():
+    from oracle import qwen as OQ
+    g = load("fbcache.npz")
+    state = {"step": 0}
+    # FLUX, bf16
+    cfg = OF.TINY
+    sd = OF.synth_state_dict(cfg, seed=7)
+    inp = OF.synth_inputs(cfg, 1, 4, 6, 8, seed=9)
+    cache = TC.FBCacheOracle(float(g["threshold"]), int(g["warmup_steps"]), lambda: state["step"])
+    core = OF.FluxCore(sd, cfg, None, cache=cache)
+
+    def fwd(i, lat, t):
+        state["step"] = i
+        return core.forward(hidden_states=lat, encoder_hidden_states=inp["encoder_hidden_states"], pooled_projections=inp["pooled_projections"],
+                            timestep=t, img_ids=inp["img_ids"], txt_ids=inp["txt_ids"], guidance=torch.tensor([3.5]))[0]
+    lat = _fb_traj(fwd, inp["hidden_states"].clone(), cfg.out_channels)
+    want = [int(x) for x in g["flux_should_calc"]]
+    assert 0 in want and [int(t[3]) for t in cache.trace] == want, cache.trace
+    d = (lat.float() - g["flux_final"].float()).abs()
+    assert d.max() <= 6e-2 and d.mean() <= 8e-3, (d.max().item(), d.mean().item())
+    # Qwen-Image, int8
+    qcfg = OQ.TINY
+    qsd = OQ.synth_state_dict(qcfg, seed=11)
+    qin = OQ.synth_inputs(qcfg, 1, 6, 4, 7, seed=12)
+    cache = TC.FBCacheOracle(float(g["threshold"]), int(g["warmup_steps"]), lambda: state["step"])
+    qcore = OQ.QwenCore(qsd, qcfg, torch.int8, cache=cache)
+
+    def qfwd(i, lat, t):
+        state["step"] = i
+        return qcore.forward(hidden_states=lat, encoder_hidden_states=qin["encoder_hidden_states"], timestep=t,
+                             img_shapes=qin["img_shapes"], txt_seq_lens=qin["txt_seq_lens"])[0]
+    lat = _fb_traj(qfwd, qin["hidden_states"].clone(), qcfg.in_channels)
+    want = [int(x) for x in g["qwen_should_calc"]]
+    assert 0 in want and [int(t[3]) for t in cache.trace] == want, cache.trace
+    d = (lat.float() - g["qwen_final"].float()).abs()
+    assert d.max() <= 6e-2 and d.mean() <= 8e-3, (d.max().item(), d.mean().item())
