@@ -169,28 +169,31 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
     return t;
   };
 
-  // ---- staging registers
-  i32x4 kreg[LD_PER_THREAD], vreg[LD_PER_THREAD];
-  auto issue_loads = [&](int t) {
+  // ---- K/V staging by LDS-DMA (global_load_lds, 16 B per lane).  A wave-instruction writes 64 consecutive 16-byte
+  //      slots, so the destination is linear: thread t, round i fills slot p = i*NT + t = (row p / CPR, position p % CPR);
+  //      the swizzle is applied on the SOURCE side (the slot at position pos of row r holds chunk pos ^ swz(r); both
+  //      swizzles are XOR involutions).  No staging VGPRs, no ds_write.
+  int srow[LD_PER_THREAD];
+  int64_t koff[LD_PER_THREAD], voff[LD_PER_THREAD];
 #pragma unroll
-    for (int i = 0; i < LD_PER_THREAD; ++i) {
-      const int c = tid + i * NT;  // chunk id within the tile
-      const int row = c / CPR, ch = c % CPR;
-      int64_t key = (int64_t)t * KT + row;
-      if (key > p.sk - 1) key = p.sk - 1;
-      kreg[i] = *reinterpret_cast<const i32x4*>(kbase + key * p.k_ts + ch * 8);
-      vreg[i] = *reinterpret_cast<const i32x4*>(vbase + key * p.v_ts + ch * 8);
-    }
-  };
-  auto write_lds = [&](int buf) {
-    uint8_t* sk_ = smem + buf * 2 * TILE_BYTES;
+  for (int i = 0; i < LD_PER_THREAD; ++i) {
+    const int pslot = tid + i * NT;
+    srow[i] = pslot / CPR;
+    const int pos = pslot % CPR;
+    koff[i] = (int64_t)Swz<D>::k(srow[i], pos) * 8;
+    voff[i] = (int64_t)Swz<D>::v(srow[i], pos) * 8;
+  }
+  auto stage_tile = [&](int t, int buf) {
+    uint8_t* sk_ = smem + buf * 2 * TILE_BYTES + wave * 1024;
     uint8_t* sv_ = sk_ + TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < LD_PER_THREAD; ++i) {
-      const int c = tid + i * NT;
-      const int row = c / CPR, ch = c % CPR;
-      *reinterpret_cast<i32x4*>(sk_ + row * (D * 2) + Swz<D>::k(row, ch) * 16) = kreg[i];
-      *reinterpret_cast<i32x4*>(sv_ + row * (D * 2) + Swz<D>::v(row, ch) * 16) = vreg[i];
+      int64_t key = (int64_t)t * KT + srow[i];
+      if (key > p.sk - 1) key = p.sk - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + key * p.k_ts + koff[i]),
+                                       (__attribute__((address_space(3))) void*)(sk_ + i * (NT * 16)), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + key * p.v_ts + voff[i]),
+                                       (__attribute__((address_space(3))) void*)(sv_ + i * (NT * 16)), 16, 0, 0);
     }
   };
 
@@ -309,21 +312,19 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
   const int t_end = is_part ? (int)((int64_t)(part + 1) * ntiles / p.split) : ntiles;
   int t = next_active(t_begin);
   int cur = 0;
-  if (t < t_end) {
-    issue_loads(t);
-    write_lds(0);
-  }
-  __syncthreads();
+  if (t < t_end) stage_tile(t, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs (and its Q loads) have landed ...
+  __syncthreads();                                    // ... and everybody's
 
   // Full tiles run the TAIL=false body in the loop; a partial last tile (sk % 64 != 0) is handled once, after
   // the loop, by the masked body (keeping both bodies inside the loop costs > 90 VGPRs on this compiler).
   const int n_main = (p.sk % KT == 0 || t_end < ntiles) ? t_end : ntiles - 1;
   while (t < n_main) {
     const int tn = next_active(t + 1);
-    if (tn < t_end) issue_loads(tn);
+    if (tn < t_end) stage_tile(tn, cur ^ 1);    // the other buffer was last read before the previous barrier
 
     process_tile(std::false_type{}, t);
-    if (tn < t_end) write_lds(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
     kld0 ^= 2 * TILE_BYTES;

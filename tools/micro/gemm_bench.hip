@@ -3,6 +3,7 @@
 //   tools/micro/gemm_bench.hip -o tools/micro/gemm_bench[_variant] [-DFDM_...]
 #include "../../fastdm_amd/csrc/gemm.hip"
 #include <cstdio>
+#include <cstring>
 namespace fdm { int g_last_hip_error = 0; }
 #include <vector>
 
@@ -54,10 +55,15 @@ int main(int argc, char** argv) {
   hipMalloc(&fdm::g_gemm_stamps, 2048 * 4 * 8);
   hipMemset(fdm::g_gemm_stamps, 0, 2048 * 4 * 8);
 #endif
+  const bool use_int8 = getenv("GEMM_DT") && !strcmp(getenv("GEMM_DT"), "int8");
+  int32_t *azp, *azp_adj;
+  hipMalloc(&azp, 8704 * 4); hipMalloc(&azp_adj, 12288 * 4);
+  hipMemset(azp, 0, 8704 * 4); hipMemset(azp_adj, 1, 12288 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   double tot = 0;
   for (auto& s : shapes) {
     auto run = [&]() {
+      if (use_int8) return fdm_gemm_w8a8_int8(C, A, B, sa, sb, azp_adj, azp, bias, s.M, s.N, s.K, s.K, s.K, s.N, s.epi, G, s.N, R, s.M, nullptr);
       return fdm_gemm_w8a8_fp8(C, A, B, sa, sb, bias, s.M, s.N, s.K, s.K, s.K, s.N, s.epi, G, s.N, R, s.M, nullptr);
     };
     for (int i = 0; i < 3; ++i) if (run() != 0) { printf("launch failed\n"); return 1; }
