@@ -29,7 +29,8 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int ATT_THREADS = FDM_ATT_THREADS;
 constexpr int QB = ATT_THREADS / 2;  // query rows per block: 32 per wave
-constexpr int KT = 64;   // keys per tile
+constexpr int KT_MASK = 64;   // keys per tile on the block-mask path (= the mask's key granularity)
+constexpr int KT_DENSE = 128;
 
 struct AttnParams {
   bf16_t* o;
@@ -76,8 +77,10 @@ __device__ __forceinline__ i32x4 tr_pair(const uint8_t* p0, const uint8_t* p1) {
 // NT threads = NT/64 waves of 32 query rows: 512 (256-row q-blocks, one block per CU: the dense path) or 256 (128-row
 // q-blocks = exactly one block-mask row, two blocks per CU: the block-sparse path, where the two halves of a 256-row
 // block would carry different masks and wait for each other).
-template <int D, int NT>
+template <int D, int NT, int KTT>
 __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
+  constexpr int KT = KTT;        // keys per tile: 128 on the dense path (half the barriers and DMA waits), 64 with a block mask
+  constexpr int NKT = KT / 32;   // 32-key S^T tiles per KV tile
   constexpr int QBT = NT / 2;   // query rows per block
   constexpr int CPR = D / 8;
   constexpr int TILE_BYTES = KT * D * 2;               // one K or V tile
@@ -221,17 +224,17 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
   auto process_tile = [&](auto tail_c, int t) {
     constexpr bool TAIL = decltype(tail_c)::value;
     // ---- S^T = K . Q^T  (two 32-key tiles)
-    f32x16 sacc[2];
+    f32x16 sacc[NKT];
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2)
+    for (int kt2 = 0; kt2 < NKT; ++kt2)
 #pragma unroll
       for (int e = 0; e < 16; ++e) sacc[kt2][e] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const i32x4 qfr = qf[ks];
 #pragma unroll
-      for (int kt2 = 0; kt2 < 2; ++kt2) {
+      for (int kt2 = 0; kt2 < NKT; ++kt2) {
         const i32x4 kf = *reinterpret_cast<const i32x4*>(smem + (kld0 ^ (uint32_t)(ks << 5)) + kt2 * 32 * ROWB);
         sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qfr),
                                                             sacc[kt2], 0, 0, 0);
@@ -241,7 +244,7 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
     if constexpr (TAIL) {
       const int rem = (int)(p.sk - (int64_t)t * KT) - 4 * h;  // keys of this tile that exist, shifted by the lane-half offset
 #pragma unroll
-      for (int kt2 = 0; kt2 < 2; ++kt2)
+      for (int kt2 = 0; kt2 < NKT; ++kt2)
 #pragma unroll
         for (int e = 0; e < 16; ++e)
           if (kt2 * 32 + (e & 3) + 8 * (e >> 2) >= rem) sacc[kt2][e] = -INFINITY;
@@ -253,10 +256,9 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
     // front of every fmaxf on an MFMA result -- 19 instead of 56 VALU instructions per tile)
     float mx = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
-    for (int e = 1; e < 16; ++e) {
-      mx = __builtin_amdgcn_fmed3f(mx, sacc[0][e], __builtin_inff());
-      mx = __builtin_amdgcn_fmed3f(mx, sacc[1][e], __builtin_inff());
-    }
+    for (int kt2 = 0; kt2 < NKT; ++kt2)
+#pragma unroll
+      for (int e = (kt2 < 2 ? 1 : 0); e < 16; ++e) mx = __builtin_amdgcn_fmed3f(mx, sacc[kt2][e], __builtin_inff());
     {
       const int mi = __builtin_bit_cast(int, mx);
       const auto sw = __builtin_amdgcn_permlane32_swap(mi, mi, false, false);  // both halves of the query row
@@ -274,9 +276,9 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
         for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
     }
     float psum = 0.f;
-    i32x4 pf[2][2];
+    i32x4 pf[NKT][2];
 #pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2) {
+    for (int kt2 = 0; kt2 < NKT; ++kt2) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt2][e], p.scale_log2e, -m_run));
@@ -292,7 +294,7 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
     // ---- O^T += V^T . P^T
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2)
+    for (int kt2 = 0; kt2 < NKT; ++kt2)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -478,7 +480,8 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
       num_cu = cu * (512 / ATT_THREADS);  // concurrent work-item slots on the chip
     }
     const int rem = (int)(grid % num_cu);
-    const int ntiles = (int)((sk + KT - 1) / KT);
+    const int kt_dense = head_dim == 128 ? KT_DENSE : KT_MASK;
+    const int ntiles = (int)((sk + kt_dense - 1) / kt_dense);
     if (rem > 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
       // time of the last round in units of one whole item: ceil(rem*S / CUs) rounds of 1/S-sized parts, plus a
       // per-part overhead (Q load, prologue, fp32 partial write + merge) priced at 2% of an item
@@ -506,11 +509,11 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
     }
   }
   if (block_mask != nullptr) {
-    if (head_dim == 128) attn_fwd_kernel<128, 256><<<(unsigned)grid, 256, 0, s>>>(p);
-    else attn_fwd_kernel<64, 256><<<(unsigned)grid, 256, 0, s>>>(p);
+    if (head_dim == 128) attn_fwd_kernel<128, 256, KT_MASK><<<(unsigned)grid, 256, 0, s>>>(p);
+    else attn_fwd_kernel<64, 256, KT_MASK><<<(unsigned)grid, 256, 0, s>>>(p);
   } else {
-    if (head_dim == 128) attn_fwd_kernel<128, 512><<<(unsigned)grid, 512, 0, s>>>(p);
-    else attn_fwd_kernel<64, 512><<<(unsigned)grid, 512, 0, s>>>(p);
+    if (head_dim == 128) attn_fwd_kernel<128, 512, KT_DENSE><<<(unsigned)grid, 512, 0, s>>>(p);
+    else attn_fwd_kernel<64, 512, KT_MASK><<<(unsigned)grid, 512, 0, s>>>(p);    // head_dim 64: 64-key tiles measured faster
   }
   FDM_CHECK_LAUNCH();
   if (n_tail > 0) {

@@ -311,7 +311,9 @@ def test_sparse_attention_masks(K):
     ones = torch.ones(B, H, nq, nk, dtype=torch.int8)
     dense = K.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5)
     sp = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=ones.cuda())
-    assert torch.equal(dense, sp)
+    # the dense path walks 128-key tiles, the masked path 64-key tiles: same math, different online-softmax grouping
+    torch.testing.assert_close(sp, dense, rtol=0.0, atol=2.0 ** -7)
+    assert (sp.float() - dense.float()).abs().mean().item() < 2e-4
     band = torch.zeros(B, H, nq, nk, dtype=torch.int8)
     for i in range(nq):
         for j in range(nk):
