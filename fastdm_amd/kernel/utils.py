@@ -1,36 +1,41 @@
-"""Host-side helpers with the reference's names (fastdm/kernel/utils.py:11-45)."""
+"""Backend selection and the two test/benchmark helpers the reference keeps next to its kernels
+(fastdm/kernel/utils.py:11-45), under the same names.
+
+There is exactly one backend in this package: the hand-written gfx950 HIP library.  "cuda" is accepted as an alias so
+that existing `--kernel-backend cuda` command lines keep working; "torch" and "triton" are refused (no fallbacks)."""
 import os
 import time
-from typing import Callable
+from typing import Callable, List, Optional, Tuple
 
 import torch
 
-_BACKENDS = ("hip", "cuda")  # "cuda" is accepted so unchanged gen.py invocations work; both mean the HIP library
+_ALIASES = {"hip": "hip", "cuda": "hip"}
 
 
-def set_global_backend(backend: str):
-    """fastdm/kernel/utils.py:11-15.  There is exactly one backend here (hand-written gfx950 HIP)."""
-    if backend not in _BACKENDS:
+def set_global_backend(backend: str) -> None:
+    chosen = _ALIASES.get(backend)
+    if chosen is None:
         raise ValueError(f"Unsupported backend: {backend}. Available backends: hip (alias: cuda).")
-    os.environ["KERNEL_BACKEND"] = "hip"
+    os.environ["KERNEL_BACKEND"] = chosen
 
 
-def get_available_backends(op_name: str) -> list:
-    return ["hip"]
+def get_available_backends(op_name: str) -> List[str]:
+    return sorted(set(_ALIASES.values()))
 
 
-def benchmark_kernel(op_name: str, impl_func: Callable, iterations: int = 50, *args, **kwargs):
-    """fastdm/kernel/utils.py:17-34: 3 warm-ups, `iterations` timed calls between device syncs."""
+def benchmark_kernel(op_name: str, impl_func: Callable, iterations: int = 50, *args, **kwargs) -> Tuple[float, object]:
+    """Mean seconds per call over `iterations` calls (after three warm-ups), and the last result."""
+    result = None
     for _ in range(3):
-        impl_func(*args, **kwargs)
+        result = impl_func(*args, **kwargs)
     torch.cuda.synchronize()
-    start = time.perf_counter()
+    t0 = time.perf_counter()
     for _ in range(iterations):
         result = impl_func(*args, **kwargs)
     torch.cuda.synchronize()
-    return (time.perf_counter() - start) / iterations, result
+    return (time.perf_counter() - t0) / max(iterations, 1), result
 
 
-def kernel_output_assert_close(actual: torch.Tensor, expected: torch.Tensor, rtol: float = None, atol: float = None):
-    """fastdm/kernel/utils.py:36-45."""
+def kernel_output_assert_close(actual: torch.Tensor, expected: torch.Tensor, rtol: Optional[float] = None,
+                               atol: Optional[float] = None) -> None:
     torch.testing.assert_close(actual, expected.to(actual.dtype), rtol=rtol, atol=atol)

@@ -1,0 +1,1 @@
+"""fastdm_amd sub-package (mirrors the reference package layout so import paths carry over)."""
