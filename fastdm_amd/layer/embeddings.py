@@ -250,3 +250,34 @@ class WanTimeTextImageEmbedding:
         temb = self.time_embedder.forward(ts).type_as(encoder_hidden_states)
         timestep_proj = self.time_proj.forward(F.silu(temb))
         return temb, timestep_proj, self.text_embedder.forward(encoder_hidden_states), None
+
+
+class PatchEmbed:
+    """embeddings.py:270-360 as SD3 uses it: 2x2 patches (a convolution with kernel == stride, i.e. a GEMM over
+    non-overlapping patches) plus the centre crop of a learned [max, max] positional table (`pos_embed_max_size`)."""
+
+    def __init__(self, height=224, width=224, patch_size=16, in_channels=3, embed_dim=768, layer_norm=False, flatten=True, bias=True,
+                 interpolation_scale=1, pos_embed_type="sincos", pos_embed_max_size=None, data_type=BF16):
+        assert not layer_norm and flatten and pos_embed_max_size, "only the SD3 configuration is built"
+        self.patch_size, self.pos_embed_max_size = patch_size, pos_embed_max_size
+        self.proj = QLinear(in_channels * patch_size * patch_size, embed_dim, bias=bias, data_type=data_type)
+        self.pos_embed = None        # [1, max*max, embed_dim], loaded from the checkpoint
+
+    def cropped_pos_embed(self, height, width):
+        height, width = height // self.patch_size, width // self.patch_size
+        m = self.pos_embed_max_size
+        if height > m:
+            raise ValueError(f"Height ({height}) cannot be greater than `pos_embed_max_size`: {m}.")
+        if width > m:
+            raise ValueError(f"Width ({width}) cannot be greater than `pos_embed_max_size`: {m}.")
+        top, left = (m - height) // 2, (m - width) // 2
+        pe = self.pos_embed.reshape(1, m, m, -1)[:, top: top + height, left: left + width, :]
+        return pe.reshape(1, -1, pe.shape[-1])
+
+    def forward(self, latent):
+        B, C, H, W = latent.shape
+        p = self.patch_size
+        h, w = H // p, W // p
+        patches = latent.reshape(B, C, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, C * p * p).contiguous()
+        x = self.proj.forward_q(patches).view(B, h * w, -1)
+        return (x + self.cropped_pos_embed(H, W)).to(x.dtype)

@@ -77,6 +77,22 @@ class AdaLayerNormZero(_AdaLNBase):
         return self._apply(x, scale_msa, shift_msa), gate_msa, shift_mlp, scale_mlp, gate_mlp
 
 
+class SD35AdaLayerNormZeroX(_AdaLNBase):
+    """normalization.py:45-88: nine chunks (the six of AdaLayerNormZero + shift/scale/gate of SD3.5's second attention);
+    LayerNorm eps 1e-5 (the reference's default for this class)."""
+    chunks = 9
+
+    def __init__(self, embedding_dim: int, elementwise_affine=False, norm_type: str = "layer_norm", bias: bool = True, eps=1e-5,
+                 data_type=BF16):
+        assert not elementwise_affine and norm_type == "layer_norm"
+        super().__init__(embedding_dim, bias=bias, eps=eps, data_type=data_type)
+
+    def forward(self, hidden_states, emb=None):
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp, shift_msa2, scale_msa2, gate_msa2 = self.modulation(emb).chunk(9, dim=1)
+        return (self._apply(hidden_states, scale_msa, shift_msa), gate_msa, shift_mlp, scale_mlp, gate_mlp,
+                self._apply(hidden_states, scale_msa2, shift_msa2), gate_msa2)
+
+
 class AdaLayerNormZeroSingle(_AdaLNBase):
     """normalization.py:201-236."""
     chunks = 3

@@ -77,38 +77,62 @@ class FluxTransformerBlock:
                                    hidden_states, encoder_hidden_states, image_rotary_emb)
 
 
-def fused_double_stream(attn, ff_img, ff_txt, mod_img, mod_txt, hidden_states, encoder_hidden_states, image_rotary_emb):
-    """One double-stream (MMDiT) block on the fused kernels; `mod_*` are the [B, 6*D] modulation projections in the
-    order (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp).  Shared by the FLUX double block
-    (flux.py:130-178) and the Qwen-Image block (qwenimage.py:58-124), whose arithmetic is identical.
-    Returns (encoder_hidden_states, hidden_states)."""
+def fused_double_stream(attn, ff_img, ff_txt, mod_img, mod_txt, hidden_states, encoder_hidden_states, image_rotary_emb,
+                        attn2=None, eps_img: float = 1e-6, context_pre_only: bool = False):
+    """One double-stream (MMDiT) block on the fused kernels.  `mod_img` is the image stream's [B, 6*D] modulation projection
+    in the order (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp) -- [B, 9*D] with (shift_msa2, scale_msa2,
+    gate_msa2) appended when `attn2` (SD3.5's second, image-only attention) is given; `mod_txt` likewise [B, 6*D], or
+    [B, 2*D] = (scale, shift) for a `context_pre_only` last block whose text stream ends in the attention.
+    Shared by the FLUX double block (flux.py:130-178), the Qwen-Image block (qwenimage.py:58-124) and SD3's
+    JointTransformerBlock (sd35.py:133-200), whose arithmetic is identical.  Returns (encoder_hidden_states | None, hidden_states)."""
     B, s_img, D = hidden_states.shape
     s_txt = encoder_hidden_states.shape[1]
     quant = attn.qkv.quant_type
     x = hidden_states.reshape(B * s_img, D)
     e = encoder_hidden_states.reshape(B * s_txt, D)
-    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mod_img.chunk(6, dim=1)
-    c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = mod_txt.chunk(6, dim=1)
+    im = mod_img.chunk(9 if attn2 is not None else 6, dim=1)
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = im[:6]
+    if context_pre_only:
+        c_scale_msa, c_shift_msa = mod_txt.chunk(2, dim=1)          # AdaLayerNormContinuous: scale first
+    else:
+        c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = mod_txt.chunk(6, dim=1)
 
     def pick(t):
         return t[1] if quant is not None else t[0]
 
-    xin = pick(fused.ln_modulate(x, scale_msa, shift_msa, s_img, quant=quant))
+    xin = pick(fused.ln_modulate(x, scale_msa, shift_msa, s_img, quant=quant, eps=eps_img))
     ein = pick(fused.ln_modulate(e, c_scale_msa, c_shift_msa, s_txt, quant=quant))
     o = attn.attend(xin, B, s_img, image_rotary_emb, ein, s_txt).view(B, s_txt + s_img, D)
 
     # attention rows of a stream are a strided slice of the joint output: quantise / project per batch element;
     # the image and text projections of one batch element share a launch
-    x_new, e_new = torch.empty_like(x), torch.empty_like(e)
-    to_o, to_ao = attn.to_out, attn.to_add_out
+    x_new = torch.empty_like(x)
+    e_new = None if context_pre_only else torch.empty_like(e)
+    to_o = attn.to_out
     for b in range(B):
-        ai, at = o[b, s_txt:], o[b, :s_txt]
+        ai = o[b, s_txt:]
         aqi = to_o.quantize_input(ai) if to_o.quant_type is not None else ai
+        if context_pre_only:
+            to_o.forward_q(aqi, epilogue=N.EPI_GATE_RESIDUAL, gate=gate_msa[b:b + 1], res=x[b * s_img:(b + 1) * s_img], rows_per_batch=s_img,
+                           out=x_new[b * s_img:(b + 1) * s_img])
+            continue
+        to_ao = attn.to_add_out
+        at = o[b, :s_txt]
         aqt = to_ao.quantize_input(at) if to_ao.quant_type is not None else at
         QLinear.forward_q_pair(to_o, aqi, to_ao, aqt, epilogue=N.EPI_GATE_RESIDUAL,
                                gate0=gate_msa[b:b + 1], res0=x[b * s_img:(b + 1) * s_img], rpb0=s_img, out0=x_new[b * s_img:(b + 1) * s_img],
                                gate1=c_gate_msa[b:b + 1], res1=e[b * s_txt:(b + 1) * s_txt], rpb1=s_txt, out1=e_new[b * s_txt:(b + 1) * s_txt])
+    if attn2 is not None:
+        # second, image-only attention on the same LayerNorm output with its own modulation (sd35.py:166-169)
+        shift_msa2, scale_msa2, gate_msa2 = im[6:]
+        xin2 = pick(fused.ln_modulate(x, scale_msa2, shift_msa2, s_img, quant=quant, eps=eps_img))
+        o2 = attn2.attend(xin2, B, s_img, None)
+        oq2 = attn2.to_out.quantize_input(o2) if attn2.to_out.quant_type is not None else o2
+        attn2.to_out.forward_q(oq2, epilogue=N.EPI_GATE_RESIDUAL, gate=gate_msa2, res=x_new, rows_per_batch=s_img, out=x_new)
     fin_x = pick(fused.ln_modulate(x_new, scale_mlp, shift_mlp, s_img, quant=quant))
+    if context_pre_only:
+        x_out = ff_img.forward_fused(fin_x, gate_mlp, x_new, s_img)
+        return None, x_out.view(B, s_img, D)
     fin_e = pick(fused.ln_modulate(e_new, c_scale_mlp, c_shift_mlp, s_txt, quant=quant))
     x, e = FeedForward.forward_fused_pair(ff_img, fin_x, gate_mlp, x_new, s_img, ff_txt, fin_e, c_gate_mlp, e_new, s_txt)
     return e.view(B, s_txt, D), x.view(B, s_img, D)

@@ -20,6 +20,7 @@ from fastdm_amd.caching.xcaching import AutoCache
 from fastdm_amd.kernel.utils import set_global_backend
 from fastdm_amd.model.flux import FluxTransformer2DModelCore
 from fastdm_amd.model.qwenimage import QwenImageTransformer2DModelCore
+from fastdm_amd.model.sd35 import SD3TransformerModelCore
 from fastdm_amd.model.wan import WanTransformer3DModelCore
 
 
@@ -108,6 +109,29 @@ class QwenTransformerWrapper(BaseModelWrapper):
         return self.core_model.forward(hidden_states, **kwargs)
 
 
+class SD35TransformerWrapper(BaseModelWrapper):
+    """model_entry.py:192-240."""
+
+    def __init__(self, ckpt_path=None, in_channels: int = 16, out_channels: int = 16, dtype: torch.dtype = torch.bfloat16,
+                 quant_type: Optional[torch.dtype] = None, kernel_backend: str = "hip", cache: AutoCache = None, **kwargs):
+        super().__init__(kernel_backend)
+        self.dtype = dtype
+        self.core_model = SD3TransformerModelCore(in_channels=in_channels, out_channels=out_channels, data_type=dtype, quant_dtype=quant_type,
+                                                  cache=cache, **kwargs)
+        c = self.core_model.config
+        self.config = self._create_diffusers_config(in_channels=in_channels, out_channels=out_channels, dtype=dtype, patch_size=c.patch_size,
+                                                    sample_size=c.sample_size, joint_attention_dim=c.joint_attention_dim,
+                                                    pooled_projection_dim=c.pooled_projection_dim)
+        if isinstance(ckpt_path, dict) or (ckpt_path and os.path.exists(ckpt_path)):
+            self.core_model.weight_loading(ckpt_path, data_type=dtype, device_type="cuda")
+        elif ckpt_path:
+            print(f"Warning: Checkpoint path {ckpt_path} does not exist")
+
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, **kwargs):
+        return self.core_model.forward(hidden_states, **kwargs)
+
+
 _WAN_A14B_CONFIG = dict(patch_size=(1, 2, 2), num_attention_heads=40, attention_head_dim=128, in_channels=16, out_channels=16, text_dim=4096,
                         freq_dim=256, ffn_dim=13824, num_layers=40, qk_norm="rms_norm_across_heads", eps=1e-6, rope_max_seq_len=1024,
                         image_dim=None)
@@ -146,8 +170,9 @@ class WanTransformer3DWrapper(BaseModelWrapper):
 
 class ModelWrapperFactory:
     """model_entry.py:463-497."""
-    _WRAPPER_MAPPING = {"flux": FluxTransformerWrapper, "qwen": QwenTransformerWrapper, "wan": WanTransformer3DWrapper}
-    _NOT_BUILT = ("sdxl", "sd35", "sdxl-controlnet", "flux-controlnet")
+    _WRAPPER_MAPPING = {"flux": FluxTransformerWrapper, "qwen": QwenTransformerWrapper, "wan": WanTransformer3DWrapper,
+                        "sd35": SD35TransformerWrapper}
+    _NOT_BUILT = ("sdxl", "sdxl-controlnet", "flux-controlnet")
 
     @classmethod
     def create_wrapper(cls, model_type: str, **kwargs) -> BaseModelWrapper:

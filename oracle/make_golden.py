@@ -527,6 +527,40 @@ def gen_fbcache():
     save("fbcache.npz", d)
 
 
+# ------------------------------------------------------------------ SD3.5
+def ref_sd3_core(cfg, quant, sd):
+    from fastdm.model.sd35 import SD3TransformerModelCore
+    core = SD3TransformerModelCore(
+        sample_size=cfg.sample_size, patch_size=cfg.patch_size, in_channels=cfg.in_channels, num_layers=cfg.num_layers,
+        attention_head_dim=cfg.attention_head_dim, num_attention_heads=cfg.num_attention_heads, joint_attention_dim=cfg.joint_attention_dim,
+        caption_projection_dim=cfg.caption_projection_dim, pooled_projection_dim=cfg.pooled_projection_dim, out_channels=cfg.out_channels,
+        pos_embed_max_size=cfg.pos_embed_max_size, dual_attention_layers=cfg.dual_attention_layers, qk_norm="rms_norm",
+        data_type=torch.bfloat16, quant_dtype=quant, cache=None)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        core.weight_loading(dict(sd), device_type="cpu")
+    return core
+
+
+def gen_tiny_sd3():
+    """Tiny SD3.5 MMDiT (3 blocks: one with dual attention, the last context_pre_only) through the reference, bf16 / fp8 / int8."""
+    import_reference()
+    from oracle import sd35 as OS
+    cfg = OS.TINY
+    sd = OS.synth_state_dict(cfg, seed=31)
+    inp = OS.synth_inputs(cfg, batch=2, height=8, width=12, n_txt=9, seed=31)
+    d = {"seed": 31, "batch": 2, "height": 8, "width": 12, "n_txt": 9}
+    for tag, qt in (("bf16", None), ("fp8", torch.float8_e4m3fn), ("int8", torch.int8)):
+        use_backend("cpu_fp8" if qt == torch.float8_e4m3fn else "torch")
+        core = ref_sd3_core(cfg, qt, sd)
+        for ti, t in enumerate((999.0, 400.0)):
+            out = core.forward(timestep=torch.tensor([t, t]), return_dict=False, **inp)
+            d[f"out_{tag}_t{ti}"] = out[0] if isinstance(out, (tuple, list)) else out
+    use_backend("torch")
+    save("tiny_sd3.npz", d)
+
+
 # ------------------------------------------------------------------ full-width C3 fixture
 def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=0, sub=64):
     """Full-width FLUX.1-dev at 1024x2048 (S = 8192 + 512) through the reference's own block
@@ -621,7 +655,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "c3"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "sd3", "c3"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     args = ap.parse_args()
@@ -640,6 +674,8 @@ def main():
         gen_tiny_wan()
     if args.what in ("small", "fbcache"):
         gen_fbcache()
+    if args.what in ("small", "sd3"):
+        gen_tiny_sd3()
     if args.what == "qwen_full":
         gen_qwen_full()
     if args.what == "c3":
