@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {"fp8": 5000.0, "bf16": 2500.0, "int8": 5000.0}   # dense MFMA, /opt/skills/guides/MI355X_MICROARCH.md
@@ -85,7 +86,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 25 (flux, qwen) / 3 (wan)")
     ap.add_argument("--warmup", type=int, default=None, help="default 3 (flux, qwen) / 1 (wan)")
-    ap.add_argument("--model", choices=["flux", "qwen", "wan"], default="flux",
+    ap.add_argument("--model", choices=["flux", "qwen", "wan", "sd35"], default="flux",
                     help="flux = the headline workload; qwen = Qwen-Image (BASELINE.json configs[3]) and wan = Wan2.2-T2V-A14B "
                          "(configs[4]): a step is a cond + uncond forward pair (CFG)")
     ap.add_argument("--frames", type=int, default=81, help="wan: video frames")
@@ -100,7 +101,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event spans")
     args = ap.parse_args()
-    dflt = {"flux": (1024, 2048, 512, "fp8"), "qwen": (1328, 1328, 128, "int8"), "wan": (768, 1280, 512, "fp8")}[args.model]
+    dflt = {"flux": (1024, 2048, 512, "fp8"), "qwen": (1328, 1328, 128, "int8"), "wan": (768, 1280, 512, "fp8"), "sd35": (1024, 1024, 333, "fp8")}[args.model]
     args.height, args.width = args.height or dflt[0], args.width or dflt[1]
     args.max_seq_len, args.quant = args.max_seq_len or dflt[2], args.quant or dflt[3]
     args.steps = args.steps if args.steps is not None else (3 if args.model == "wan" else 25)
@@ -129,6 +130,13 @@ def main():
         model = create_model("qwen", ckpt_path=SyntheticQwenStateDict(seed=0), dtype=torch.bfloat16, quant_type=quant,
                              kernel_backend="hip", cache=cache, out_channels=16).eval()
         pipe = SyntheticQwenPipeline(model, seed=0)
+    elif args.model == "sd35":
+        from fastdm_amd.synthetic import SyntheticSD3StateDict, sd3_step_inputs
+        arch = dict(num_layers=38, num_attention_heads=38, attention_head_dim=64, caption_projection_dim=2432, pos_embed_max_size=192,
+                    dual_attention_layers=())                                     # SD3.5-large
+        model = create_model("sd35", ckpt_path=SyntheticSD3StateDict(seed=0, **arch), dtype=torch.bfloat16, quant_type=quant, kernel_backend="hip",
+                             **arch).eval()
+        pipe = None
     else:
         from fastdm_amd.pipeline import SyntheticWanPipeline
         from fastdm_amd.sparse import SparseAttn
@@ -143,7 +151,13 @@ def main():
     if cache:
         cache.config.current_steps_callback = lambda: pipe.scheduler_step_index
     # rank r denoises image r of the global batch (different latents/prompt per image)
-    if args.model == "wan":
+    if args.model == "sd35":
+        IMAGE_STEPS = 28
+        inp = sd3_step_inputs(2, args.height // 8, args.width // 8, args.max_seq_len, seed=rank)      # cond + uncond batched (CFG), as diffusers does
+        n_img = (args.height // 16) * (args.width // 16)
+        lin = np.linspace(1.0, 1.0 / IMAGE_STEPS, IMAGE_STEPS)
+        sig = np.concatenate([3.0 * lin / (1.0 + 2.0 * lin), [0.0]]).astype(np.float32)      # flow-match schedule, shift 3
+    elif args.model == "wan":
         IMAGE_STEPS = 40
         inp = pipe.prepare(1, args.height, args.width, args.frames, args.max_seq_len, seed=rank)
         n_img = inp["hidden_states"].shape[2] * (inp["hidden_states"].shape[3] // 2) * (inp["hidden_states"].shape[4] // 2)
@@ -160,7 +174,17 @@ def main():
         i = (state["i"] + args.start_step) % IMAGE_STEPS
         if i == 0:
             state["lat"] = inp["hidden_states"].clone()
-        pipe.scheduler_step_index = i
+        if pipe is not None:
+            pipe.scheduler_step_index = i
+        if args.model == "sd35":
+            lat = state["lat"]
+            t = torch.full((2,), float(sig[i]) * 1000.0, device=dev, dtype=torch.float32)
+            v = model(hidden_states=lat, encoder_hidden_states=inp["encoder_hidden_states"], pooled_projections=inp["pooled_projections"],
+                      timestep=t, return_dict=False)[0].float()
+            noise = v[1:2] + 4.5 * (v[0:1] - v[1:2])
+            state["lat"] = (lat.float() + float(sig[i + 1] - sig[i]) * noise).to(torch.bfloat16).expand(2, -1, -1, -1).contiguous()
+            state["i"] += 1
+            return
         if args.model == "wan":
             state["lat"] = pipe.step(state["lat"], inp, sig[i], sig[i + 1], 5.0)      # cond + uncond forward, CFG combine, Euler update
             state["i"] += 1
@@ -210,6 +234,9 @@ def main():
     if args.model == "flux":
         workload = (f"FLUX.1-dev {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step flow-match schedule, "
                     f"batch 1 per GPU, 19 double + 38 single blocks" + (f", TeaCache ({skipped}/{args.steps} steps skipped)" if cache else ""))
+    elif args.model == "sd35":
+        workload = (f"SD3.5-large {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), 28-step schedule, CFG as one batch-2 forward "
+                    f"per step, 38 joint blocks")
     elif args.model == "wan":
         hs = inp["hidden_states"].shape
         nl = len(model.core_model.blocks)
@@ -228,6 +255,7 @@ def main():
     out = {
         "metric": {"flux": "denoise it/s (sec/image = 25 / (value / n_gpus)), FLUX 1024x2048 fp8 @25 steps",
                    "qwen": "denoise it/s (sec/image = 25 / (value / n_gpus)), Qwen-Image 1328x1328 int8 @25 steps, true CFG",
+                   "sd35": "denoise it/s (sec/image = 28 / (value / n_gpus)), SD3.5-large 1024x1024 fp8 @28 steps, CFG",
                    "wan": "denoise it/s (sec/video = 40 / (value / n_gpus)), Wan2.2-T2V-A14B 768x1280x81f fp8 @40 steps, CFG"}[args.model],
         "value": world * args.steps / elapsed,
         "unit": "it/s",

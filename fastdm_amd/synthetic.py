@@ -243,3 +243,79 @@ def wan_step_inputs(batch, frames, height, width, n_txt=512, in_channels=16, tex
     """Same tensors as oracle.wan.synth_inputs (bit-identical): latents [B, C, F, H, W] ~ N(0,1), text [B, n_txt, text_dim]."""
     return dict(hidden_states=normal("wan.input.latents", (batch, in_channels, frames, height, width), 1.0, 0.0, seed, device),
                 encoder_hidden_states=normal("wan.input.prompt_embeds", (batch, n_txt, text_dim), 1.0, 0.0, seed, device))
+
+
+class SyntheticSD3StateDict(dict):
+    """Lazily generated diffusers-named SD3.5 state_dict, bit-identical to oracle.sd35.synth_state_dict."""
+
+    def __init__(self, patch_size=2, in_channels=16, num_layers=38, attention_head_dim=64, num_attention_heads=38, joint_attention_dim=4096,
+                 caption_projection_dim=2432, pooled_projection_dim=2048, out_channels=16, pos_embed_max_size=192, dual_attention_layers=(),
+                 mlp_ratio=4.0, seed=0, device="cuda", **_):
+        super().__init__()
+        self.seed, self.device = seed, device
+        D, hd, p = attention_head_dim * num_attention_heads, attention_head_dim, patch_size
+        mlp = int(D * mlp_ratio)
+        spec = {}
+
+        def lin(name, k, n, kind="w"):
+            spec[f"{name}.weight"] = ((n, k), kind)
+            spec[f"{name}.bias"] = ((n,), "b")
+
+        spec["pos_embed.proj.weight"] = ((D, in_channels, p, p), "conv")
+        spec["pos_embed.proj.bias"] = ((D,), "b")
+        spec["pos_embed.pos_embed"] = ((1, pos_embed_max_size ** 2, D), "b")
+        lin("time_text_embed.timestep_embedder.linear_1", 256, D)
+        lin("time_text_embed.timestep_embedder.linear_2", D, D)
+        lin("time_text_embed.text_embedder.linear_1", pooled_projection_dim, D)
+        lin("time_text_embed.text_embedder.linear_2", D, D)
+        lin("context_embedder", joint_attention_dim, caption_projection_dim)
+        for i in range(num_layers):
+            b = f"transformer_blocks.{i}"
+            last, dual = i == num_layers - 1, i in dual_attention_layers
+            lin(f"{b}.norm1.linear", D, (9 if dual else 6) * D, "w_mod")
+            lin(f"{b}.norm1_context.linear", D, (2 if last else 6) * D, "w_mod")
+            for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0"):
+                lin(f"{b}.attn.{n}", D, D)
+            if not last:
+                lin(f"{b}.attn.to_add_out", D, D)
+            for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+                spec[f"{b}.attn.{n}.weight"] = ((hd,), "rms")
+            if dual:
+                for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                    lin(f"{b}.attn2.{n}", D, D)
+                spec[f"{b}.attn2.norm_q.weight"] = ((hd,), "rms")
+                spec[f"{b}.attn2.norm_k.weight"] = ((hd,), "rms")
+            lin(f"{b}.ff.net.0.proj", D, mlp)
+            lin(f"{b}.ff.net.2", mlp, D)
+            if not last:
+                lin(f"{b}.ff_context.net.0.proj", D, mlp)
+                lin(f"{b}.ff_context.net.2", mlp, D)
+        lin("norm_out.linear", D, 2 * D, "w_mod")
+        lin("proj_out", D, p * p * out_channels)
+        self.spec = spec
+        for k in spec:
+            dict.__setitem__(self, k, None)
+
+    def _make(self, name):
+        shape, kind = self.spec[name]
+        key = "sd3." + name
+        if kind == "w":
+            return normal(key, shape, (1.0 / shape[1]) ** 0.5, 0.0, self.seed, self.device)
+        if kind == "conv":
+            return normal(key, shape, (1.0 / math.prod(shape[1:])) ** 0.5, 0.0, self.seed, self.device)
+        if kind in ("w_mod", "b"):
+            return normal(key, shape, 0.02, 0.0, self.seed, self.device)
+        return normal(key, shape, 0.1, 1.0, self.seed, self.device)
+
+    def __getitem__(self, name):
+        return self._make(name)
+
+    def get(self, name, default=None):
+        return self._make(name) if name in self.spec else default
+
+
+def sd3_step_inputs(batch, height, width, n_txt=333, in_channels=16, joint_attention_dim=4096, pooled_projection_dim=2048, seed=0, device="cuda"):
+    """Same tensors as oracle.sd35.synth_inputs (bit-identical); height/width are LATENT sizes (pixels / 8)."""
+    return dict(hidden_states=normal("sd3.input.latents", (batch, in_channels, height, width), 1.0, 0.0, seed, device),
+                encoder_hidden_states=uniform("sd3.input.prompt_embeds", (batch, n_txt, joint_attention_dim), seed, device),
+                pooled_projections=uniform("sd3.input.pooled", (batch, pooled_projection_dim), seed, device))
