@@ -24,6 +24,13 @@ namespace fdm {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// s_setprio(1) around the MFMA clusters: measured -2 % with 128-key tiles (it paid +1 % with 64-key tiles), so off
+#ifndef FDM_ATT_PRIO_QK
+#define FDM_ATT_PRIO_QK 0
+#endif
+#ifndef FDM_ATT_PRIO_PV
+#define FDM_ATT_PRIO_PV 0
+#endif
 #ifndef FDM_ATT_THREADS
 #define FDM_ATT_THREADS 512
 #endif
@@ -225,7 +232,9 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
     constexpr bool TAIL = decltype(tail_c)::value;
     // ---- S^T = K . Q^T  (two 32-key tiles)
     f32x16 sacc[NKT];
+#if FDM_ATT_PRIO_QK
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int kt2 = 0; kt2 < NKT; ++kt2)
 #pragma unroll
@@ -240,7 +249,9 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
                                                             sacc[kt2], 0, 0, 0);
       }
     }
+#if FDM_ATT_PRIO_QK
     __builtin_amdgcn_s_setprio(0);
+#endif
     if constexpr (TAIL) {
       const int rem = (int)(p.sk - (int64_t)t * KT) - 4 * h;  // keys of this tile that exist, shifted by the lane-half offset
 #pragma unroll
@@ -292,7 +303,9 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
     }
     l_run += psum;
     // ---- O^T += V^T . P^T
+#if FDM_ATT_PRIO_PV
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int kt2 = 0; kt2 < NKT; ++kt2)
 #pragma unroll
@@ -306,9 +319,14 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the V-fragment prefetch depth at one (kt2, s) group: VGPR budget
       }
+#if FDM_ATT_PRIO_PV
     __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
+#ifdef FDM_ATT_STATIC_PRIO
+  if (wave >= NT / 128) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every arbitration otherwise
+#endif
   // KV range of this work item: everything, or the part-th of `split` consecutive ranges
   const int t_begin = is_part ? (int)((int64_t)part * ntiles / p.split) : 0;
   const int t_end = is_part ? (int)((int64_t)(part + 1) * ntiles / p.split) : ntiles;
