@@ -317,7 +317,6 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
           oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[kt2][s]),
                                                             oacc[d], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the V-fragment prefetch depth at one (kt2, s) group: VGPR budget
       }
 #if FDM_ATT_PRIO_PV
     __builtin_amdgcn_s_setprio(0);
