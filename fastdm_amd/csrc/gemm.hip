@@ -157,6 +157,48 @@ __device__ __forceinline__ float fast_gelu_erf(float x) {
   return 0.5f * x * (1.0f + erf_x);
 }
 
+// The same activations over 16 independent values, written stage by stage: hipcc packs neighbouring scalar f32 ops into
+// v_pk_* instructions, and a v_pk_* that consumes the previous instruction's result costs a wait state (s_nop); with 16
+// independent lanes of work per stage every packed op has an independent neighbour.
+template <int EPI>
+__device__ __forceinline__ void gelu16(float (&v)[16]) {
+  if constexpr (EPI == FDM_EPI_GELU_TANH) {
+    const float c0 = 0.79788456080286535588f * 2.885390081777927f, c1 = c0 * 0.044715f;
+    float e[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) e[k] = v[k] * v[k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) e[k] = __builtin_fmaf(e[k], c1, c0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) e[k] = __builtin_amdgcn_exp2f(v[k] * e[k]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) e[k] = __builtin_amdgcn_rcpf(e[k] + 1.0f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = __builtin_fmaf(-v[k], e[k], v[k]);
+  } else if constexpr (EPI == FDM_EPI_GELU_ERF) {
+    float z[16], t[16], pl[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) z[k] = fabsf(v[k]) * 0.70710678118654752440f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z[k], 1.0f));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pl[k] = __builtin_fmaf(t[k], 1.061405429f, -1.453152027f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pl[k] = __builtin_fmaf(t[k], pl[k], 1.421413741f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pl[k] = __builtin_fmaf(t[k], pl[k], -0.284496736f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pl[k] = __builtin_fmaf(t[k], pl[k], 0.254829592f) * t[k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) z[k] = __builtin_amdgcn_exp2f(-z[k] * z[k] * 1.4426950408889634f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float er = __builtin_fmaf(-pl[k], z[k], 1.0f);
+      v[k] = 0.5f * v[k] * (1.0f + (v[k] < 0.f ? -er : er));
+    }
+  }
+}
+
 __device__ __forceinline__ void unpack4(const i32x2 v, float (&o)[4]) {
   o[0] = __builtin_bit_cast(float, (uint32_t)v[0] << 16);
   o[1] = __builtin_bit_cast(float, (uint32_t)v[0] & 0xffff0000u);
@@ -353,27 +395,31 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
         if constexpr (DT == DT_INT8) {
           if (p.azp_adj != nullptr) adjq = *reinterpret_cast<const i32x4*>(p.azp_adj + nc);
         }
+        float y[16];   // [i][c]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float y[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const int e = 4 * q + c;
+            float yy;
             if constexpr (DT == DT_FP8) {
-              y[c] = acc[i][j][e] * sam[i] * sbq[c] + bias4[c];
+              yy = acc[i][j][e] * sam[i] * sbq[c] + bias4[c];
             } else if constexpr (DT == DT_INT8) {
               const int a = acc[i][j][e] - azpm[i] * adjq[c];
-              y[c] = (float)a * (sam[i] * sbq[c]);
-              if (p.bias != nullptr) y[c] = rbf(y[c]) + bias4[c];
+              yy = (float)a * (sam[i] * sbq[c]);
+              if (p.bias != nullptr) yy = rbf(yy) + bias4[c];
             } else {
-              y[c] = acc[i][j][e] + bias4[c];
+              yy = acc[i][j][e] + bias4[c];
             }
-            if constexpr (EPI == FDM_EPI_GELU_TANH) y[c] = fast_gelu_tanh(rbf(y[c]));
-            if constexpr (EPI == FDM_EPI_GELU_ERF) y[c] = fast_gelu_erf(rbf(y[c]));
+            y[4 * i + c] = (EPI == FDM_EPI_GELU_TANH || EPI == FDM_EPI_GELU_ERF) ? rbf(yy) : yy;
           }
+        }
+        gelu16<EPI>(y);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
           i32x2 o;
-          o[0] = (int)pack2bf(y[0], y[1]);
-          o[1] = (int)pack2bf(y[2], y[3]);
+          o[0] = (int)pack2bf(y[4 * i], y[4 * i + 1]);
+          o[1] = (int)pack2bf(y[4 * i + 2], y[4 * i + 3]);
           const int r = i * 32 + lrow;
           *reinterpret_cast<i32x2*>(wt + r * 128 + (((j * 4 + q) ^ (r & 7)) << 4) + g * 8) = o;
         }
