@@ -277,6 +277,27 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(ok ? gb[i] + koff : zero_page, sB + i * 8192);
   };
+  // Steps whose whole 64-byte K slice lies inside K need no per-lane bounds select: the source is a wave-uniform base
+  // (tile origin + K offset, SALU) plus a loop-invariant 32-bit lane offset, which the compiler can issue in the
+  // saddr + voffset form -- no 64-bit VALU address math or v_cndmask in the steady state.
+  const uint8_t* baseA = p.A + (int64_t)min(m0, p.M - 1) * p.lda;
+  const uint8_t* baseB = p.B + (int64_t)min(n0, p.N - 1) * p.ldb;
+  uint32_t oa[2], ob[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    oa[i] = (uint32_t)((min(m0 + i * 128 + srow, p.M - 1) - min(m0, p.M - 1)) * p.lda) + schunk * 16;
+    ob[i] = (uint32_t)((min(n0 + i * 128 + srow, p.N - 1) - min(n0, p.N - 1)) * p.ldb) + schunk * 16;
+  }
+  auto stage_inner = [&](int kt) {
+    uint8_t* sA = smem + (kt & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024;
+    uint8_t* sB = sA + BM * BKB;
+    const uint8_t* ka = baseA + (int64_t)kt * BKB;
+    const uint8_t* kb = baseB + (int64_t)kt * BKB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(ka + oa[i], sA + i * 8192);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(kb + ob[i], sB + i * 8192);
+  };
 
   // ---- fragment read addresses (byte offsets inside a stage)
   const int lrow = lane & 31, g = lane >> 5;
@@ -336,10 +357,11 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
 
   // One step: wait for DMA(t+1) (leaving DMA(t+2) in flight), barrier, issue DMA(t+3), then MFMA(t) with the
   // fragments of step t+1 streaming in behind it.
-  auto step = [&](Frag (&bc)[NS][2], Frag (&bn)[NS][2], int t) {
+  auto step = [&](auto inner_c, Frag (&bc)[NS][2], Frag (&bn)[NS][2], int t) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    stage(t + 3);
+    if constexpr (decltype(inner_c)::value) stage_inner(t + 3);
+    else stage(t + 3);
     read_b(bn, t + 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -351,9 +373,15 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
     }
   };
   const int nk2 = (nk + 1) & ~1;
-  for (int t = 0; t < nk2; t += 2) {
-    step(fb0, fb1, t);
-    step(fb1, fb0, t + 1);
+  const int nk_full = (int)(Kb / BKB);          // slices that lie completely inside K
+  int t = 0;
+  for (; t + 4 < nk_full; t += 2) {              // issues slices t+3 and t+4: both complete
+    step(std::true_type{}, fb0, fb1, t);
+    step(std::true_type{}, fb1, fb0, t + 1);
+  }
+  for (; t < nk2; t += 2) {                      // K tail and the zero-filled padding slices
+    step(std::false_type{}, fb0, fb1, t);
+    step(std::false_type{}, fb1, fb0, t + 1);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // retire the padding DMAs and the dead fragment reads
   __builtin_amdgcn_s_barrier();                                  // every wave is done with the ring: reuse it below
