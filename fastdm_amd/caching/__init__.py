@@ -1,2 +1,2 @@
-from .config import CacheConfig, FBCacheConfig, TeaCacheConfig  # noqa: F401
-from .xcaching import AutoCache, FBCache, TeaCache  # noqa: F401
+from .config import CacheConfig, DiCacheConfig, FBCacheConfig, TeaCacheConfig  # noqa: F401
+from .xcaching import AutoCache, DiCache, FBCache, TeaCache  # noqa: F401

@@ -30,3 +30,11 @@ class TeaCacheConfig(CacheConfig):
 @dataclass
 class FBCacheConfig(CacheConfig):
     warmup_steps: int = 6
+
+
+@CacheConfig.register("dicache")
+@dataclass
+class DiCacheConfig(CacheConfig):
+    probe_depth: int = 1                      # blocks that always run and serve as the probe
+    ret_ratio: float = 0.2                    # the first ret_ratio * total_steps steps are always computed
+    rel_l1_distance_algo: str = "delta_y"     # "delta_y" | "delta_minus"

@@ -164,3 +164,72 @@ class FBCache(AutoCache):
                               encoder_hidden_states_mask=encoder_hidden_states_mask)
         self.previous_residual_dict[cache_key] = out - hidden_states
         return out
+
+
+@AutoCache.register("dicache")
+class DiCache(AutoCache):
+    """Probe-based cache (xcaching.py:418-556): the first `probe_depth` blocks always run; the relative change of their
+    output (and optionally of their input) since the previous step accumulates -- in bf16, as the reference's 0-dim
+    tensors do -- and while it stays under the threshold the remaining blocks are replaced by a cached residual,
+    extrapolated from the last two computed residuals once two are available.  As in the reference the residual
+    (`out - in` of the whole stack) is added to the PROBE output on skipped steps."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        keys = ("positive", "negative")
+        self.previous_probe_stats_dict = {k: None for k in keys}
+        self.previous_residual_window_dict = {k: [] for k in keys}
+
+    def apply_cache(self, model_type: str, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
+                    encoder_hidden_states_mask=None, temb: torch.Tensor = None, image_rotary_emb: torch.Tensor = None,
+                    attention_kwargs: Optional[Dict[str, Any]] = None, transformer_blocks=None, single_transformer_blocks=None,
+                    core=None, **_):
+        if model_type not in ("flux", "qwenimage"):
+            raise ValueError(f"DiCache unsupported model type: {model_type}. Supported types: qwenimage, flux")
+        current_step = self.get_current_step()
+        tcb = self.config.total_steps_callback
+        total_steps = tcb() if tcb is not None and tcb() is not None else 25
+        cache_key = self.get_cache_key()
+        ori = hidden_states
+        probe_h, probe_e = hidden_states, encoder_hidden_states
+        for blk in transformer_blocks[: self.config.probe_depth]:          # blocks return fresh tensors: `ori` stays intact
+            kw = dict(hidden_states=probe_h, encoder_hidden_states=probe_e, temb=temb, image_rotary_emb=image_rotary_emb,
+                      joint_attention_kwargs=attention_kwargs)
+            if model_type == "qwenimage":
+                kw["encoder_hidden_states_mask"] = encoder_hidden_states_mask
+            probe_e, probe_h = blk.forward(**kw)
+        err = None
+        if current_step <= int(self.config.ret_ratio * total_steps):
+            should_calc = True
+            self.accumulated_rel_l1_distance_dict[cache_key] = 0
+        else:
+            delta_y = self.rel_distance(probe_h, self.previous_probe_stats_dict[cache_key])
+            if self.config.rel_l1_distance_algo == "delta_minus":
+                delta_x = self.rel_distance(ori, self.previous_modulated_input_dict[cache_key])
+                err = _bf16(abs(_bf16(delta_y - delta_x)))
+            elif self.config.rel_l1_distance_algo == "delta_y":
+                err = delta_y
+            else:
+                raise ValueError(f"unknown rel_l1_distance_algo: {self.config.rel_l1_distance_algo}")
+            acc = _bf16(self.accumulated_rel_l1_distance_dict[cache_key] + err)
+            self.accumulated_rel_l1_distance_dict[cache_key] = acc
+            if acc < self.config.threshold:
+                should_calc = False
+            else:
+                should_calc = True
+                self.accumulated_rel_l1_distance_dict[cache_key] = 0
+        self.trace.append((current_step, err, float(self.accumulated_rel_l1_distance_dict[cache_key]), should_calc, cache_key))
+        self.previous_probe_stats_dict[cache_key] = probe_h.clone()
+        self.previous_modulated_input_dict[cache_key] = ori.clone()
+        if not should_calc:
+            window = self.previous_residual_window_dict[cache_key]
+            if len(window) >= 2:
+                r2, r1 = window[-2], window[-1]
+                gamma = (r2.abs().mean() / (r1 - r2).abs().mean()).clip(1, 1.5)      # bf16 0-dim tensor ops, as in the reference
+                return probe_h + (r2 + gamma * (r1 - r2))
+            return probe_h + self.previous_residual_dict[cache_key]
+        out = core.run_blocks(probe_h, probe_e, temb, image_rotary_emb, attention_kwargs, start_block=self.config.probe_depth,
+                              encoder_hidden_states_mask=encoder_hidden_states_mask)
+        self.previous_residual_dict[cache_key] = out - ori
+        self.previous_residual_window_dict[cache_key].append(self.previous_residual_dict[cache_key])
+        return out

@@ -561,6 +561,61 @@ def gen_tiny_sd3():
     save("tiny_sd3.npz", d)
 
 
+def gen_dicache():
+    """DiCache (probe depth 1, delta_y) decisions + final latents on the tiny FLUX (bf16) and Qwen-Image (int8) cores over
+    12-step trajectories through the reference's AutoCache."""
+    import_reference()
+    use_backend("torch")
+    from fastdm.caching.xcaching import AutoCache
+    from oracle import flux as OF, qwen as OQ
+    import contextlib
+    import io
+    d = {"threshold": 0.52, "probe_depth": 1, "ret_ratio": 0.2, "total_steps": 12}
+    state = {"step": 0}
+    sig = torch.linspace(1.0, 1.0 / 12, 12)
+
+    def make_cache():
+        c = AutoCache.from_dict({"cache_algorithm": "dicache", "enable_caching": True, "threshold": 0.52, "probe_depth": 1, "ret_ratio": 0.2,
+                                 "rel_l1_distance_algo": "delta_y"})
+        c.config.current_steps_callback = lambda: state["step"]
+        c.config.total_steps_callback = lambda: 12
+        return c
+
+    cfg = OF.TINY
+    sd = OF.synth_state_dict(cfg, seed=7)
+    inp = OF.synth_inputs(cfg, batch=1, img_h=4, img_w=6, n_txt=8, seed=9)
+    core = ref_flux_core(cfg, None, sd, cache=make_cache())
+    lat, dec = inp["hidden_states"].clone(), []
+    for i in range(12):
+        state["step"] = i
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            out = core.forward(hidden_states=lat, encoder_hidden_states=inp["encoder_hidden_states"], pooled_projections=inp["pooled_projections"],
+                               timestep=sig[i:i + 1], img_ids=inp["img_ids"], txt_ids=inp["txt_ids"], guidance=torch.tensor([3.5]))[0]
+        dec.append(0 if "Skipping" in buf.getvalue() else 1)
+        dt = (sig[i + 1] - sig[i]) if i + 1 < 12 else -sig[i]
+        lat = (lat.float() + dt * out.float()).to(torch.bfloat16)
+    d["flux_should_calc"], d["flux_final"] = np.array(dec, dtype=np.int8), lat
+    qcfg = OQ.TINY
+    qsd = OQ.synth_state_dict(qcfg, seed=11)
+    qin = OQ.synth_inputs(qcfg, batch=1, img_h=6, img_w=4, n_txt=7, seed=12)
+    core = ref_qwen_core(qcfg, torch.int8, qsd, cache=make_cache())
+    lat, dec = qin["hidden_states"].clone(), []
+    for i in range(12):
+        state["step"] = i
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            out = core.forward(hidden_states=lat, encoder_hidden_states=qin["encoder_hidden_states"],
+                               encoder_hidden_states_mask=qin["encoder_hidden_states_mask"], timestep=sig[i:i + 1],
+                               img_shapes=qin["img_shapes"], txt_seq_lens=qin["txt_seq_lens"])[0]
+        dec.append(0 if "Skipping" in buf.getvalue() else 1)
+        dt = (sig[i + 1] - sig[i]) if i + 1 < 12 else -sig[i]
+        lat = (lat.float() + dt * out.float()[..., : qcfg.in_channels]).to(torch.bfloat16)
+    d["qwen_should_calc"], d["qwen_final"] = np.array(dec, dtype=np.int8), lat
+    print("flux decisions", d["flux_should_calc"].tolist(), "qwen decisions", d["qwen_should_calc"].tolist())
+    save("dicache.npz", d)
+
+
 # ------------------------------------------------------------------ full-width C3 fixture
 def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=0, sub=64):
     """Full-width FLUX.1-dev at 1024x2048 (S = 8192 + 512) through the reference's own block
@@ -655,7 +710,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "sd3", "c3"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "c3"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     args = ap.parse_args()
@@ -674,6 +729,8 @@ def main():
         gen_tiny_wan()
     if args.what in ("small", "fbcache"):
         gen_fbcache()
+    if args.what in ("small", "dicache"):
+        gen_dicache()
     if args.what in ("small", "sd3"):
         gen_tiny_sd3()
     if args.what == "qwen_full":

@@ -171,3 +171,64 @@ class FBCacheOracle:
             enc1, hid1 = blk(hid1, enc1, temb, rope)
         self.prev_residual = hid1 - hidden
         return hid1
+
+
+class DiCacheOracle:
+    """fastdm/caching/xcaching.py:418-556 (FLUX and Qwen-Image branches, single cache key), tensor arithmetic exactly as the
+    reference writes it (the accumulated distance becomes a 0-dim bf16 tensor after the first add)."""
+
+    def __init__(self, threshold, probe_depth, ret_ratio, algo, current_steps_callback, total_steps):
+        self.threshold, self.probe_depth, self.ret_ratio, self.algo = threshold, probe_depth, ret_ratio, algo
+        self.cb, self.total_steps = current_steps_callback, total_steps
+        self.acc = 0
+        self.prev_in = self.prev_probe = self.prev_residual = None
+        self.window = []
+        self.trace = []
+        self.config = type("Cfg", (), {"enable_caching": True})()
+
+    def _run(self, core, hidden, encoder, temb, rope, flux: bool):
+        step = self.cb()
+        step = 0 if step is None else step
+        ori = hidden.clone()
+        enc = encoder
+        for blk in core.transformer_blocks[: self.probe_depth]:
+            enc, hidden = blk(hidden, enc, temb, rope)
+        if step <= int(self.ret_ratio * self.total_steps):
+            calc, self.acc = True, 0
+        else:
+            delta_x = (hidden - self.prev_in).abs().mean() / self.prev_in.abs().mean()
+            delta_y = (hidden - self.prev_probe).abs().mean() / self.prev_probe.abs().mean()
+            error = (delta_y - delta_x).abs() if self.algo == "delta_minus" else delta_y
+            self.acc = self.acc + error
+            if self.acc < self.threshold:
+                calc = False
+            else:
+                calc, self.acc = True, 0
+        self.trace.append((step, float(self.acc), calc))
+        self.prev_probe = hidden.clone()
+        self.prev_in = ori
+        if not calc:
+            if len(self.window) >= 2:
+                import torch
+                ind = torch.zeros_like(hidden)
+                gamma = ((ind - self.window[-2]).abs().mean() / (self.window[-1] - self.window[-2]).abs().mean()).clip(1, 1.5)
+                return hidden + (self.window[-2] + gamma * (self.window[-1] - self.window[-2]))
+            return hidden + self.prev_residual
+        for blk in core.transformer_blocks[self.probe_depth:]:
+            enc, hidden = blk(hidden, enc, temb, rope)
+        if flux:
+            import torch
+            n_txt = enc.shape[1]
+            x = torch.cat([enc, hidden], dim=1)
+            for blk in core.single_transformer_blocks:
+                x = blk(x, temb, rope)
+            hidden = x[:, n_txt:]
+        self.prev_residual = hidden - ori
+        self.window.append(self.prev_residual)
+        return hidden
+
+    def apply_cache(self, core, hidden, encoder, temb, rope):
+        return self._run(core, hidden, encoder, temb, rope, flux=True)
+
+    def apply_cache_qwen(self, core, hidden, encoder, temb, rope):
+        return self._run(core, hidden, encoder, temb, rope, flux=False)

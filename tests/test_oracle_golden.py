@@ -345,3 +345,42 @@ def test_sd3_tiny_core_matches_reference(tag, qt):
         # fp8 also quantises norm_out.linear and proj_out here (sd35.py:326-329): measured 0.10 / 0.013 on |out| ~ 0.8
         lim = {"bf16": (4e-2, 5e-3), "fp8": (1.5e-1, 2e-2), "int8": (5e-2, 8e-3)}[tag]
         assert d.max() <= lim[0] and d.mean() <= lim[1], (tag, ti, d.max().item(), d.mean().item(), ref.float().abs().mean().item())
+
+
+def test_dicache_trace_flux_and_qwen():
+    """DiCache (fastdm/caching/xcaching.py:418-556): probe block, bf16-accumulated delta_y, residual-window extrapolation."""
+    from oracle import qwen as OQ
+    g = load("dicache.npz")
+    state = {"step": 0}
+    mk = lambda: TC.DiCacheOracle(float(g["threshold"]), int(g["probe_depth"]), float(g["ret_ratio"]), "delta_y", lambda: state["step"],
+                                  int(g["total_steps"]))
+    cfg = OF.TINY
+    sd = OF.synth_state_dict(cfg, seed=7)
+    inp = OF.synth_inputs(cfg, 1, 4, 6, 8, seed=9)
+    cache = mk()
+    core = OF.FluxCore(sd, cfg, None, cache=cache)
+
+    def fwd(i, lat, t):
+        state["step"] = i
+        return core.forward(hidden_states=lat, encoder_hidden_states=inp["encoder_hidden_states"], pooled_projections=inp["pooled_projections"],
+                            timestep=t, img_ids=inp["img_ids"], txt_ids=inp["txt_ids"], guidance=torch.tensor([3.5]))[0]
+    lat = _fb_traj(fwd, inp["hidden_states"].clone(), cfg.out_channels)
+    want = [int(x) for x in g["flux_should_calc"]]
+    assert want.count(0) >= 3 and [int(t[2]) for t in cache.trace] == want, cache.trace
+    d = (lat.float() - g["flux_final"].float()).abs()
+    assert d.max() <= 6e-2 and d.mean() <= 8e-3, (d.max().item(), d.mean().item())
+    qcfg = OQ.TINY
+    qsd = OQ.synth_state_dict(qcfg, seed=11)
+    qin = OQ.synth_inputs(qcfg, 1, 6, 4, 7, seed=12)
+    cache = mk()
+    qcore = OQ.QwenCore(qsd, qcfg, torch.int8, cache=cache)
+
+    def qfwd(i, lat, t):
+        state["step"] = i
+        return qcore.forward(hidden_states=lat, encoder_hidden_states=qin["encoder_hidden_states"], timestep=t,
+                             img_shapes=qin["img_shapes"], txt_seq_lens=qin["txt_seq_lens"])[0]
+    lat = _fb_traj(qfwd, qin["hidden_states"].clone(), qcfg.in_channels)
+    want = [int(x) for x in g["qwen_should_calc"]]
+    assert [int(t[2]) for t in cache.trace] == want, cache.trace
+    d = (lat.float() - g["qwen_final"].float()).abs()
+    assert d.max() <= 6e-2 and d.mean() <= 8e-3, (d.max().item(), d.mean().item())

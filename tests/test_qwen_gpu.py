@@ -223,3 +223,52 @@ def test_fbcache_decisions_match_reference_trace_flux_and_qwen():
         lat = (lat.float() + float(dt) * out.float()).to(BF16)
     assert [int(t[3]) for t in cache.trace] == g["flux_should_calc"].tolist(), cache.trace
     close(lat, g["flux_final"], 8e-2, 1e-2, "fbcache flux final latents")
+
+
+def test_dicache_decisions_match_reference_trace_flux_and_qwen():
+    """Probe-based cache (xcaching.py:418-556) on both double-stream families against traces produced by the reference."""
+    from fastdm_amd.caching import AutoCache
+    from fastdm_amd.model_entry import create_model
+    from oracle import flux as OF
+    g = load("dicache.npz")
+    state = {"step": 0}
+    sig = torch.linspace(1.0, 1.0 / 12, 12)
+
+    def make_cache():
+        c = AutoCache.from_dict({"cache_algorithm": "dicache", "enable_caching": True, "threshold": float(g["threshold"]),
+                                 "probe_depth": int(g["probe_depth"]), "ret_ratio": float(g["ret_ratio"]), "rel_l1_distance_algo": "delta_y"})
+        c.config.current_steps_callback = lambda: state["step"]
+        c.config.total_steps_callback = lambda: int(g["total_steps"])
+        return c
+
+    cfg = OQ.TINY
+    cache = make_cache()
+    model = tiny_core(torch.int8, cache=cache, seed=11)
+    qin = dev_inputs(OQ.synth_inputs(cfg, 1, 6, 4, 7, seed=12))
+    lat = qin["hidden_states"].clone()
+    for i in range(12):
+        state["step"] = i
+        out = model(hidden_states=lat, encoder_hidden_states=qin["encoder_hidden_states"], encoder_hidden_states_mask=qin["encoder_hidden_states_mask"],
+                    timestep=sig[i:i + 1].cuda(), img_shapes=qin["img_shapes"], txt_seq_lens=qin["txt_seq_lens"])[0]
+        dt = (sig[i + 1] - sig[i]) if i + 1 < 12 else -sig[i]
+        lat = (lat.float() + float(dt) * out.float()[..., : cfg.in_channels]).to(BF16)
+    assert [int(t[3]) for t in cache.trace] == g["qwen_should_calc"].tolist(), cache.trace
+    close(lat, g["qwen_final"], 8e-2, 1e-2, "dicache qwen final latents")
+
+    fcfg = OF.TINY
+    cache = make_cache()
+    fmodel = create_model("flux", ckpt_path=OF.synth_state_dict(fcfg, seed=7), dtype=BF16, quant_type=None, kernel_backend="hip", cache=cache,
+                          in_channels=fcfg.in_channels, out_channels=fcfg.out_channels, num_layers=fcfg.num_layers,
+                          num_single_layers=fcfg.num_single_layers, attention_head_dim=fcfg.attention_head_dim,
+                          num_attention_heads=fcfg.num_attention_heads, joint_attention_dim=fcfg.joint_attention_dim,
+                          pooled_projection_dim=fcfg.pooled_projection_dim, axes_dims_rope=fcfg.axes_dims_rope).eval()
+    fin = {k: v.cuda() for k, v in OF.synth_inputs(fcfg, 1, 4, 6, 8, seed=9).items()}
+    lat = fin["hidden_states"].clone()
+    for i in range(12):
+        state["step"] = i
+        out = fmodel(hidden_states=lat, encoder_hidden_states=fin["encoder_hidden_states"], pooled_projections=fin["pooled_projections"],
+                     timestep=sig[i:i + 1].cuda(), img_ids=fin["img_ids"], txt_ids=fin["txt_ids"], guidance=torch.tensor([3.5]).cuda())[0]
+        dt = (sig[i + 1] - sig[i]) if i + 1 < 12 else -sig[i]
+        lat = (lat.float() + float(dt) * out.float()).to(BF16)
+    assert [int(t[3]) for t in cache.trace] == g["flux_should_calc"].tolist(), cache.trace
+    close(lat, g["flux_final"], 8e-2, 1e-2, "dicache flux final latents")
