@@ -39,6 +39,7 @@ SIGNATURES = {
     "fdm_gelu": (I32, [P, P, I64, I32, P]),
     "fdm_quant_rowwise_cat2": (I32, [P, P, P, I32, P, I32, I64, P, I32, I64, I64, P]),
     "fdm_qk_norm_rope": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, I32, F32, P]),
+    "fdm_qk_norm_rope_inplace": (I32, [P, P, P, P, I64, I64, I64, I64, I32, I32, F32, P]),
     "fdm_absdiff_sums": (I32, [P, P, P, I64, P]),
     "fdm_synth_fill_bf16": (I32, [P, I64, U32, I32, F32, F32, P]),
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),

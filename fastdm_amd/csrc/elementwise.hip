@@ -447,6 +447,29 @@ __global__ void __launch_bounds__(256) gelu_and_mul_kernel(bf16_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------ q/k norm + rope + scatter
+template <int HD>
+__device__ __forceinline__ Vec8 qk_norm_rope_apply(const Vec8& x, float rs, const bf16_t* __restrict__ w,
+                                                 const bf16_t* __restrict__ cache, int64_t pos, int sub) {
+  Vec8 wv = load8(w + sub * 8), o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o.v[j] = rbf(rbf(x.v[j] * rs) * wv.v[j]);
+  if (cache != nullptr) {
+    const bf16_t* crow = cache + pos * HD;
+    const i32x2 cr = *reinterpret_cast<const i32x2*>(crow + sub * 4);
+    const i32x2 sr = *reinterpret_cast<const i32x2*>(crow + HD / 2 + sub * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t cw = (uint32_t)cr[j >> 1], sw = (uint32_t)sr[j >> 1];
+      float cs = (j & 1) ? __builtin_bit_cast(float, cw & 0xffff0000u) : __builtin_bit_cast(float, cw << 16);
+      float sn = (j & 1) ? __builtin_bit_cast(float, sw & 0xffff0000u) : __builtin_bit_cast(float, sw << 16);
+      float a = o.v[2 * j], bb = o.v[2 * j + 1];
+      o.v[2 * j] = rbf(a * cs) - rbf(bb * sn);
+      o.v[2 * j + 1] = rbf(bb * cs) + rbf(a * sn);
+    }
+  }
+  return o;
+}
+
 // One wave handles one (token, head) pair-of-8-lanes... layout: 16 lanes x 8 elements = one 128-wide head
 // (8 lanes for hd 64).  Each wave covers 64/LPH heads of q, then k; v is copied.
 template <int HD>
@@ -483,24 +506,41 @@ __global__ void __launch_bounds__(256) qk_norm_rope_kernel(bf16_t* __restrict__ 
     return;
   }
   const float rs = rsqrtf(ss / (float)HD + eps);
-  Vec8 wv = load8((which == 0 ? wq : wk) + sub * 8), o;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o.v[j] = rbf(rbf(x.v[j] * rs) * wv.v[j]);
-  if (cache != nullptr) {
-    const bf16_t* crow = cache + pos * HD;
-    const i32x2 cr = *reinterpret_cast<const i32x2*>(crow + sub * 4);
-    const i32x2 sr = *reinterpret_cast<const i32x2*>(crow + HD / 2 + sub * 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint32_t cw = (uint32_t)cr[j >> 1], sw = (uint32_t)sr[j >> 1];
-      float cs = (j & 1) ? __builtin_bit_cast(float, cw & 0xffff0000u) : __builtin_bit_cast(float, cw << 16);
-      float sn = (j & 1) ? __builtin_bit_cast(float, sw & 0xffff0000u) : __builtin_bit_cast(float, sw << 16);
-      float a = o.v[2 * j], bb = o.v[2 * j + 1];
-      o.v[2 * j] = rbf(a * cs) - rbf(bb * sn);
-      o.v[2 * j + 1] = rbf(bb * cs) + rbf(a * sn);
-    }
-  }
+  const Vec8 o = qk_norm_rope_apply<HD>(x, rs, which == 0 ? wq : wk, cache, pos, sub);
   store8((which == 0 ? qo : ko) + orow * inner + head * HD + sub * 8, o);
+}
+
+// In-place variant for a joint [rows, 3*inner] qkv buffer: q and k heads are normalised + rotated where they lie, v is
+// not touched (the attention kernel reads all three through the 3*inner row stride).  Saves the v copy and the separate
+// q/k/v outputs: 4/3 x rows x inner x 2 B of HBM traffic instead of 2 x.  Each 8/16-lane group reads its head before it
+// writes it, so aliasing is safe.
+template <int HD>
+__global__ void __launch_bounds__(256) qk_norm_rope_inplace_kernel(bf16_t* qkv, const bf16_t* __restrict__ wq,
+                                                                   const bf16_t* __restrict__ wk,
+                                                                   const bf16_t* __restrict__ cache, int64_t rows,
+                                                                   int64_t rows_per_batch, int64_t row_stride_batch,
+                                                                   int64_t pos_offset, int heads, float eps) {
+  constexpr int LPH = HD / 8;
+  const int inner = heads * HD;
+  const int items_per_row = 2 * heads;  // (q|k, head)
+  const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPH;
+  const int sub = threadIdx.x % LPH;
+  const bool ok = gid < rows * items_per_row;
+  const int64_t row = ok ? gid / items_per_row : 0;
+  const int it = ok ? (int)(gid - row * items_per_row) : 0;
+  const int which = it / heads, head = it % heads;
+  const int64_t b = row / rows_per_batch, r = row - b * rows_per_batch;
+  bf16_t* p = qkv + (b * row_stride_batch + r) * 3 * inner + (size_t)which * inner + head * HD + sub * 8;
+  Vec8 x;
+  if (ok) x = load8(p);
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ss += x.v[j] * x.v[j];
+#pragma unroll
+  for (int off = LPH / 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  if (!ok) return;
+  const float rs = rsqrtf(ss / (float)HD + eps);
+  store8(p, qk_norm_rope_apply<HD>(x, rs, which == 0 ? wq : wk, cache, pos_offset + r, sub));
 }
 
 // ------------------------------------------------------------------------------------ TeaCache metric
@@ -830,6 +870,31 @@ int fdm_qk_norm_rope(void* q_out, void* k_out, void* v_out, const void* qkv, con
   else if (head_dim == 64) FDM_QK(64);
   else FDM_QK(32);
 #undef FDM_QK
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+int fdm_qk_norm_rope_inplace(void* qkv, const void* wq, const void* wk, const void* cos_sin_cache, int64_t rows,
+                             int64_t rows_per_batch, int64_t batch_row_stride, int64_t pos_offset, int heads,
+                             int head_dim, float eps, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (!qkv || !wq || !wk || rows < 0 || rows_per_batch <= 0 || batch_row_stride < rows_per_batch || pos_offset < 0 ||
+      heads <= 0)
+    return FDM_ERR_INVALID;
+  if (head_dim != 128 && head_dim != 64 && head_dim != 32) return FDM_ERR_UNSUPPORTED;
+  if (!aligned16(qkv) || !aligned16(wq) || !aligned16(wk) || (cos_sin_cache && !aligned16(cos_sin_cache))) return FDM_ERR_INVALID;
+  if (rows == 0) return FDM_OK;
+  const int64_t threads = rows * 2 * heads * (head_dim / 8);
+  const int64_t grid = (threads + 255) / 256;
+  hipStream_t s = to_stream(stream);
+#define FDM_QKI(HD)                                                                                                  \
+  qk_norm_rope_inplace_kernel<HD><<<(unsigned)grid, 256, 0, s>>>((bf16_t*)qkv, (const bf16_t*)wq, (const bf16_t*)wk, \
+                                                                 (const bf16_t*)cos_sin_cache, rows, rows_per_batch,  \
+                                                                 batch_row_stride, pos_offset, heads, eps)
+  if (head_dim == 128) FDM_QKI(128);
+  else if (head_dim == 64) FDM_QKI(64);
+  else FDM_QKI(32);
+#undef FDM_QKI
   FDM_CHECK_LAUNCH();
   return FDM_OK;
 }

@@ -118,11 +118,20 @@ def qk_norm_rope(qkv: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, rope: Op
                                      rows_per_batch, seq_total, seq_offset, heads, head_dim, eps, N.stream()), "qk_norm_rope")
 
 
+def qk_norm_rope_inplace(qkv_rows: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, rope: Optional[torch.Tensor], rows: int,
+                         rows_per_batch: int, batch_row_stride: int, pos_offset: int, heads: int, head_dim: int, eps: float = 1e-6):
+    """RMS-norm(q,k) -> RoPE in place on rows of a joint [B, batch_row_stride, 3*heads*hd] projection buffer; `qkv_rows`
+    is a view starting at the first row to rewrite (row stride 3*heads*hd).  v is left where the GEMM wrote it."""
+    assert qkv_rows.stride(-1) == 1 and qkv_rows.stride(-2) == 3 * heads * head_dim
+    N.check(N.lib().fdm_qk_norm_rope_inplace(N.ptr(qkv_rows), N.ptr(wq), N.ptr(wk), N.ptr(rope), rows, rows_per_batch, batch_row_stride,
+                                             pos_offset, heads, head_dim, eps, N.stream()), "qk_norm_rope_inplace")
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, head_dim: int, scale: float) -> torch.Tensor:
     """Dense attention on [B*S, H*D] buffers (same kernel as operators_set.scaled_dot_product_attention)."""
     S = q.shape[0] // batch
     Sk = k.shape[0] // batch
-    out = torch.empty_like(q)
+    out = torch.empty((q.shape[0], heads * head_dim), device=q.device, dtype=q.dtype)  # q/k/v may be strided views
     ws = N.attn_workspace(q.device, head_dim)
     with span("attn_fwd_bf16", 4.0 * batch * S * Sk * heads * head_dim):
         N.check(N.lib().fdm_attn_fwd(N.ptr(out), N.ptr(q), N.ptr(k), N.ptr(v), batch, S, Sk, heads, heads, head_dim,

@@ -12,6 +12,7 @@ import torch
 
 from fastdm_amd import _native as N
 from fastdm_amd.kernel import fused
+from fastdm_amd.kernel.fused import Quantized
 from fastdm_amd.layer.qlinear import QLinear
 
 BF16 = torch.bfloat16
@@ -61,6 +62,16 @@ class _ActProj:
         self.proj = QLinear(dim_in, dim_out, bias=bias, data_type=data_type)
 
 
+def _rows(x, b: int, rows_per_batch: int, batch: int):
+    """Batch element b's rows of a [B*rows, K] GEMM input (a bf16 matrix or a `Quantized` with its per-row scales)."""
+    if batch == 1:
+        return x
+    lo, hi = b * rows_per_batch, (b + 1) * rows_per_batch
+    if isinstance(x, Quantized):
+        return Quantized(x.q[lo:hi], x.scale[lo:hi], None if x.azp is None else x.azp[lo:hi])
+    return x[lo:hi]
+
+
 class Attention:
     """transformer.py:64-317 restricted to what FLUX instantiates (model/flux.py:39-50,92-104):
     qk_norm='rms_norm', bias=True, either joint (added_kv_proj_dim, context_pre_only=False) or
@@ -90,20 +101,26 @@ class Attention:
 
     # ---- fused path: inputs are [B*S, D] matrices (quantised or bf16), output = attention result [B*S_tot, D]
     def attend(self, xq, batch: int, s_img: int, rope: Optional[torch.Tensor], enc_q=None, s_txt: int = 0) -> torch.Tensor:
+        """Both fused-qkv GEMMs write into ONE joint [B, S_txt+S_img, 3*inner] buffer (text rows first, as the reference
+        concatenates them, transformer.py:288-296); q/k are normalised + rotated in place and the attention kernel reads
+        q, k, v through the 3*inner token stride -- no split, no cat, no copy of v."""
         s_tot = s_img + s_txt
+        inner = self.inner_dim
         dev = (xq.q if hasattr(xq, "q") else xq).device
-        q = torch.empty((batch * s_tot, self.inner_dim), device=dev, dtype=BF16)
-        k = torch.empty_like(q)
-        v = torch.empty_like(q)
+        joint = torch.empty((batch, s_tot, 3 * inner), device=dev, dtype=BF16)
+        for b in range(batch):
+            xb = _rows(xq, b, s_img, batch)
+            if enc_q is not None:
+                QLinear.forward_q_pair(self.qkv, xb, self.add_qkv_proj, _rows(enc_q, b, s_txt, batch), out0=joint[b, s_txt:], out1=joint[b, :s_txt])
+            else:
+                self.qkv.forward_q(xb, out=joint[b])
+        flat = joint.view(batch * s_tot, 3 * inner)
+        fused.qk_norm_rope_inplace(flat[s_txt:], self.norm_q_weight, self.norm_k_weight, rope, batch * s_img, s_img, s_tot, s_txt,
+                                   self.heads, self.head_dim, self.eps)
         if enc_q is not None:
-            qkv, eqkv = QLinear.forward_q_pair(self.qkv, xq, self.add_qkv_proj, enc_q)
-        else:
-            qkv = self.qkv.forward_q(xq)
-        fused.qk_norm_rope(qkv, self.norm_q_weight, self.norm_k_weight, rope, q, k, v, s_img, s_tot, s_txt, self.heads, self.head_dim, self.eps)
-        if enc_q is not None:
-            fused.qk_norm_rope(eqkv, self.norm_added_q_weight, self.norm_added_k_weight, rope, q, k, v, s_txt, s_tot, 0, self.heads,
-                               self.head_dim, self.eps)
-        return fused.attention(q, k, v, batch, self.heads, self.head_dim, self.scale)
+            fused.qk_norm_rope_inplace(flat, self.norm_added_q_weight, self.norm_added_k_weight, rope, batch * s_txt, s_txt, s_tot, 0,
+                                       self.heads, self.head_dim, self.eps)
+        return fused.attention(flat[:, :inner], flat[:, inner:2 * inner], flat[:, 2 * inner:], batch, self.heads, self.head_dim, self.scale)
 
     # ---- reference signature
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None, attention_mask=None,

@@ -207,6 +207,16 @@ int fdm_qk_norm_rope(void* q_out, void* k_out, void* v_out, const void* qkv,
                      int64_t rows, int64_t rows_per_batch, int64_t seq_total, int64_t seq_offset,
                      int heads, int head_dim, float eps, fdm_stream_t stream);
 
+/* The same q/k RMS-norm + RoPE (layer/transformer.py:264-298) applied IN PLACE to a joint projection buffer
+ * [B, batch_row_stride, 3*heads*hd]: the fused-qkv GEMMs of the text and image stream write their rows straight into
+ * it, this kernel rewrites the q and k thirds of `rows` = B*rows_per_batch rows (batch b's rows start at row
+ * b*batch_row_stride of `qkv`, rope position = pos_offset + r) and leaves v alone; fdm_attn_fwd then reads q, k, v
+ * through the 3*heads*hd token stride.  Replaces the reference's split + per-tensor norm + cat; 1/3 less HBM traffic
+ * than fdm_qk_norm_rope.                                                                            */
+int fdm_qk_norm_rope_inplace(void* qkv, const void* wq, const void* wk, const void* cos_sin_cache,
+                             int64_t rows, int64_t rows_per_batch, int64_t batch_row_stride,
+                             int64_t pos_offset, int heads, int head_dim, float eps, fdm_stream_t stream);
+
 /* TeaCache metric (caching/xcaching.py:214): out[0] = sum|a-b|, out[1] = sum|b| (fp32 atomics;
  * caller zeroes out[0..1]).                                                                      */
 int fdm_absdiff_sums(float* out2, const void* a, const void* b, int64_t n, fdm_stream_t stream);

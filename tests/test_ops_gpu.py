@@ -240,6 +240,27 @@ def test_bf16_gemm_and_epilogues():
         ulp_close(out, want, 0.03, f"bf16 gemm epi {epi}", ulps=2)
 
 
+@pytest.mark.parametrize("M,Kd,Nn", [(1, 256, 3072), (2, 3072, 18432), (3, 3072, 1001), (8, 3072, 9216 + 4), (5, 8192, 64)])
+def test_bf16_skinny_rows_gemv_path(M, Kd, Nn):
+    """M <= 8 (the AdaLN modulation / timestep-embedding linears) takes the HBM-streaming GEMV kernel; it must agree
+    with the fp32-accumulate torch product like the tile kernel does, including ragged N and a strided output."""
+    from fastdm_amd import _native as N
+    g = gen(M * 131 + Nn)
+    a, w, bias = rbf(g, M, Kd), rbf(g, Nn, Kd, scale=Kd ** -0.5), rbf(g, Nn, scale=0.1)
+    want = torch.addmm(bias.float(), a.float(), w.float().t()).to(BF16)
+    ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+    ldc = Nn + 8
+    out = torch.full((M, ldc), 7.0, dtype=BF16, device="cuda")
+    N.check(N.lib().fdm_gemm_bf16(out.data_ptr(), ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), M, Nn, Kd, Kd, Kd, ldc, N.EPI_NONE,
+                                  None, 0, None, 0, N.stream()), "gemm_bf16 skinny")
+    ulp_close(out[:, :Nn], want, 0.03, f"gemv {M}x{Kd}x{Nn}", ulps=1)
+    assert (out[:, Nn:] == 7.0).all()                      # nothing written past N
+    out2 = torch.empty((M, Nn), dtype=BF16, device="cuda")   # no bias
+    N.check(N.lib().fdm_gemm_bf16(out2.data_ptr(), ad.data_ptr(), wd.data_ptr(), None, M, Nn, Kd, Kd, Kd, Nn, N.EPI_NONE,
+                                  None, 0, None, 0, N.stream()), "gemm_bf16 skinny nobias")
+    ulp_close(out2, (a.float() @ w.float().t()).to(BF16), 0.03, f"gemv nobias {M}x{Kd}x{Nn}", ulps=1)
+
+
 ATT_SHAPES = [  # /root/reference/tests/test_attention.py:7-21  (B, Sq, Skv, H, hd)
     (1, 4608, 4608, 24, 128), (1, 4110, 4110, 24, 128), (2, 4096, 4096, 10, 64), (2, 4096, 77, 10, 64), (2, 1024, 1024, 20, 64),
     (2, 1024, 77, 20, 64), (1, 4106, 4106, 24, 128), (2, 4685, 4685, 24, 64), (1, 8704, 8704, 24, 128),
