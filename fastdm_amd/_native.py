@@ -39,7 +39,7 @@ SIGNATURES = {
     "fdm_gelu": (I32, [P, P, I64, I32, P]),
     "fdm_quant_rowwise_cat2": (I32, [P, P, P, I32, P, I32, I64, P, I32, I64, I64, P]),
     "fdm_qk_norm_rope": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, I32, F32, P]),
-    "fdm_qk_norm_rope_inplace": (I32, [P, P, P, P, I64, I64, I64, I64, I32, I32, F32, P]),
+    "fdm_qk_norm_rope_inplace": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, P]),
     "fdm_absdiff_sums": (I32, [P, P, P, I64, P]),
     "fdm_synth_fill_bf16": (I32, [P, I64, U32, I32, F32, F32, P]),
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
@@ -52,7 +52,8 @@ class GemmFp8Desc(C.Structure):
     """struct fdm_gemm_fp8_desc (include/fastdm_amd.h)."""
     _fields_ = [("out", P), ("a", P), ("b", P), ("scale_a", P), ("scale_b", P), ("bias", P),
                 ("M", I64), ("N", I64), ("K", I64), ("lda", I64), ("ldb", I64), ("ldc", I64),
-                ("epilogue", I64), ("epi_gate", P), ("epi_gate_stride", I64), ("epi_res", P), ("epi_rows_per_batch", I64)]
+                ("epilogue", I64), ("epi_gate", P), ("epi_gate_stride", I64), ("epi_res", P), ("epi_rows_per_batch", I64),
+                ("out_plane_cols", I64), ("out_plane_stride", I64)]
 
 
 
@@ -60,7 +61,8 @@ class GemmInt8Desc(C.Structure):
     """struct fdm_gemm_int8_desc (include/fastdm_amd.h)."""
     _fields_ = [("out", P), ("a", P), ("b", P), ("scale_a", P), ("scale_b", P), ("azp_adj", P), ("azp", P), ("bias", P),
                 ("M", I64), ("N", I64), ("K", I64), ("lda", I64), ("ldb", I64), ("ldc", I64),
-                ("epilogue", I64), ("epi_gate", P), ("epi_gate_stride", I64), ("epi_res", P), ("epi_rows_per_batch", I64)]
+                ("epilogue", I64), ("epi_gate", P), ("epi_gate_stride", I64), ("epi_res", P), ("epi_rows_per_batch", I64),
+                ("out_plane_cols", I64), ("out_plane_stride", I64)]
 
 
 _lib = None

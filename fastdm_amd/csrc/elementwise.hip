@@ -510,18 +510,19 @@ __global__ void __launch_bounds__(256) qk_norm_rope_kernel(bf16_t* __restrict__ 
   store8((which == 0 ? qo : ko) + orow * inner + head * HD + sub * 8, o);
 }
 
-// In-place variant for a joint [rows, 3*inner] qkv buffer: q and k heads are normalised + rotated where they lie, v is
-// not touched (the attention kernel reads all three through the 3*inner row stride).  Saves the v copy and the separate
-// q/k/v outputs: 4/3 x rows x inner x 2 B of HBM traffic instead of 2 x.  Each 8/16-lane group reads its head before it
-// writes it, so aliasing is safe.
+// In-place variant: the fused-qkv GEMMs have already written q, k and v where the attention kernel reads them (three
+// compact planes via the GEMM's plane-split output, or one interleaved [rows, 3*inner] buffer); q and k heads are
+// normalised + rotated where they lie and v is not touched.  4/3 x rows x inner x 2 B of HBM traffic instead of the
+// scatter kernel's 4 x.  Row r's q head lives at qkv + r*row_stride, its k head k_offset elements further.  Each
+// 8/16-lane group reads its head before it writes it, so aliasing is safe.
 template <int HD>
 __global__ void __launch_bounds__(256) qk_norm_rope_inplace_kernel(bf16_t* qkv, const bf16_t* __restrict__ wq,
                                                                    const bf16_t* __restrict__ wk,
                                                                    const bf16_t* __restrict__ cache, int64_t rows,
                                                                    int64_t rows_per_batch, int64_t row_stride_batch,
+                                                                   int64_t row_stride, int64_t k_offset,
                                                                    int64_t pos_offset, int heads, float eps) {
   constexpr int LPH = HD / 8;
-  const int inner = heads * HD;
   const int items_per_row = 2 * heads;  // (q|k, head)
   const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPH;
   const int sub = threadIdx.x % LPH;
@@ -530,7 +531,7 @@ __global__ void __launch_bounds__(256) qk_norm_rope_inplace_kernel(bf16_t* qkv, 
   const int it = ok ? (int)(gid - row * items_per_row) : 0;
   const int which = it / heads, head = it % heads;
   const int64_t b = row / rows_per_batch, r = row - b * rows_per_batch;
-  bf16_t* p = qkv + (b * row_stride_batch + r) * 3 * inner + (size_t)which * inner + head * HD + sub * 8;
+  bf16_t* p = qkv + (b * row_stride_batch + r) * row_stride + (which ? k_offset : 0) + head * HD + sub * 8;
   Vec8 x;
   if (ok) x = load8(p);
   float ss = 0.f;
@@ -875,11 +876,11 @@ int fdm_qk_norm_rope(void* q_out, void* k_out, void* v_out, const void* qkv, con
 }
 
 int fdm_qk_norm_rope_inplace(void* qkv, const void* wq, const void* wk, const void* cos_sin_cache, int64_t rows,
-                             int64_t rows_per_batch, int64_t batch_row_stride, int64_t pos_offset, int heads,
-                             int head_dim, float eps, fdm_stream_t stream) {
+                             int64_t rows_per_batch, int64_t batch_row_stride, int64_t row_stride, int64_t k_offset,
+                             int64_t pos_offset, int heads, int head_dim, float eps, fdm_stream_t stream) {
   (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!qkv || !wq || !wk || rows < 0 || rows_per_batch <= 0 || batch_row_stride < rows_per_batch || pos_offset < 0 ||
-      heads <= 0)
+      heads <= 0 || row_stride < (int64_t)heads * head_dim || (row_stride & 7) || k_offset < (int64_t)heads * head_dim || (k_offset & 7))
     return FDM_ERR_INVALID;
   if (head_dim != 128 && head_dim != 64 && head_dim != 32) return FDM_ERR_UNSUPPORTED;
   if (!aligned16(qkv) || !aligned16(wq) || !aligned16(wk) || (cos_sin_cache && !aligned16(cos_sin_cache))) return FDM_ERR_INVALID;
@@ -890,7 +891,7 @@ int fdm_qk_norm_rope_inplace(void* qkv, const void* wq, const void* wk, const vo
 #define FDM_QKI(HD)                                                                                                  \
   qk_norm_rope_inplace_kernel<HD><<<(unsigned)grid, 256, 0, s>>>((bf16_t*)qkv, (const bf16_t*)wq, (const bf16_t*)wk, \
                                                                  (const bf16_t*)cos_sin_cache, rows, rows_per_batch,  \
-                                                                 batch_row_stride, pos_offset, heads, eps)
+                                                                 batch_row_stride, row_stride, k_offset, pos_offset, heads, eps)
   if (head_dim == 128) FDM_QKI(128);
   else if (head_dim == 64) FDM_QKI(64);
   else FDM_QKI(32);

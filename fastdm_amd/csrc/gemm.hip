@@ -66,6 +66,8 @@ struct GemmProblem {
   int tiles_m, tiles_n;
   int epi;           // FDM_EPI_* (uniform per problem); FDM_EPI_GATE_RESIDUAL_F32 is stored as GATE_RESIDUAL + gate_f32
   int gate_f32;      // the gate vector is fp32 and the epilogue rounds once
+  int plane_cols;    // > 0: output column n lands in plane n / plane_cols at column n % plane_cols (fused-qkv -> q|k|v planes)
+  int64_t plane_stride;  // elements between planes
 };
 
 struct GemmGroup {
@@ -460,13 +462,15 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
     const int ncol = n0 + wn * 64 + ch * 8;
     const bool n_ok = full || ncol < p.N;      // N % 8 == 0 is required by the host check for this path
     const int ncc = n_ok ? ncol : 0;
+    // plane mode: the 8-column piece of this lane never straddles a plane (plane_cols % 8 == 0)
+    const int64_t ccol = p.plane_cols > 0 ? (int64_t)(ncc / p.plane_cols) * p.plane_stride + (ncc % p.plane_cols) : (int64_t)ncc;
     auto lds_row = [&](int it) -> i32x4 {
       const int r = it * 8 + rsub;
       return *reinterpret_cast<const i32x4*>(wt + r * 128 + ((ch ^ (r & 7)) << 4));
     };
     auto store_row = [&](int it, const i32x4& v) {
       const int m = m0 + wm * 128 + it * 8 + rsub;
-      if (n_ok && (full || m < p.M) && !(grp.debug & 4)) *reinterpret_cast<i32x4*>(p.C + (int64_t)m * p.ldc + ncc) = v;
+      if (n_ok && (full || m < p.M) && !(grp.debug & 4)) *reinterpret_cast<i32x4*>(p.C + (int64_t)m * p.ldc + ccol) = v;
     };
     // out = res + gate * y.  bf16 gates (FLUX / Qwen-Image): the product is rounded to bf16 before the add, as the
     // reference's two bf16 ops do; fp32 gates (Wan: `(x.float() + y * gate).type_as(x)`, wan.py:102,113): one rounding.
@@ -592,13 +596,14 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s) {
 
 static int fill_problem(GemmProblem& p, void* out, const void* a, const void* b, int64_t M, int64_t N, int64_t K, int64_t lda,
                         int64_t ldb, int64_t ldc, int elem_bytes, int epi, const void* gate, int64_t gate_stride, const void* res,
-                        int64_t rpb) {
+                        int64_t rpb, int64_t plane_cols = 0) {
   if (!out || !a || !b || M <= 0 || N <= 0 || K <= 0) return FDM_ERR_INVALID;
+  const int64_t min_ldc = plane_cols > 0 ? plane_cols : N;
   if (M > 0x7fffffff || N > 0x7fffffff) return FDM_ERR_UNSUPPORTED;
   if (epi < FDM_EPI_NONE || epi > FDM_EPI_GATE_RESIDUAL_F32) return FDM_ERR_UNSUPPORTED;
   const int gate_f32 = epi == FDM_EPI_GATE_RESIDUAL_F32;
   if (gate_f32) epi = FDM_EPI_GATE_RESIDUAL;
-  if ((K * elem_bytes) % 16 || (lda * elem_bytes) % 16 || (ldb * elem_bytes) % 16 || lda < K || ldb < K || ldc < N)
+  if ((K * elem_bytes) % 16 || (lda * elem_bytes) % 16 || (ldb * elem_bytes) % 16 || lda < K || ldb < K || ldc < min_ldc)
     return FDM_ERR_INVALID;
   if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(b) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) || (ldc & 7) || (N & 7))
     return FDM_ERR_INVALID;
@@ -625,6 +630,19 @@ static int fill_problem(GemmProblem& p, void* out, const void* a, const void* b,
   p.sa = p.sb = nullptr;
   p.bias = nullptr;
   p.azp = p.azp_adj = nullptr;
+  p.plane_cols = 0;
+  p.plane_stride = 0;
+  return FDM_OK;
+}
+
+// Plane-split output of a fused projection (q|k|v): validated separately because ldc is then the PLANE's row stride.
+static int set_planes(GemmProblem& p, int64_t plane_cols, int64_t plane_stride) {
+  if (plane_cols == 0) return FDM_OK;
+  if (plane_cols < 8 || (plane_cols & 7) || plane_cols > p.N || p.ldc < plane_cols || plane_stride <= 0 || (plane_stride & 7) ||
+      p.epi >= FDM_EPI_GATE_RESIDUAL)
+    return FDM_ERR_INVALID;
+  p.plane_cols = (int)plane_cols;
+  p.plane_stride = plane_stride;
   return FDM_OK;
 }
 
@@ -762,7 +780,8 @@ int fdm_gemm_w8a8_fp8_x2(const fdm_gemm_fp8_desc* d0, const fdm_gemm_fp8_desc* d
     const fdm_gemm_fp8_desc* d = ds[i];
     if (d->M == 0 && d->N > 0 && d->K > 0) continue;
     int rc = fill_problem(g.p[n], d->out, d->a, d->b, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, 1, (int)d->epilogue, d->epi_gate,
-                          d->epi_gate_stride, d->epi_res, d->epi_rows_per_batch);
+                          d->epi_gate_stride, d->epi_res, d->epi_rows_per_batch, d->out_plane_cols);
+    if (rc == FDM_OK) rc = set_planes(g.p[n], d->out_plane_cols, d->out_plane_stride);
     if (rc != FDM_OK) return rc;
     if (!d->scale_a || !d->scale_b) return FDM_ERR_INVALID;
     g.p[n].sa = d->scale_a;
@@ -805,7 +824,8 @@ int fdm_gemm_w8a8_int8_x2(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_desc
     const fdm_gemm_int8_desc* d = ds[i];
     if (d->M == 0 && d->N > 0 && d->K > 0) continue;
     int rc = fill_problem(g.p[n], d->out, d->a, d->b, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, 1, (int)d->epilogue, d->epi_gate,
-                          d->epi_gate_stride, d->epi_res, d->epi_rows_per_batch);
+                          d->epi_gate_stride, d->epi_res, d->epi_rows_per_batch, d->out_plane_cols);
+    if (rc == FDM_OK) rc = set_planes(g.p[n], d->out_plane_cols, d->out_plane_stride);
     if (rc != FDM_OK) return rc;
     if (!d->scale_a || !d->scale_b || ((d->azp == nullptr) != (d->azp_adj == nullptr))) return FDM_ERR_INVALID;
     if (d->azp_adj && (reinterpret_cast<uintptr_t>(d->azp_adj) & 15)) return FDM_ERR_INVALID;

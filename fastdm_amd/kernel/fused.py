@@ -118,13 +118,15 @@ def qk_norm_rope(qkv: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, rope: Op
                                      rows_per_batch, seq_total, seq_offset, heads, head_dim, eps, N.stream()), "qk_norm_rope")
 
 
-def qk_norm_rope_inplace(qkv_rows: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, rope: Optional[torch.Tensor], rows: int,
-                         rows_per_batch: int, batch_row_stride: int, pos_offset: int, heads: int, head_dim: int, eps: float = 1e-6):
-    """RMS-norm(q,k) -> RoPE in place on rows of a joint [B, batch_row_stride, 3*heads*hd] projection buffer; `qkv_rows`
-    is a view starting at the first row to rewrite (row stride 3*heads*hd).  v is left where the GEMM wrote it."""
-    assert qkv_rows.stride(-1) == 1 and qkv_rows.stride(-2) == 3 * heads * head_dim
-    N.check(N.lib().fdm_qk_norm_rope_inplace(N.ptr(qkv_rows), N.ptr(wq), N.ptr(wk), N.ptr(rope), rows, rows_per_batch, batch_row_stride,
-                                             pos_offset, heads, head_dim, eps, N.stream()), "qk_norm_rope_inplace")
+def qk_norm_rope_inplace(q_rows: torch.Tensor, k_rows: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, rope: Optional[torch.Tensor],
+                         rows: int, rows_per_batch: int, batch_row_stride: int, pos_offset: int, heads: int, head_dim: int,
+                         eps: float = 1e-6):
+    """RMS-norm(q,k) -> RoPE in place.  `q_rows` / `k_rows` are views of the same allocation starting at the first row
+    to rewrite (equal row strides): planes of a plane-split projection or thirds of an interleaved qkv buffer."""
+    assert q_rows.stride(-1) == 1 and k_rows.stride(-1) == 1 and q_rows.stride(-2) == k_rows.stride(-2)
+    k_off = (k_rows.data_ptr() - q_rows.data_ptr()) // q_rows.element_size()
+    N.check(N.lib().fdm_qk_norm_rope_inplace(N.ptr(q_rows), N.ptr(wq), N.ptr(wk), N.ptr(rope), rows, rows_per_batch, batch_row_stride,
+                                             q_rows.stride(-2), k_off, pos_offset, heads, head_dim, eps, N.stream()), "qk_norm_rope_inplace")
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, head_dim: int, scale: float) -> torch.Tensor:

@@ -147,6 +147,43 @@ class QLinear:
             return o0, o1
         return (lin0.forward_q(x0, epilogue, gate0, res0, rpb0, out0), lin1.forward_q(x1, epilogue, gate1, res1, rpb1, out1))
 
+    @staticmethod
+    def forward_q_planes(items, planes: torch.Tensor):
+        """Fused projections whose N = P*C output columns are split into P compact planes (q|k|v): `planes` is a
+        contiguous [P, rows, C] buffer and `items` = [(linear, x, first_row)], each linear writing its M rows at
+        first_row of every plane.  W8A8 linears go two per launch through the GEMM's plane-split output; bf16 linears
+        run one GEMM per plane on a column slice of the weight."""
+        import ctypes
+        P_, rows, Cc = planes.shape
+        assert planes.is_contiguous() and all(lin.weight.shape[1] == P_ * Cc for lin, _, _ in items)
+        pending = []
+        for lin, x, r0 in items:
+            if lin.quant_type is None:
+                wt = lin.weight
+                K = wt.shape[0]
+                a = x
+                assert a.dtype == lin.dtype and a.stride(1) == 1
+                for pl in range(P_):
+                    with span("gemm_bf16", 2.0 * a.shape[0] * Cc * K):
+                        N.check(N.lib().fdm_gemm_bf16(N.ptr(planes[pl, r0:]), N.ptr(a), N.ptr(wt[:, pl * Cc:]),
+                                                      N.ptr(lin.bias[pl * Cc:]) if lin.bias is not None else None, a.shape[0], Cc, K,
+                                                      a.stride(0), wt.stride(1), Cc, N.EPI_NONE, None, 0, None, 0, N.stream()), "bf16 linear")
+                continue
+            d, _, f = lin._desc(x, N.EPI_NONE, None, None, 0, planes[0, r0:])
+            d.out_plane_cols, d.out_plane_stride = Cc, rows * Cc
+            pending.append((lin.quant_type, d, f))
+        while pending:
+            qt, d0, f0 = pending.pop(0)
+            mate = next((i for i, (q2, _, _) in enumerate(pending) if q2 == qt), None)
+            if mate is not None:
+                _, d1, f1 = pending.pop(mate)
+            else:
+                d1, f1 = type(d0)(), 0.0
+                d1.M, d1.N, d1.K = 0, 1, 1          # an empty problem: skipped by the library
+            fn, name = (N.lib().fdm_gemm_w8a8_fp8_x2, "gemm_w8a8_fp8") if qt == FP8 else (N.lib().fdm_gemm_w8a8_int8_x2, "gemm_w8a8_int8")
+            with span(name, f0 + f1):
+                N.check(fn(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "plane-split linear")
+
     def forward(self, input_tensor: torch.Tensor) -> torch.Tensor:
         """fastdm/layer/qlinear.py:56-81: quantise per token, scaled GEMM (+bias), restore the leading dims."""
         if self.dtype == torch.float32:

@@ -101,26 +101,26 @@ class Attention:
 
     # ---- fused path: inputs are [B*S, D] matrices (quantised or bf16), output = attention result [B*S_tot, D]
     def attend(self, xq, batch: int, s_img: int, rope: Optional[torch.Tensor], enc_q=None, s_txt: int = 0) -> torch.Tensor:
-        """Both fused-qkv GEMMs write into ONE joint [B, S_txt+S_img, 3*inner] buffer (text rows first, as the reference
-        concatenates them, transformer.py:288-296); q/k are normalised + rotated in place and the attention kernel reads
-        q, k, v through the 3*inner token stride -- no split, no cat, no copy of v."""
+        """Both fused-qkv GEMMs write straight into three joint planes q|k|v [B*(S_txt+S_img), inner] (text rows first,
+        as the reference concatenates them, transformer.py:288-296) through the GEMM's plane-split output; q/k are
+        normalised + rotated in place and the attention kernel reads the planes -- no chunk, no cat, no copy of v."""
         s_tot = s_img + s_txt
         inner = self.inner_dim
         dev = (xq.q if hasattr(xq, "q") else xq).device
-        joint = torch.empty((batch, s_tot, 3 * inner), device=dev, dtype=BF16)
+        planes = torch.empty((3, batch * s_tot, inner), device=dev, dtype=BF16)
+        items = []
         for b in range(batch):
-            xb = _rows(xq, b, s_img, batch)
+            items.append((self.qkv, _rows(xq, b, s_img, batch), b * s_tot + s_txt))
             if enc_q is not None:
-                QLinear.forward_q_pair(self.qkv, xb, self.add_qkv_proj, _rows(enc_q, b, s_txt, batch), out0=joint[b, s_txt:], out1=joint[b, :s_txt])
-            else:
-                self.qkv.forward_q(xb, out=joint[b])
-        flat = joint.view(batch * s_tot, 3 * inner)
-        fused.qk_norm_rope_inplace(flat[s_txt:], self.norm_q_weight, self.norm_k_weight, rope, batch * s_img, s_img, s_tot, s_txt,
+                items.append((self.add_qkv_proj, _rows(enc_q, b, s_txt, batch), b * s_tot))
+        QLinear.forward_q_planes(items, planes)
+        q, k, v = planes[0], planes[1], planes[2]
+        fused.qk_norm_rope_inplace(q[s_txt:], k[s_txt:], self.norm_q_weight, self.norm_k_weight, rope, batch * s_img, s_img, s_tot, s_txt,
                                    self.heads, self.head_dim, self.eps)
         if enc_q is not None:
-            fused.qk_norm_rope_inplace(flat, self.norm_added_q_weight, self.norm_added_k_weight, rope, batch * s_txt, s_txt, s_tot, 0,
+            fused.qk_norm_rope_inplace(q, k, self.norm_added_q_weight, self.norm_added_k_weight, rope, batch * s_txt, s_txt, s_tot, 0,
                                        self.heads, self.head_dim, self.eps)
-        return fused.attention(flat[:, :inner], flat[:, inner:2 * inner], flat[:, 2 * inner:], batch, self.heads, self.head_dim, self.scale)
+        return fused.attention(q, k, v, batch, self.heads, self.head_dim, self.scale)
 
     # ---- reference signature
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None, attention_mask=None,

@@ -103,6 +103,11 @@ typedef struct fdm_gemm_fp8_desc {
   int64_t epi_gate_stride;
   const void* epi_res;
   int64_t epi_rows_per_batch;
+  /* Plane-split output (0 = off): output column n is written to out + (n / out_plane_cols) * out_plane_stride
+   * + row*ldc + n % out_plane_cols, so a fused q|k|v projection (layer/transformer.py:264-266 `chunk(3)`) lands in
+   * three compact [rows, out_plane_cols] planes; ldc is then the plane's row stride.  Not with residual epilogues. */
+  int64_t out_plane_cols;
+  int64_t out_plane_stride;
 } fdm_gemm_fp8_desc;
 int fdm_gemm_w8a8_fp8_x2(const fdm_gemm_fp8_desc* d0, const fdm_gemm_fp8_desc* d1, fdm_stream_t stream);
 
@@ -134,6 +139,8 @@ typedef struct fdm_gemm_int8_desc {
   int64_t epi_gate_stride;
   const void* epi_res;
   int64_t epi_rows_per_batch;
+  int64_t out_plane_cols;   /* as in fdm_gemm_fp8_desc */
+  int64_t out_plane_stride;
 } fdm_gemm_int8_desc;
 int fdm_gemm_w8a8_int8_x2(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_desc* d1, fdm_stream_t stream);
 
@@ -207,15 +214,17 @@ int fdm_qk_norm_rope(void* q_out, void* k_out, void* v_out, const void* qkv,
                      int64_t rows, int64_t rows_per_batch, int64_t seq_total, int64_t seq_offset,
                      int heads, int head_dim, float eps, fdm_stream_t stream);
 
-/* The same q/k RMS-norm + RoPE (layer/transformer.py:264-298) applied IN PLACE to a joint projection buffer
- * [B, batch_row_stride, 3*heads*hd]: the fused-qkv GEMMs of the text and image stream write their rows straight into
- * it, this kernel rewrites the q and k thirds of `rows` = B*rows_per_batch rows (batch b's rows start at row
- * b*batch_row_stride of `qkv`, rope position = pos_offset + r) and leaves v alone; fdm_attn_fwd then reads q, k, v
- * through the 3*heads*hd token stride.  Replaces the reference's split + per-tensor norm + cat; 1/3 less HBM traffic
- * than fdm_qk_norm_rope.                                                                            */
+/* The same q/k RMS-norm + RoPE (layer/transformer.py:264-298) applied IN PLACE, for when the fused-qkv GEMMs of the
+ * text and image stream have already written q, k, v where fdm_attn_fwd reads them -- three compact planes
+ * (fdm_gemm_*_desc.out_plane_cols: row_stride = heads*hd, k_offset = plane stride) or one interleaved
+ * [rows, 3*heads*hd] buffer (row_stride = 3*heads*hd, k_offset = heads*hd).  Rewrites the q and k heads of
+ * `rows` = B*rows_per_batch rows (batch b's rows start at row b*batch_row_stride of `qkv`, rope position =
+ * pos_offset + r); v is not touched.  Replaces the reference's chunk + per-tensor norm + cat with a third of the
+ * scatter kernel's HBM traffic.                                                                      */
 int fdm_qk_norm_rope_inplace(void* qkv, const void* wq, const void* wk, const void* cos_sin_cache,
                              int64_t rows, int64_t rows_per_batch, int64_t batch_row_stride,
-                             int64_t pos_offset, int heads, int head_dim, float eps, fdm_stream_t stream);
+                             int64_t row_stride, int64_t k_offset, int64_t pos_offset,
+                             int heads, int head_dim, float eps, fdm_stream_t stream);
 
 /* TeaCache metric (caching/xcaching.py:214): out[0] = sum|a-b|, out[1] = sum|b| (fp32 atomics;
  * caller zeroes out[0..1]).                                                                      */

@@ -222,6 +222,38 @@ def test_int8_matmul_reference_shapes(K, M, Kd, Nn):
     assert torch.equal(got[rows], ref), f"int8 {M}x{Kd}x{Nn}: max diff {(got[rows].float() - ref.float()).abs().max()}"
 
 
+@pytest.mark.parametrize("quant", ["fp8", "int8", "bf16"])
+@pytest.mark.parametrize("C", [256, 152])      # plane width: a multiple of the 256-column tile, and one that straddles tiles
+def test_plane_split_projection_equals_plain_output(K, quant, C):
+    """The fused-qkv GEMMs write q|k|v into three compact planes (fdm_gemm_*_desc.out_plane_cols).  Same bits as the
+    plain [M, 3C] output, rows of the two streams interleaved as the joint [text ; image] layout wants."""
+    from fastdm_amd.layer.qlinear import QLinear
+    g = gen(C)
+    Kd, m_img, m_txt = 192, 300, 37
+    dt = {"fp8": FP8, "int8": torch.int8, "bf16": None}[quant]
+    lins = []
+    for i in range(2):
+        lin = QLinear(Kd, 3 * C, bias=True, data_type=BF16)
+        w, bias = rbf(g, 3 * C, Kd, scale=Kd ** -0.5), rbf(g, 3 * C, scale=0.1)
+        lin.weight_loading_and_quant([w.t()], [bias], dt)
+        lins.append(lin)
+    xi, xt = rbf(g, m_img, Kd).cuda(), rbf(g, m_txt, Kd).cuda()
+    qi = lins[0].quantize_input(xi) if dt is not None else xi
+    qt = lins[1].quantize_input(xt) if dt is not None else xt
+    plain_i, plain_t = lins[0].forward_q(qi), lins[1].forward_q(qt)
+    rows = m_txt + m_img
+    planes = torch.full((3, rows + 5, C), 3.0, dtype=BF16, device="cuda")
+    QLinear.forward_q_planes([(lins[0], qi, m_txt), (lins[1], qt, 0)], planes)
+    for pl in range(3):
+        assert torch.equal(planes[pl, :m_txt], plain_t[:, pl * C:(pl + 1) * C]), (quant, C, pl, "txt")
+        assert torch.equal(planes[pl, m_txt:rows], plain_i[:, pl * C:(pl + 1) * C]), (quant, C, pl, "img")
+        assert (planes[pl, rows:] == 3.0).all()
+    # a single stream (FLUX single blocks) pairs with an empty problem
+    planes1 = torch.empty((3, m_img, C), dtype=BF16, device="cuda")
+    QLinear.forward_q_planes([(lins[0], qi, 0)], planes1)
+    assert torch.equal(planes1.permute(1, 0, 2).reshape(m_img, 3 * C), plain_i)
+
+
 def test_bf16_gemm_and_epilogues():
     from fastdm_amd import _native as N
     g = gen(5)
