@@ -21,6 +21,7 @@ from fastdm_amd.kernel.utils import set_global_backend
 from fastdm_amd.model.flux import FluxTransformer2DModelCore
 from fastdm_amd.model.qwenimage import QwenImageTransformer2DModelCore
 from fastdm_amd.model.sd35 import SD3TransformerModelCore
+from fastdm_amd.model.sdxl import SDXLUNetModelCore
 from fastdm_amd.model.wan import WanTransformer3DModelCore
 
 
@@ -132,6 +133,30 @@ class SD35TransformerWrapper(BaseModelWrapper):
         return self.core_model.forward(hidden_states, **kwargs)
 
 
+class SDXLUNetModelWrapper(BaseModelWrapper):
+    """model_entry.py:240-291 (IP-adapter arguments are accepted and rejected: that branch is not built)."""
+
+    def __init__(self, ckpt_path=None, in_channels=4, dtype=torch.bfloat16, is_ipadapter=False, ipadapter_scale=0.6,
+                 diffu_ipadapter_encoder_hid_proj=None, quant_type=None, kernel_backend: str = "hip", **kwargs):
+        super().__init__(kernel_backend)
+        self.config = self._create_diffusers_config(in_channels=in_channels, addition_time_embed_dim=256, sample_size=128,
+                                                    time_cond_proj_dim=None, ip_adapter=is_ipadapter, dtype=dtype)
+        self.dtype = dtype
+        self.core_model = SDXLUNetModelCore(in_channels=in_channels, is_ip_adapter=is_ipadapter, ip_adapter_scale=ipadapter_scale,
+                                            diffu_ipadapter_encoder_hid_proj=diffu_ipadapter_encoder_hid_proj, data_type=dtype,
+                                            quant_dtype=quant_type, **kwargs)
+        self.add_embedding = self.core_model.add_embedding
+        self.encoder_hid_proj = self.core_model.encoder_hid_proj
+        if isinstance(ckpt_path, dict) or (ckpt_path and os.path.exists(ckpt_path)):
+            self.core_model.weight_loading(ckpt_path, data_type=dtype, device_type="cuda")
+        elif ckpt_path:
+            print(f"Warning: Checkpoint path {ckpt_path} does not exist")
+
+    @torch.no_grad()
+    def forward(self, sample, timesteps, encoder_hidden_states, added_cond_kwargs, **kwargs):
+        return self.core_model.forward(sample, timesteps, encoder_hidden_states, added_cond_kwargs, **kwargs)
+
+
 _WAN_A14B_CONFIG = dict(patch_size=(1, 2, 2), num_attention_heads=40, attention_head_dim=128, in_channels=16, out_channels=16, text_dim=4096,
                         freq_dim=256, ffn_dim=13824, num_layers=40, qk_norm="rms_norm_across_heads", eps=1e-6, rope_max_seq_len=1024,
                         image_dim=None)
@@ -171,8 +196,8 @@ class WanTransformer3DWrapper(BaseModelWrapper):
 class ModelWrapperFactory:
     """model_entry.py:463-497."""
     _WRAPPER_MAPPING = {"flux": FluxTransformerWrapper, "qwen": QwenTransformerWrapper, "wan": WanTransformer3DWrapper,
-                        "sd35": SD35TransformerWrapper}
-    _NOT_BUILT = ("sdxl", "sdxl-controlnet", "flux-controlnet")
+                        "sd35": SD35TransformerWrapper, "sdxl": SDXLUNetModelWrapper}
+    _NOT_BUILT = ("sdxl-controlnet", "flux-controlnet")
 
     @classmethod
     def create_wrapper(cls, model_type: str, **kwargs) -> BaseModelWrapper:

@@ -319,3 +319,111 @@ def sd3_step_inputs(batch, height, width, n_txt=333, in_channels=16, joint_atten
     return dict(hidden_states=normal("sd3.input.latents", (batch, in_channels, height, width), 1.0, 0.0, seed, device),
                 encoder_hidden_states=uniform("sd3.input.prompt_embeds", (batch, n_txt, joint_attention_dim), seed, device),
                 pooled_projections=uniform("sd3.input.pooled", (batch, pooled_projection_dim), seed, device))
+
+
+class SyntheticSDXLStateDict(dict):
+    """Lazily generated diffusers-named SDXL UNet state_dict, bit-identical to oracle.sdxl.synth_state_dict (the key
+    inventory follows the loaders of fastdm/model/sdxl.py:178-373)."""
+
+    def __init__(self, in_channels=4, block_out_channels=(320, 640, 1280), transformer_layers=(2, 10), mid_layers=10, cross_attention_dim=2048,
+                 time_proj_dim=320, time_embed_dim=1280, addition_time_embed_dim=256, text_embed_dim=1280, seed=0, device="cuda", **_):
+        super().__init__()
+        self.seed, self.device = seed, device
+        c0, c1, c2 = block_out_channels
+        l1, l2 = transformer_layers
+        te, x = time_embed_dim, cross_attention_dim
+        spec = {}
+
+        def lin(name, k, n, bias=True):
+            spec[f"{name}.weight"] = ((n, k), "w")
+            if bias:
+                spec[f"{name}.bias"] = ((n,), "b")
+
+        def norm(name, c):
+            spec[f"{name}.weight"] = ((c,), "rms")
+            spec[f"{name}.bias"] = ((c,), "b")
+
+        def conv(name, cout, cin, k):
+            spec[f"{name}.weight"] = ((cout, cin, k, k), "conv")
+            spec[f"{name}.bias"] = ((cout,), "b")
+
+        def resnet(name, cin, cout, shortcut):
+            norm(f"{name}.norm1", cin)
+            conv(f"{name}.conv1", cout, cin, 3)
+            lin(f"{name}.time_emb_proj", te, cout)
+            norm(f"{name}.norm2", cout)
+            conv(f"{name}.conv2", cout, cout, 3)
+            if shortcut:
+                conv(f"{name}.conv_shortcut", cout, cin, 1)
+
+        def transformer(name, c, layers):
+            norm(f"{name}.norm", c)
+            lin(f"{name}.proj_in", c, c)
+            lin(f"{name}.proj_out", c, c)
+            for j in range(layers):
+                b = f"{name}.transformer_blocks.{j}"
+                for n in ("norm1", "norm2", "norm3"):
+                    norm(f"{b}.{n}", c)
+                for n in ("to_q", "to_k", "to_v"):
+                    lin(f"{b}.attn1.{n}", c, c, bias=False)
+                lin(f"{b}.attn2.to_q", c, c, bias=False)
+                lin(f"{b}.attn2.to_k", x, c, bias=False)
+                lin(f"{b}.attn2.to_v", x, c, bias=False)
+                lin(f"{b}.attn1.to_out.0", c, c)
+                lin(f"{b}.attn2.to_out.0", c, c)
+                lin(f"{b}.ff.net.0.proj", c, 8 * c)
+                lin(f"{b}.ff.net.2", 4 * c, c)
+
+        conv("conv_in", c0, in_channels, 3)
+        for name, k in (("time_embedding", time_proj_dim), ("add_embedding", text_embed_dim + 6 * addition_time_embed_dim)):
+            lin(f"{name}.linear_1", k, te)
+            lin(f"{name}.linear_2", te, te)
+        resnet("down_blocks.0.resnets.0", c0, c0, False)
+        resnet("down_blocks.0.resnets.1", c0, c0, False)
+        for m, (cin, cout, layers) in ((1, (c0, c1, l1)), (2, (c1, c2, l2))):
+            resnet(f"down_blocks.{m}.resnets.0", cin, cout, True)
+            resnet(f"down_blocks.{m}.resnets.1", cout, cout, False)
+            for i in range(2):
+                transformer(f"down_blocks.{m}.attentions.{i}", cout, layers)
+        for m, c in ((0, c0), (1, c1)):
+            conv(f"down_blocks.{m}.downsamplers.0.conv", c, c, 3)
+        resnet("mid_block.resnets.0", c2, c2, False)
+        resnet("mid_block.resnets.1", c2, c2, False)
+        transformer("mid_block.attentions.0", c2, mid_layers)
+        for m, (cin, cout, prev, layers) in ((0, (c1, c2, c2, l2)), (1, (c0, c1, c2, l1)), (2, (c0, c0, c1, 0))):
+            for i, rin in enumerate((prev + cout, 2 * cout, cout + cin)):
+                resnet(f"up_blocks.{m}.resnets.{i}", rin, cout, True)
+            if m < 2:
+                for i in range(3):
+                    transformer(f"up_blocks.{m}.attentions.{i}", cout, layers)
+                conv(f"up_blocks.{m}.upsamplers.0.conv", cout, cout, 3)
+        norm("conv_norm_out", c0)
+        conv("conv_out", in_channels, c0, 3)
+        self.spec = spec
+        for k in spec:
+            dict.__setitem__(self, k, None)
+
+    def _make(self, name):
+        shape, kind = self.spec[name]
+        key = "sdxl." + name
+        if kind == "w":
+            return normal(key, shape, (1.0 / shape[1]) ** 0.5, 0.0, self.seed, self.device)
+        if kind == "conv":
+            return normal(key, shape, (1.0 / math.prod(shape[1:])) ** 0.5, 0.0, self.seed, self.device)
+        if kind == "b":
+            return normal(key, shape, 0.02, 0.0, self.seed, self.device)
+        return normal(key, shape, 0.1, 1.0, self.seed, self.device)
+
+    def __getitem__(self, name):
+        return self._make(name)
+
+    def get(self, name, default=None):
+        return self._make(name) if name in self.spec else default
+
+
+def sdxl_step_inputs(batch, height, width, n_txt=77, in_channels=4, cross_attention_dim=2048, text_embed_dim=1280, seed=0, device="cuda"):
+    """Same tensors as oracle.sdxl.synth_inputs (bit-identical); height/width are LATENT sizes (pixels / 8)."""
+    ids = torch.tensor([height * 8, width * 8, 0, 0, height * 8, width * 8], dtype=torch.bfloat16, device=device).repeat(batch, 1)
+    return dict(sample=normal("sdxl.input.latents", (batch, in_channels, height, width), 1.0, 0.0, seed, device),
+                encoder_hidden_states=uniform("sdxl.input.prompt_embeds", (batch, n_txt, cross_attention_dim), seed, device),
+                added_cond_kwargs={"text_embeds": uniform("sdxl.input.pooled", (batch, text_embed_dim), seed, device), "time_ids": ids})

@@ -561,6 +561,146 @@ def gen_tiny_sd3():
     save("tiny_sd3.npz", d)
 
 
+# ------------------------------------------------------------------ SDXL UNet (BASELINE configs[0])
+def ref_sdxl_core(cfg, quant, sd):
+    """The reference's SDXLUNetModelCore.  Its constructor and loaders hard-code SDXL-base's widths (sdxl.py:53-113,
+    178-373) while its blocks take them as arguments, so for a narrow config the core object is assembled here from the
+    reference's own block classes and filled through the reference's `init_weight`; `forward` is the reference's."""
+    import contextlib
+    import io
+    from collections import namedtuple
+    from oracle import sdxl as OX
+    from fastdm.model.sdxl import SDXLUNetModelCore
+    from fastdm.model.basemodel import BaseModelCore
+    from fastdm.layer.embeddings import Timesteps, TimestepEmbedding
+    from fastdm.layer import unetblock as U
+    bf = torch.bfloat16
+    if cfg == OX.SDXLConfig():
+        core = SDXLUNetModelCore(data_type=bf, quant_dtype=quant)
+        with contextlib.redirect_stdout(io.StringIO()):
+            core.weight_loading(dict(sd), device_type="cpu")
+        return core
+    c0, c1, c2 = cfg.block_out_channels
+    l1, l2 = cfg.transformer_layers
+    core = object.__new__(SDXLUNetModelCore)
+    BaseModelCore.__init__(core, type="Unet")
+    core.config = namedtuple("config", "is_ip_adapter")
+    core.config.is_ip_adapter = False
+    core.time_proj = Timesteps(cfg.time_proj_dim, True, 0)
+    core.time_embedding = TimestepEmbedding(in_features=cfg.time_proj_dim, out_features=cfg.time_embed_dim, data_type=bf)
+    core.add_time_proj = Timesteps(cfg.addition_time_embed_dim, True, 0)
+    core.add_embedding = TimestepEmbedding(in_features=cfg.text_embed_dim + 6 * cfg.addition_time_embed_dim, out_features=cfg.time_embed_dim,
+                                           data_type=bf)
+    core.down_blocks = [U.DownBlock2D(in_channels=c0, out_channels=c0, data_type=bf),
+                        U.CrossAttnDownBlock2D(in_channels=c0, out_channels=c1, n_layers=l1, data_type=bf),
+                        U.CrossAttnDownBlock2D(in_channels=c1, out_channels=c2, n_layers=l2, has_downsamplers=False, data_type=bf)]
+    core.mid_block = U.UNetMidBlock2DCrossAttn(c2, data_type=bf)
+    core.mid_block.attentions = [U.Transformer2DModel(c2, c2, n_layers=cfg.mid_layers, data_type=bf)]
+    core.up_blocks = [U.CrossAttnUpBlock2D(in_channels=c1, out_channels=c2, prev_output_channel=c2, n_layers=l2, data_type=bf),
+                      U.CrossAttnUpBlock2D(in_channels=c0, out_channels=c1, prev_output_channel=c2, n_layers=l1, data_type=bf),
+                      U.UpBlock2D(in_channels=c0, out_channels=c0, prev_output_channel=c1, data_type=bf)]
+    core.origin_tensor_dict, core.device, core.dtype = dict(sd), "cpu", bf
+    core.unmatched_tensors = list(sd.keys())
+    ld = core.init_weight
+
+    def resnet(r, n):
+        r.norm1_gamma, r.norm1_beta = ld([f"{n}.norm1.weight"]), ld([f"{n}.norm1.bias"])
+        r.conv1_weight, r.conv1_bias = ld([f"{n}.conv1.weight"]), ld([f"{n}.conv1.bias"])
+        ld([f"{n}.time_emb_proj"], r.time_emb_proj)
+        r.norm2_gamma, r.norm2_beta = ld([f"{n}.norm2.weight"]), ld([f"{n}.norm2.bias"])
+        r.conv2_weight, r.conv2_bias = ld([f"{n}.conv2.weight"]), ld([f"{n}.conv2.bias"])
+        if r.conv_shortcut:
+            r.convshortcut_weight, r.convshortcut_bias = ld([f"{n}.conv_shortcut.weight"]), ld([f"{n}.conv_shortcut.bias"])
+
+    def transformer(t, n):
+        t.norm_gamma, t.norm_beta = ld([f"{n}.norm.weight"]), ld([f"{n}.norm.bias"])
+        ld([f"{n}.proj_in"], t.proj_in, quant)
+        ld([f"{n}.proj_out"], t.proj_out, quant)
+        for j, b in enumerate(t.transformer_blocks):
+            k = f"{n}.transformer_blocks.{j}"
+            for i in (1, 2, 3):
+                setattr(b, f"norm{i}_gamma", ld([f"{k}.norm{i}.weight"]))
+                setattr(b, f"norm{i}_beta", ld([f"{k}.norm{i}.bias"]))
+            ld([f"{k}.attn1.to_q", f"{k}.attn1.to_k", f"{k}.attn1.to_v"], b.attn1.qkv_proj, quant)
+            ld([f"{k}.attn1.to_out.0"], b.attn1.out_proj, quant)
+            ld([f"{k}.attn2.to_q"], b.attn2.q_proj, quant)
+            ld([f"{k}.attn2.to_k", f"{k}.attn2.to_v"], b.attn2.kv_proj, quant)
+            ld([f"{k}.attn2.to_out.0"], b.attn2.out_proj, quant)
+            ld([f"{k}.ff.net.0.proj"], b.ff.proj1, quant)
+            ld([f"{k}.ff.net.2"], b.ff.proj2, quant)
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        core.conv_in_weight, core.conv_in_bias = ld(["conv_in.weight"]), ld(["conv_in.bias"])
+        for emb, n in ((core.time_embedding, "time_embedding"), (core.add_embedding, "add_embedding")):
+            ld([f"{n}.linear_1"], emb.linear1, quant)
+            ld([f"{n}.linear_2"], emb.linear2, quant)
+        for m, blk in enumerate(core.down_blocks):
+            for i, r in enumerate(blk.resnets):
+                resnet(r, f"down_blocks.{m}.resnets.{i}")
+            for i, t in enumerate(getattr(blk, "attentions", [])):
+                transformer(t, f"down_blocks.{m}.attentions.{i}")
+            if m < 2:
+                blk.downsample_conv_weight = ld([f"down_blocks.{m}.downsamplers.0.conv.weight"])
+                blk.downsample_conv_bias = ld([f"down_blocks.{m}.downsamplers.0.conv.bias"])
+        for i, r in enumerate(core.mid_block.resnets):
+            resnet(r, f"mid_block.resnets.{i}")
+        transformer(core.mid_block.attentions[0], "mid_block.attentions.0")
+        for m, blk in enumerate(core.up_blocks):
+            for i, r in enumerate(blk.resnets):
+                resnet(r, f"up_blocks.{m}.resnets.{i}")
+            for i, t in enumerate(getattr(blk, "attentions", [])):
+                transformer(t, f"up_blocks.{m}.attentions.{i}")
+            if m < 2:
+                blk.upsample_conv_weight = ld([f"up_blocks.{m}.upsamplers.0.conv.weight"])
+                blk.upsample_conv_bias = ld([f"up_blocks.{m}.upsamplers.0.conv.bias"])
+        core.conv_norm_out_gemma, core.conv_norm_out_beta = ld(["conv_norm_out.weight"]), ld(["conv_norm_out.bias"])
+        core.conv_out_weight, core.conv_out_bias = ld(["conv_out.weight"]), ld(["conv_out.bias"])
+    assert not core.unmatched_tensors, core.unmatched_tensors[:5]
+    return core
+
+
+def gen_tiny_sdxl():
+    """A narrow SDXL UNet (32/64/128 channels, 1 and 2 transformer layers, same wiring) through the reference's blocks and
+    forward, bf16 / fp8 / int8, CFG-style batch 2, two timesteps."""
+    import_reference()
+    from oracle import sdxl as OX
+    cfg = OX.TINY
+    sd = OX.synth_state_dict(cfg, seed=41)
+    inp = OX.synth_inputs(cfg, batch=2, height=16, width=24, n_txt=11, seed=41)
+    d = {"seed": 41, "batch": 2, "height": 16, "width": 24, "n_txt": 11}
+    for tag, qt in (("bf16", None), ("fp8", torch.float8_e4m3fn), ("int8", torch.int8)):
+        use_backend("cpu_fp8" if qt == torch.float8_e4m3fn else "torch")
+        core = ref_sdxl_core(cfg, qt, sd)
+        for ti, t in enumerate((981.0, 341.0)):
+            d[f"out_{tag}_t{ti}"] = core.forward(inp["sample"], torch.tensor(t), inp["encoder_hidden_states"], inp["added_cond_kwargs"])[0]
+    use_backend("torch")
+    save("tiny_sdxl.npz", d)
+
+
+def gen_sdxl_full(quants=("fp8", "bf16")):
+    """SDXL-base-1.0 at full width (2.6 B synthetic parameters) through the reference's own core and loaders, 256x256 image
+    (latent 32x32: 1024 / 256 tokens at the two attention levels), CFG batch 2."""
+    import_reference()
+    from oracle import sdxl as OX
+    cfg = OX.SDXLConfig()
+    t0 = time.time()
+    sd = OX.synth_state_dict(cfg, seed=43)
+    print(f"synthetic SDXL state_dict: {sum(v.numel() for v in sd.values()) / 1e9:.2f} B parameters in {time.time() - t0:.0f}s", flush=True)
+    inp = OX.synth_inputs(cfg, batch=2, height=32, width=32, n_txt=77, seed=43)
+    d = {"seed": 43, "batch": 2, "height": 32, "width": 32, "n_txt": 77}
+    for tag in quants:
+        qt = {"bf16": None, "fp8": torch.float8_e4m3fn, "int8": torch.int8}[tag]
+        use_backend("cpu_fp8" if tag == "fp8" else "torch")
+        t0 = time.time()
+        core = ref_sdxl_core(cfg, qt, sd)
+        out = core.forward(inp["sample"], torch.tensor(601.0), inp["encoder_hidden_states"], inp["added_cond_kwargs"])[0]
+        print(f"reference SDXL {tag}: load+forward {time.time() - t0:.0f}s, mean|out| {out.float().abs().mean():.4f}", flush=True)
+        d[f"out_{tag}"] = out
+        del core
+    use_backend("torch")
+    save("sdxl_full.npz", d)
+
+
 def gen_dicache():
     """DiCache (probe depth 1, delta_y) decisions + final latents on the tiny FLUX (bf16) and Qwen-Image (int8) cores over
     12-step trajectories through the reference's AutoCache."""
@@ -710,7 +850,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "c3"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sdxl", "sdxl_full", "c3"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     args = ap.parse_args()
@@ -733,6 +873,10 @@ def main():
         gen_dicache()
     if args.what in ("small", "sd3"):
         gen_tiny_sd3()
+    if args.what in ("small", "sdxl"):
+        gen_tiny_sdxl()
+    if args.what == "sdxl_full":
+        gen_sdxl_full(args.quant)
     if args.what == "qwen_full":
         gen_qwen_full()
     if args.what == "c3":

@@ -3,6 +3,7 @@
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import ops, layers as L, flux as OF, teacache as TC
 from oracle.make_golden import load
@@ -345,6 +346,37 @@ def test_sd3_tiny_core_matches_reference(tag, qt):
         # fp8 also quantises norm_out.linear and proj_out here (sd35.py:326-329): measured 0.10 / 0.013 on |out| ~ 0.8
         lim = {"bf16": (4e-2, 5e-3), "fp8": (1.5e-1, 2e-2), "int8": (5e-2, 8e-3)}[tag]
         assert d.max() <= lim[0] and d.mean() <= lim[1], (tag, ti, d.max().item(), d.mean().item(), ref.float().abs().mean().item())
+
+
+@pytest.mark.parametrize("tag,qt", [("bf16", None), ("fp8", torch.float8_e4m3fn), ("int8", torch.int8)])
+def test_sdxl_tiny_unet_matches_reference(tag, qt, monkeypatch):
+    """A narrow SDXL UNet assembled from the reference's own blocks (oracle/make_golden.py `sdxl`).  With torch's SDPA
+    substituted for the oracle's fp32-softmax attention the restatement is BIT-EXACT against the reference in all three
+    modes; with the oracle's own attention (what the GPU kernel is compared to) it stays within the attention-rounding
+    envelope."""
+    from oracle import sdxl as OX
+    from oracle import ops as OPS
+    g = load("tiny_sdxl.npz")
+    cfg = OX.TINY
+    sd = OX.synth_state_dict(cfg, seed=int(g["seed"]))
+    inp = OX.synth_inputs(cfg, int(g["batch"]), int(g["height"]), int(g["width"]), int(g["n_txt"]), seed=int(g["seed"]))
+    core = OX.SDXLCore(sd, cfg, qt)
+    run = lambda t: core.forward(inp["sample"], torch.tensor(t), inp["encoder_hidden_states"], inp["added_cond_kwargs"])[0]
+    for ti, t in enumerate((981.0, 341.0)):
+        ref = g[f"out_{tag}_t{ti}"]
+        out = run(t)
+        assert out.shape == ref.shape == (2, 4, 16, 24)
+        d = (out.float() - ref.float()).abs()
+        lim = {"bf16": (5e-2, 9e-3), "fp8": (2.3e-1, 3.6e-2), "int8": (7e-2, 1.3e-2)}[tag]
+        assert d.max() <= lim[0] and d.mean() <= lim[1], (tag, ti, d.max().item(), d.mean().item())
+
+    def torch_sdpa(query, key, value, hq, hk, hd, is_causal=False, scale=None, **_):   # fastdm/kernel/torch/attention.py:34-43
+        b, s, c = query.shape
+        q, k, v = (x.view(b, x.size(1), h, hd).transpose(1, 2) for x, h in ((query, hq), (key, hk), (value, hk)))
+        return F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=is_causal, scale=scale).transpose(1, 2).contiguous().view(b, s, c)
+    monkeypatch.setattr(OPS, "scaled_dot_product_attention", torch_sdpa)
+    for ti, t in enumerate((981.0, 341.0)):
+        assert torch.equal(run(t), g[f"out_{tag}_t{ti}"]), (tag, ti)
 
 
 def test_dicache_trace_flux_and_qwen():

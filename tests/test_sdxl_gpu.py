@@ -1,0 +1,103 @@
+"""GPU parity of the SDXL UNet (BASELINE.json configs[0]).
+
+* tests/golden/tiny_sdxl.npz: a narrow UNet (32/64/128 channels, same wiring) assembled from the reference's own blocks and
+  run through the reference's forward on CPU, bf16 / fp8 / int8;
+* tests/golden/sdxl_full.npz: SDXL-base at full width (2.6 B synthetic parameters, generated bit-identically on the GPU)
+  through the reference's own core and loaders, 256x256 image, CFG batch 2, bf16 / fp8.
+"""
+import pytest
+import torch
+
+from oracle import sdxl as OX
+from oracle.make_golden import load
+
+pytestmark = pytest.mark.gpu
+BF16, FP8 = torch.bfloat16, torch.float8_e4m3fn
+
+
+def to_cuda(inp):
+    return dict(sample=inp["sample"].cuda(), encoder_hidden_states=inp["encoder_hidden_states"].cuda(),
+                added_cond_kwargs={k: v.cuda() for k, v in inp["added_cond_kwargs"].items()})
+
+
+def tiny_model(quant, seed, channels_last=True):
+    from fastdm_amd.model_entry import create_model
+    cfg = OX.TINY
+    return create_model("sdxl", ckpt_path=OX.synth_state_dict(cfg, seed=seed), dtype=BF16, quant_type=quant, kernel_backend="hip",
+                        block_out_channels=cfg.block_out_channels, transformer_layers=cfg.transformer_layers, mid_layers=cfg.mid_layers,
+                        channels_last=channels_last).eval()
+
+
+@pytest.mark.parametrize("channels_last", [True, False])
+@pytest.mark.parametrize("tag,qt", [("bf16", None), ("fp8", FP8), ("int8", torch.int8)])
+def test_tiny_sdxl_against_reference_golden(tag, qt, channels_last):
+    g = load("tiny_sdxl.npz")
+    cfg = OX.TINY
+    model = tiny_model(qt, int(g["seed"]), channels_last)
+    assert model.config.in_channels == 4 and model.config.addition_time_embed_dim == 256 and model.add_embedding is model.core_model.add_embedding
+    inp = to_cuda(OX.synth_inputs(cfg, int(g["batch"]), int(g["height"]), int(g["width"]), int(g["n_txt"]), seed=int(g["seed"])))
+    cpu_inp = OX.synth_inputs(cfg, int(g["batch"]), int(g["height"]), int(g["width"]), int(g["n_txt"]), seed=int(g["seed"]))
+    oracle = OX.SDXLCore(OX.synth_state_dict(cfg, seed=int(g["seed"])), cfg, qt)
+    for ti, t in enumerate((981.0, 341.0)):
+        out = model(inp["sample"], torch.tensor(t).cuda(), inp["encoder_hidden_states"], inp["added_cond_kwargs"])
+        assert isinstance(out, list) and out[0].shape == (2, 4, 16, 24) and out[0].is_contiguous()
+        got = out[0].float().cpu()
+        ref = g[f"out_{tag}_t{ti}"].float()
+        orc = oracle.forward(cpu_inp["sample"], torch.tensor(t), cpu_inp["encoder_hidden_states"], cpu_inp["added_cond_kwargs"])[0].float()
+        d, do = (got - ref).abs(), (got - orc).abs()
+        print(f"tiny SDXL {tag} cl={channels_last} t{ti}: vs reference {d.max().item():.4f}/{d.mean().item():.5f}  vs oracle "
+              f"{do.max().item():.4f}/{do.mean().item():.5f}")
+        # oracle-vs-reference on this fixture (torch's CPU flash SDPA keeps P in bf16; everything else is bit-exact):
+        # bf16 0.042 / 0.0076, int8 0.063 / 0.011, fp8 0.20 / 0.032 on |out| ~ 0.44
+        lim = {"bf16": (8e-2, 1.4e-2), "fp8": (3e-1, 4.5e-2), "int8": (1e-1, 1.8e-2)}[tag]
+        assert torch.isfinite(got).all() and d.max() <= lim[0] and d.mean() <= lim[1], (tag, ti, d.max().item(), d.mean().item())
+        assert do.max() <= lim[0] and do.mean() <= lim[1], (tag, ti, do.max().item(), do.mean().item())
+
+
+@pytest.mark.parametrize("tag,qt", [("bf16", None), ("fp8", FP8)])
+def test_full_width_sdxl_against_reference_core(tag, qt):
+    from fastdm_amd.model_entry import create_model
+    from fastdm_amd.synthetic import SyntheticSDXLStateDict, sdxl_step_inputs
+    g = load("sdxl_full.npz")
+    seed = int(g["seed"])
+    model = create_model("sdxl", ckpt_path=SyntheticSDXLStateDict(seed=seed), dtype=BF16, quant_type=qt, kernel_backend="hip").eval()
+    inp = sdxl_step_inputs(int(g["batch"]), int(g["height"]), int(g["width"]), int(g["n_txt"]), seed=seed)
+    # the GPU generator and the numpy twin the reference consumed agree bit for bit
+    want = OX.synth_inputs(OX.SDXLConfig(), int(g["batch"]), int(g["height"]), int(g["width"]), int(g["n_txt"]), seed=seed)
+    assert torch.equal(inp["sample"].cpu(), want["sample"]) and torch.equal(inp["encoder_hidden_states"].cpu(), want["encoder_hidden_states"])
+    assert torch.equal(inp["added_cond_kwargs"]["text_embeds"].cpu(), want["added_cond_kwargs"]["text_embeds"])
+    out = model(inp["sample"], torch.tensor(601.0).cuda(), inp["encoder_hidden_states"], inp["added_cond_kwargs"])[0]
+    ref = g[f"out_{tag}"]
+    assert out.shape == ref.shape == (2, 4, 32, 32)
+    d = (out.float().cpu() - ref.float()).abs()
+    print(f"SDXL full width {tag}: max|d| {d.max().item():.4f} mean|d| {d.mean().item():.5f} on mean|ref| {ref.float().abs().mean().item():.3f}")
+    lim = {"bf16": (1.2e-1, 1.5e-2), "fp8": (4e-1, 5e-2)}[tag]
+    assert torch.isfinite(out.float()).all() and d.max() <= lim[0] and d.mean() <= lim[1], (tag, d.max().item(), d.mean().item())
+
+
+def test_sdxl_blocks_keep_reference_signatures_and_errors():
+    from fastdm_amd.layer.unetblock import Attention_SDXL, BasicTransformerBlock, FeedForward_SDXL
+    from fastdm_amd.model.sdxl import SDXLUNetModelCore
+    with pytest.raises(NotImplementedError):
+        Attention_SDXL(128, 2048, has_ipadapter=True)
+    with pytest.raises(NotImplementedError):
+        SDXLUNetModelCore(is_ip_adapter=True)
+    model = tiny_model(None, 41)
+    core = model.core_model
+    with pytest.raises(NotImplementedError):
+        core.forward(None, None, None, {}, mid_block_additional_residual=torch.zeros(1), down_block_additional_residuals=[torch.zeros(1)])
+    # block-level forwards with the reference's argument lists: [B*S, C] tokens in and out
+    blk = core.down_blocks[1].attentions[0].transformer_blocks[0]
+    assert isinstance(blk, BasicTransformerBlock) and isinstance(blk.ff, FeedForward_SDXL)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2 * 24, 64, generator=g).to(BF16).cuda()
+    enc = torch.rand(2, 11, 2048, generator=g).to(BF16).cuda()
+    y = blk.forward(x, enc, 2)
+    y_parts = x
+    import torch.nn.functional as F
+    ln = lambda t, i: F.layer_norm(t, [64], getattr(blk, f"norm{i}_gamma"), getattr(blk, f"norm{i}_beta"), eps=1e-5)
+    y_parts = blk.attn1.forward(ln(y_parts, 1), batch=2) + y_parts
+    y_parts = blk.attn2.forward(ln(y_parts, 2), enc, batch=2) + y_parts
+    y_parts = blk.ff.forward(ln(y_parts, 3)) + y_parts
+    d = (y.float() - y_parts.float()).abs()
+    assert y.shape == x.shape and d.max() <= 2 ** -5 and (d > 0).float().mean() < 0.05, (d.max().item(), (d > 0).float().mean().item())
