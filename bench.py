@@ -80,13 +80,16 @@ def cpu_baseline_leg(height, width, n_txt, quant_tag):
                       f"to one denoise step ({step_s:.0f}s)"}
 
 
+ARCH_NAME = {"flux": "FLUX.1-dev", "qwen": "Qwen-Image", "wan": "Wan2.2-T2V-A14B", "sd35": "SD3.5-large", "sdxl": "SDXL-base-1.0"}
+
+
 def main():
     global IMAGE_STEPS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 25 (flux, qwen) / 3 (wan)")
     ap.add_argument("--warmup", type=int, default=None, help="default 3 (flux, qwen) / 1 (wan)")
-    ap.add_argument("--model", choices=["flux", "qwen", "wan", "sd35"], default="flux",
+    ap.add_argument("--model", choices=["flux", "qwen", "wan", "sd35", "sdxl"], default="flux",
                     help="flux = the headline workload; qwen = Qwen-Image (BASELINE.json configs[3]) and wan = Wan2.2-T2V-A14B "
                          "(configs[4]): a step is a cond + uncond forward pair (CFG)")
     ap.add_argument("--frames", type=int, default=81, help="wan: video frames")
@@ -98,12 +101,16 @@ def main():
     ap.add_argument("--max-seq-len", type=int, default=None, help="text tokens: default 512 (flux) / 128 (qwen)")
     ap.add_argument("--quant", choices=["fp8", "int8", "bf16"], default=None, help="default fp8 (flux) / int8 (qwen)")
     ap.add_argument("--cache-config", default=None, help="TeaCache JSON (changes the metric: reported as a different workload)")
+    ap.add_argument("--graph", action="store_true", help="sdxl: replay the UNet forward from a HIP graph (the step is launch-bound: ~2000 small kernels)")
+    ap.add_argument("--nhwc", action="store_true", help="sdxl: keep convolution activations channels-last instead of NCHW")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event spans")
     args = ap.parse_args()
-    dflt = {"flux": (1024, 2048, 512, "fp8"), "qwen": (1328, 1328, 128, "int8"), "wan": (768, 1280, 512, "fp8"), "sd35": (1024, 1024, 333, "fp8")}[args.model]
+    dflt = {"flux": (1024, 2048, 512, "fp8"), "qwen": (1328, 1328, 128, "int8"), "wan": (768, 1280, 512, "fp8"), "sd35": (1024, 1024, 333, "fp8"), "sdxl": (1024, 1024, 77, "fp8")}[args.model]
     args.height, args.width = args.height or dflt[0], args.width or dflt[1]
     args.max_seq_len, args.quant = args.max_seq_len or dflt[2], args.quant or dflt[3]
+    if args.graph:
+        args.no_kernel_timing = True       # HIP-event spans cannot be recorded inside a graph replay
     args.steps = args.steps if args.steps is not None else (3 if args.model == "wan" else 25)
     args.warmup = args.warmup if args.warmup is not None else (1 if args.model == "wan" else 3)
 
@@ -137,6 +144,11 @@ def main():
         model = create_model("sd35", ckpt_path=SyntheticSD3StateDict(seed=0, **arch), dtype=torch.bfloat16, quant_type=quant, kernel_backend="hip",
                              **arch).eval()
         pipe = None
+    elif args.model == "sdxl":
+        from fastdm_amd.synthetic import SyntheticSDXLStateDict, sdxl_step_inputs
+        model = create_model("sdxl", ckpt_path=SyntheticSDXLStateDict(seed=0), dtype=torch.bfloat16, quant_type=quant, kernel_backend="hip",
+                             channels_last=args.nhwc).eval()
+        pipe = None
     else:
         from fastdm_amd.pipeline import SyntheticWanPipeline
         from fastdm_amd.sparse import SparseAttn
@@ -157,6 +169,12 @@ def main():
         n_img = (args.height // 16) * (args.width // 16)
         lin = np.linspace(1.0, 1.0 / IMAGE_STEPS, IMAGE_STEPS)
         sig = np.concatenate([3.0 * lin / (1.0 + 2.0 * lin), [0.0]]).astype(np.float32)      # flow-match schedule, shift 3
+    elif args.model == "sdxl":
+        IMAGE_STEPS = 30
+        inp = sdxl_step_inputs(2, args.height // 8, args.width // 8, args.max_seq_len, seed=rank)     # cond + uncond batched (CFG), as diffusers does
+        inp["hidden_states"] = inp["sample"]
+        n_img = (args.height // 16) * (args.width // 16)
+        sig = np.concatenate([np.linspace(1.0, 1.0 / IMAGE_STEPS, IMAGE_STEPS), [0.0]]).astype(np.float32)
     elif args.model == "wan":
         IMAGE_STEPS = 40
         inp = pipe.prepare(1, args.height, args.width, args.frames, args.max_seq_len, seed=rank)
@@ -169,6 +187,15 @@ def main():
     guidance = torch.full((1,), 3.5, device=dev, dtype=torch.float32)
 
     state = {"lat": inp["hidden_states"].clone(), "i": 0}
+    if args.model == "sdxl":
+        from fastdm_amd.graph import GraphedForward
+        unet = lambda lat, t: model(lat, t, inp["encoder_hidden_states"], inp["added_cond_kwargs"])[0]
+        graphed = GraphedForward(unet, inp["hidden_states"], torch.zeros((), device=dev)) if args.graph else None
+
+        def sdxl_forward(lat, t):
+            if graphed is not None:
+                return graphed(lat, torch.tensor(t, device=dev))
+            return unet(lat, torch.tensor(t, device=dev))
 
     def one_step():
         i = (state["i"] + args.start_step) % IMAGE_STEPS
@@ -182,6 +209,13 @@ def main():
             v = model(hidden_states=lat, encoder_hidden_states=inp["encoder_hidden_states"], pooled_projections=inp["pooled_projections"],
                       timestep=t, return_dict=False)[0].float()
             noise = v[1:2] + 4.5 * (v[0:1] - v[1:2])
+            state["lat"] = (lat.float() + float(sig[i + 1] - sig[i]) * noise).to(torch.bfloat16).expand(2, -1, -1, -1).contiguous()
+            state["i"] += 1
+            return
+        if args.model == "sdxl":
+            lat = state["lat"]
+            eps = sdxl_forward(lat, float(sig[i]) * 999.0).float()
+            noise = eps[1:2] + 5.0 * (eps[0:1] - eps[1:2])
             state["lat"] = (lat.float() + float(sig[i + 1] - sig[i]) * noise).to(torch.bfloat16).expand(2, -1, -1, -1).contiguous()
             state["i"] += 1
             return
@@ -237,6 +271,10 @@ def main():
     elif args.model == "sd35":
         workload = (f"SD3.5-large {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), 28-step schedule, CFG as one batch-2 forward "
                     f"per step, 38 joint blocks")
+    elif args.model == "sdxl":
+        workload = (f"SDXL-base-1.0 UNet {args.quant} {args.height}x{args.width} (latent {args.height // 8}x{args.width // 8}; {n_img} and {n_img // 4} "
+                    f"tokens at the two attention levels, {args.max_seq_len} prompt tokens), 30-step schedule, CFG as one batch-2 forward per step, "
+                    f"70 transformer layers + 52 MIOpen convolutions")
     elif args.model == "wan":
         hs = inp["hidden_states"].shape
         nl = len(model.core_model.blocks)
@@ -256,6 +294,7 @@ def main():
         "metric": {"flux": "denoise it/s (sec/image = 25 / (value / n_gpus)), FLUX 1024x2048 fp8 @25 steps",
                    "qwen": "denoise it/s (sec/image = 25 / (value / n_gpus)), Qwen-Image 1328x1328 int8 @25 steps, true CFG",
                    "sd35": "denoise it/s (sec/image = 28 / (value / n_gpus)), SD3.5-large 1024x1024 fp8 @28 steps, CFG",
+                   "sdxl": "denoise it/s (sec/image = 30 / (value / n_gpus)), SDXL-base UNet 1024x1024 fp8 @30 steps, CFG",
                    "wan": "denoise it/s (sec/video = 40 / (value / n_gpus)), Wan2.2-T2V-A14B 768x1280x81f fp8 @40 steps, CFG"}[args.model],
         "value": world * args.steps / elapsed,
         "unit": "it/s",
@@ -268,7 +307,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": {"fp8": "fp8_e4m3 W8A8 GEMM (fp32 accumulate) + bf16 attention", "int8": "int8 W8A8 + bf16 attention", "bf16": "bf16"}[args.quant],
-        "data": "synthetic (counter-based random weights of the FLUX.1-dev architecture, U[0,1) latents/prompt embeddings)",
+        "data": f"synthetic (counter-based random weights of the {ARCH_NAME[args.model]} architecture, synthetic latents/prompt embeddings)",
         "config": {"workload": workload, "global_batch": world, "height": args.height, "width": args.width, "parallelism": f"dp{world} (image-sharded, one all-gather of final latents)"},
     }
     if rec:

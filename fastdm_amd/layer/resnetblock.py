@@ -23,12 +23,14 @@ class ResnetBlock2D:
         self.conv_shortcut = conv_shortcut
         self.convshortcut_weight = self.convshortcut_bias = None
 
+    @staticmethod
+    def _gn_silu_conv3(x, gamma, beta, weight, bias):
+        """GroupNorm(32, eps 1e-5) -> SiLU -> 3x3 convolution (stride 1, padding 1)."""
+        return F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, 1e-05)), weight, bias, 1, 1)
+
     def forward(self, input_tensor, temb):
-        h = F.silu(F.group_norm(input_tensor, 32, self.norm1_gamma, self.norm1_beta, 1e-05))
-        h = F.conv2d(h, self.conv1_weight, self.conv1_bias, 1, 1)
-        h = h + self.time_emb_proj.forward(F.silu(temb))[:, :, None, None]
-        h = F.silu(F.group_norm(h, 32, self.norm2_gamma, self.norm2_beta, 1e-05))
-        h = F.conv2d(h, self.conv2_weight, self.conv2_bias, 1, 1)
-        if self.conv_shortcut:
-            input_tensor = F.conv2d(input_tensor, self.convshortcut_weight, self.convshortcut_bias, 1)
-        return input_tensor + h
+        h = self._gn_silu_conv3(input_tensor, self.norm1_gamma, self.norm1_beta, self.conv1_weight, self.conv1_bias)
+        shift = self.time_emb_proj.forward(F.silu(temb))                   # [B, C_out]: per-channel offset from the time embedding
+        h = self._gn_silu_conv3(h + shift[:, :, None, None], self.norm2_gamma, self.norm2_beta, self.conv2_weight, self.conv2_bias)
+        skip = input_tensor if not self.conv_shortcut else F.conv2d(input_tensor, self.convshortcut_weight, self.convshortcut_bias, 1)
+        return skip + h

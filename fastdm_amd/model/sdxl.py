@@ -4,7 +4,9 @@ Same constructor surface, diffusers key names and forward signature as the refer
 SDXL-base's widths inside the class (sdxl.py:53-113); here they are constructor arguments that default to SDXL-base, so
 the narrow configuration of the parity fixtures goes through the same code.  Transformer blocks run on the fused HIP
 kernels (layer/unetblock.py); convolutions, group-norm and nearest upsampling are MIOpen / PyTorch-ROCm library calls as
-they are cuDNN calls in the reference.
+they are cuDNN calls in the reference.  `channels_last=True` keeps the convolution activations in NHWC (the token <-> image
+permutes become views); measured on MI355X at 1024x1024 the NCHW MIOpen kernels win by 1.5 ms of a 42 ms step, so NCHW is
+the default.
 """
 from typing import Any, Dict, Tuple
 
@@ -28,7 +30,7 @@ class SDXLUNetModelCore(BaseModelCore):
                  ip_adapter_scale=0.6, diffu_ipadapter_encoder_hid_proj=None, data_type=BF16, quant_dtype: torch.dtype = torch.float8_e4m3fn,
                  block_out_channels: Tuple[int, int, int] = (320, 640, 1280), transformer_layers: Tuple[int, int] = (2, 10),
                  mid_layers: int = 10, time_proj_dim: int = 320, time_embed_dim: int = 1280, text_embed_dim: int = 1280,
-                 channels_last: bool = True):
+                 channels_last: bool = False):
         super().__init__(type="Unet")
         if is_ip_adapter:
             raise NotImplementedError("the IP-adapter branch of the SDXL UNet is not built (DESIGN.md §8)")

@@ -101,3 +101,21 @@ def test_sdxl_blocks_keep_reference_signatures_and_errors():
     y_parts = blk.ff.forward(ln(y_parts, 3)) + y_parts
     d = (y.float() - y_parts.float()).abs()
     assert y.shape == x.shape and d.max() <= 2 ** -5 and (d > 0).float().mean() < 0.05, (d.max().item(), (d > 0).float().mean().item())
+
+
+def test_hip_graph_replay_equals_eager_forward():
+    """fastdm_amd.graph.GraphedForward: the UNet forward captured into a HIP graph (library kernels + MIOpen) and replayed on
+    new latents / timesteps gives the eager forward's bits."""
+    from fastdm_amd.graph import GraphedForward
+    cfg = OX.TINY
+    model = tiny_model(FP8, 41)
+    inp = to_cuda(OX.synth_inputs(cfg, 2, 16, 24, 11, seed=41))
+    unet = lambda lat, t: model(lat, t, inp["encoder_hidden_states"], inp["added_cond_kwargs"])[0]
+    graphed = GraphedForward(unet, inp["sample"], torch.zeros((), device="cuda"))
+    g = torch.Generator().manual_seed(5)
+    for t in (981.0, 341.0, 20.0):
+        lat = torch.randn(inp["sample"].shape, generator=g).to(BF16).cuda()
+        tt = torch.tensor(t, device="cuda")
+        want = unet(lat, tt).clone()
+        got = graphed(lat, tt)
+        assert torch.equal(got, want), t
