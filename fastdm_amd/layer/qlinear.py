@@ -69,6 +69,34 @@ class QLinear:
         else:
             raise ValueError(f"Unsupported quantization type: {quant_type}")
 
+    # ------------------------------------------------------------------ pre-quantised checkpoints (model/basemodel.py)
+    def export_state(self):
+        """The layer exactly as the kernels consume it: w [N, K] (fp8 / int8 / bf16 / fp32, K contiguous), per-output-channel
+        scale, int8 column sums, bias."""
+        d = {"w": self.weight.t().contiguous()}
+        if self.quant_type is not None:
+            d["s"] = self.weight_quant_scale
+        if self.weight_asym_sumcol is not None:
+            d["c"] = self.weight_asym_sumcol
+        if self.bias is not None:
+            d["b"] = self.bias
+        return d
+
+    def import_state(self, d, device=None):
+        """Inverse of `export_state`: no quantisation pass, the stored bytes are the kernel operands."""
+        dev = device or self.device
+        w = d["w"].to(dev)
+        if w.dtype in (FP8, torch.int8):
+            self.quant_type = w.dtype
+            self.weight_quant_scale = d["s"].to(dev)
+            self.weight_asym_sumcol = d["c"].to(dev) if "c" in d else None
+        else:
+            assert w.dtype == self.dtype, f"stored {w.dtype} weight for a {self.dtype} layer"
+            self.quant_type = None
+        self.out_features, self.in_features = w.shape
+        self.weight = w.t()
+        self.bias = d["b"].to(dev) if "b" in d else None
+
     # ------------------------------------------------------------------ forward
     def quantize_input(self, x2d: torch.Tensor) -> Quantized:
         return fused.quantize_rows(x2d, None, self.quant_type)

@@ -51,6 +51,18 @@ class BaseModelWrapper(nn.Module, ConfigMixin):
         """diffusers >= 0.35 enters `transformer.cache_context("cond")` around each call; no-op like the reference."""
         yield
 
+    def _load_weights(self, ckpt_path, dtype, quantized_cache=None):
+        """Checkpoint (path / directory / state_dict) -> GPU layers.  `quantized_cache`: a safetensors file of the layers as
+        the kernels consume them -- written on the first load, read INSTEAD of the checkpoint afterwards (basemodel.py)."""
+        have_ckpt = isinstance(ckpt_path, dict) or bool(ckpt_path and os.path.exists(ckpt_path))
+        have_cache = bool(quantized_cache and os.path.isfile(quantized_cache))
+        if have_cache:
+            self.core_model.weight_loading(None, data_type=dtype, device_type="cuda", quantized_cache=quantized_cache)
+        elif have_ckpt:
+            self.core_model.weight_loading(ckpt_path, data_type=dtype, device_type="cuda", quantized_cache=quantized_cache)
+        elif ckpt_path:
+            print(f"Warning: Checkpoint path {ckpt_path} does not exist")
+
     def to(self, *args, **kwargs):
         """Weights already live on the GPU in their final (quantised) form: `pipe.to('cuda')` must not touch them."""
         return self
@@ -68,6 +80,7 @@ class FluxTransformerWrapper(BaseModelWrapper):
                  quant_type: Optional[torch.dtype] = None, kernel_backend: str = "hip", need_resolve_oom=False,
                  cache: AutoCache = None, **kwargs):
         super().__init__(kernel_backend)
+        quantized_cache = kwargs.pop("quantized_cache", None)
         guidance_embeds = kwargs.pop("guidance_embeds", True)
         self.config = self._create_diffusers_config(in_channels=in_channels, out_channels=out_channels,
                                                     guidance_embeds=guidance_embeds, dtype=dtype)
@@ -76,10 +89,7 @@ class FluxTransformerWrapper(BaseModelWrapper):
         self.core_model = FluxTransformer2DModelCore(in_channels=in_channels, out_channels=out_channels, guidance_embeds=guidance_embeds,
                                                      data_type=dtype, quant_dtype=quant_type, cache=cache, oom_ressolve=need_resolve_oom,
                                                      **kwargs)
-        if isinstance(ckpt_path, dict) or (ckpt_path and os.path.exists(ckpt_path)):
-            self.core_model.weight_loading(ckpt_path, data_type=dtype, device_type="cuda")
-        elif ckpt_path:
-            print(f"Warning: Checkpoint path {ckpt_path} does not exist")
+        self._load_weights(ckpt_path, dtype, quantized_cache)
 
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, **kwargs):
@@ -94,16 +104,14 @@ class QwenTransformerWrapper(BaseModelWrapper):
                  quant_type: Optional[torch.dtype] = None, kernel_backend: str = "hip", need_resolve_oom=False,
                  cache: AutoCache = None, **kwargs):
         super().__init__(kernel_backend)
+        quantized_cache = kwargs.pop("quantized_cache", None)
         self.config = self._create_diffusers_config(in_channels=in_channels, out_channels=out_channels, guidance_embeds=False, dtype=dtype)
         self.dtype = dtype
         self.need_resolve_oom = need_resolve_oom
         self.core_model = QwenImageTransformer2DModelCore(in_channels=in_channels, out_channels=out_channels, guidance_embeds=False,
                                                           data_type=dtype, quant_dtype=quant_type, cache=cache,
                                                           oom_ressolve=need_resolve_oom, **kwargs)
-        if isinstance(ckpt_path, dict) or (ckpt_path and os.path.exists(ckpt_path)):
-            self.core_model.weight_loading(ckpt_path, data_type=dtype, device_type="cuda")
-        elif ckpt_path:
-            print(f"Warning: Checkpoint path {ckpt_path} does not exist")
+        self._load_weights(ckpt_path, dtype, quantized_cache)
 
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, **kwargs):
@@ -116,6 +124,7 @@ class SD35TransformerWrapper(BaseModelWrapper):
     def __init__(self, ckpt_path=None, in_channels: int = 16, out_channels: int = 16, dtype: torch.dtype = torch.bfloat16,
                  quant_type: Optional[torch.dtype] = None, kernel_backend: str = "hip", cache: AutoCache = None, **kwargs):
         super().__init__(kernel_backend)
+        quantized_cache = kwargs.pop("quantized_cache", None)
         self.dtype = dtype
         self.core_model = SD3TransformerModelCore(in_channels=in_channels, out_channels=out_channels, data_type=dtype, quant_dtype=quant_type,
                                                   cache=cache, **kwargs)
@@ -123,10 +132,7 @@ class SD35TransformerWrapper(BaseModelWrapper):
         self.config = self._create_diffusers_config(in_channels=in_channels, out_channels=out_channels, dtype=dtype, patch_size=c.patch_size,
                                                     sample_size=c.sample_size, joint_attention_dim=c.joint_attention_dim,
                                                     pooled_projection_dim=c.pooled_projection_dim)
-        if isinstance(ckpt_path, dict) or (ckpt_path and os.path.exists(ckpt_path)):
-            self.core_model.weight_loading(ckpt_path, data_type=dtype, device_type="cuda")
-        elif ckpt_path:
-            print(f"Warning: Checkpoint path {ckpt_path} does not exist")
+        self._load_weights(ckpt_path, dtype, quantized_cache)
 
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, **kwargs):
@@ -139,6 +145,7 @@ class SDXLUNetModelWrapper(BaseModelWrapper):
     def __init__(self, ckpt_path=None, in_channels=4, dtype=torch.bfloat16, is_ipadapter=False, ipadapter_scale=0.6,
                  diffu_ipadapter_encoder_hid_proj=None, quant_type=None, kernel_backend: str = "hip", **kwargs):
         super().__init__(kernel_backend)
+        quantized_cache = kwargs.pop("quantized_cache", None)
         self.config = self._create_diffusers_config(in_channels=in_channels, addition_time_embed_dim=256, sample_size=128,
                                                     time_cond_proj_dim=None, ip_adapter=is_ipadapter, dtype=dtype)
         self.dtype = dtype
@@ -147,10 +154,7 @@ class SDXLUNetModelWrapper(BaseModelWrapper):
                                             quant_dtype=quant_type, **kwargs)
         self.add_embedding = self.core_model.add_embedding
         self.encoder_hid_proj = self.core_model.encoder_hid_proj
-        if isinstance(ckpt_path, dict) or (ckpt_path and os.path.exists(ckpt_path)):
-            self.core_model.weight_loading(ckpt_path, data_type=dtype, device_type="cuda")
-        elif ckpt_path:
-            print(f"Warning: Checkpoint path {ckpt_path} does not exist")
+        self._load_weights(ckpt_path, dtype, quantized_cache)
 
     @torch.no_grad()
     def forward(self, sample, timesteps, encoder_hidden_states, added_cond_kwargs, **kwargs):
@@ -170,6 +174,7 @@ class WanTransformer3DWrapper(BaseModelWrapper):
                  quant_type: Optional[torch.dtype] = None, kernel_backend: str = "hip", config_json=None, cache: AutoCache = None,
                  model_config: Optional[Dict] = None, **kwargs):
         super().__init__(kernel_backend, config_path=config_json)
+        quantized_cache = kwargs.pop("quantized_cache", None)
         cfg = dict(_WAN_A14B_CONFIG)
         cfg.update(self.model_config_dict or {})
         cfg.update(model_config or {})
@@ -183,10 +188,7 @@ class WanTransformer3DWrapper(BaseModelWrapper):
             ffn_dim=cfg["ffn_dim"], num_layers=cfg["num_layers"], qk_norm=cfg["qk_norm"], eps=cfg["eps"],
             rope_max_seq_len=cfg["rope_max_seq_len"], data_type=dtype, quant_dtype=quant_type, cache=cache,
             sparse_attn=kwargs.get("sparse_attn", None))
-        if isinstance(ckpt_path, dict) or (ckpt_path and os.path.exists(ckpt_path)):
-            self.core_model.weight_loading(ckpt_path, data_type=dtype, device_type="cuda")
-        elif ckpt_path:
-            print(f"Warning: Checkpoint path {ckpt_path} does not exist")
+        self._load_weights(ckpt_path, dtype, quantized_cache)
 
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, **kwargs):
