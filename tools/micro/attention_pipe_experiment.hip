@@ -1,0 +1,877 @@
+// EXPERIMENT (not built into the library): attention.hip plus a software-pipelined dense kernel, `attn_fwd_pipe_kernel`,
+// that interleaves QK^T(i+1), P.V(i-1) and the softmax of step i inside each wave.  Build it into the micro-benchmark with
+//   hipcc ... -DATTN_SRC=\"attention_pipe_experiment.hip\" attn_bench.hip      (ablations: -DFDM_ATT_EXP_NODMA / _NOBAR / _NOLDS_K / _NOLDS_V)
+// Measured on MI355X, S = 8704, 24 heads x 128: 1003-1166 us against 814 us for the shipped kernel; 861 us without DMA and
+// barriers, 631 us with the LDS operand reads removed as well -- see DESIGN.md 4.5.
+
+// Dense / block-sparse flash-attention forward for gfx950 (bf16, head_dim 64 or 128, non-causal).
+//
+//   block     512 threads = 8 waves; one 256-row Q block of one (batch, head); wave w owns rows
+//             [32w, 32w+32).  KV tile = 64 keys, K and V staged global -> VGPR -> LDS (split
+//             issue-early / write-late), double buffered: 2 x (K + V) = 64 KiB at D = 128.
+//   QK^T      swapped: S^T[key][q] = K . Q^T on v_mfma_f32_32x32x16_bf16, so lane (q = lane&31,
+//             h = lane>>5) holds 16 of each 32 keys of ITS query row: row max / sum are in-lane plus
+//             one cross-half exchange (lane ^ 32).
+//   PV        O^T[d][q] += V^T[d][key] . P^T[key][q].  The S^T accumulator, converted pairwise to
+//             bf16, IS the B operand (no lane movement); the matching (permuted-k) A operand comes
+//             from the row-major V tile with ds_read_b64_tr_b16 (hardware transpose).
+//   LDS       K rows: chunk c of key r at slot c ^ (r & 15) (D=128) -> conflict-free ds_read_b128;
+//             V rows: chunk c of key r at slot c ^ ((r & 3) << 2)  -> conflict-free transposed reads.
+//   softmax   fp32 running max / sum in the exp2 domain (scale * log2 e folded into one FMA).
+//   grid      block id -> (xcd = id % 8): every q-block of a (batch, head) runs on one XCD so that
+//             K/V (4.4 MB per head at S = 8704) is fetched from HBM once and re-read from that L2.
+//   mask      optional int8 block mask [B, H, ceil(Sq/bq), ceil(Sk/bk)] (1 = compute): tiles masked
+//             for both 128-row halves of the Q block are skipped entirely (no loads, no barrier).
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+
+namespace fdm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// s_setprio(1) around the MFMA clusters: measured -2 % with 128-key tiles (it paid +1 % with 64-key tiles), so off
+#ifndef FDM_ATT_PRIO_QK
+#define FDM_ATT_PRIO_QK 0
+#endif
+#ifndef FDM_ATT_PRIO_PV
+#define FDM_ATT_PRIO_PV 0
+#endif
+#ifndef FDM_ATT_THREADS
+#define FDM_ATT_THREADS 512
+#endif
+#ifndef FDM_ATT_SGB_LEAD
+#define FDM_ATT_SGB_LEAD 4
+#endif
+#ifndef FDM_ATT_SGB_VALU
+#define FDM_ATT_SGB_VALU 4
+#endif
+constexpr int ATT_THREADS = FDM_ATT_THREADS;
+constexpr int QB = ATT_THREADS / 2;  // query rows per block: 32 per wave
+constexpr int KT_MASK = 64;   // keys per tile on the block-mask path (= the mask's key granularity)
+constexpr int KT_DENSE = 128;
+
+struct AttnParams {
+  bf16_t* o;
+  const bf16_t* q;
+  const bf16_t* k;
+  const bf16_t* v;
+  const int8_t* mask;
+  int64_t sq, sk;
+  int64_t q_ts, k_ts, v_ts, o_ts;  // token strides (elements)
+  int batch, heads, kv_heads;
+  int n_qblocks;
+  int mask_bq, mask_bk, mask_nq, mask_nk;
+  float scale_log2e;
+  // split-KV tail balancing: block ids >= n_full are parts of tail q-blocks (S parts each, consecutive KV ranges)
+  int n_full, split;
+  float* ws_o;   // [tail part][256 rows][D] unnormalised fp32 O
+  float* ws_ml;  // [tail part][256 rows][2] running max (exp2 domain), row sum
+};
+
+template <int D>
+struct Swz {
+  static constexpr int CPR = D / 8;  // 16-byte chunks per row
+  // K image: conflict-free ds_read_b128 for 16-lane groups of distinct rows
+  static __device__ __forceinline__ int k(int row, int ch) {
+    if constexpr (D == 128) return ch ^ (row & 15);
+    else return ch ^ ((row >> 1) & 7);
+  }
+  // V image: conflict-free ds_read_b64_tr_b16 (4 consecutive keys x 64 B per 32-lane half)
+  static __device__ __forceinline__ int v(int row, int ch) {
+    if constexpr (D == 128) return ch ^ ((row & 3) << 2);
+    else return ch ^ (((row >> 1) & 1) << 2);
+  }
+};
+
+__device__ __forceinline__ i32x4 tr_pair(const uint8_t* p0, const uint8_t* p1) {
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  i32x2 lo = __builtin_bit_cast(i32x2, a), hi = __builtin_bit_cast(i32x2, b);
+  i32x4 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+  return r;
+}
+
+// NT threads = NT/64 waves of 32 query rows: 512 (256-row q-blocks, one block per CU: the dense path) or 256 (128-row
+// q-blocks = exactly one block-mask row, two blocks per CU: the block-sparse path, where the two halves of a 256-row
+// block would carry different masks and wait for each other).
+template <int D, int NT, int KTT>
+__global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
+  constexpr int KT = KTT;        // keys per tile: 128 on the dense path (half the barriers and DMA waits), 64 with a block mask
+  constexpr int NKT = KT / 32;   // 32-key S^T tiles per KV tile
+  constexpr int QBT = NT / 2;   // query rows per block
+  constexpr int CPR = D / 8;
+  constexpr int TILE_BYTES = KT * D * 2;               // one K or V tile
+  constexpr int LD_PER_THREAD = KT * CPR / NT;  // 16-B chunks per thread per tile (2 @128, 1 @64)
+  constexpr int KSTEPS = D / 16;                        // QK^T k-steps
+  constexpr int DT = D / 32;                            // 32-wide d tiles of O^T
+  __shared__ __attribute__((aligned(1024))) uint8_t smem[4 * TILE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 31, h = lane >> 5;
+
+  // ---- block id -> (batch*head, q block), heads pinned to XCDs
+  const int BH = p.batch * p.heads;
+  int item = blockIdx.x, part = 0;
+  const bool is_part = item >= p.n_full;
+  if (is_part) {
+    part = (item - p.n_full) % p.split;
+    item = p.n_full + (item - p.n_full) / p.split;
+  }
+  const int xcd = item & 7, j = item >> 3;
+  const int bh = xcd + 8 * (j / p.n_qblocks);
+  if (bh >= BH) return;
+  const int qb = j % p.n_qblocks;
+  const int b = bh / p.heads, head = bh % p.heads;
+  const int kvh = head / (p.heads / p.kv_heads);
+  const int64_t q0 = (int64_t)qb * QBT;
+
+  const bf16_t* qbase = p.q + ((int64_t)b * p.sq) * p.q_ts + (int64_t)head * D;
+  const bf16_t* kbase = p.k + ((int64_t)b * p.sk) * p.k_ts + (int64_t)kvh * D;
+  const bf16_t* vbase = p.v + ((int64_t)b * p.sk) * p.v_ts + (int64_t)kvh * D;
+
+  // ---- Q fragments: B operand of the swapped QK^T: lane holds Q[q][16*ks + 8*h .. +8]
+  i32x4 qf[KSTEPS];
+  {
+    int64_t qrow = q0 + wave * 32 + lq;
+    if (qrow > p.sq - 1) qrow = p.sq - 1;
+    const bf16_t* qp = qbase + qrow * p.q_ts + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *reinterpret_cast<const i32x4*>(qp + 16 * ks);
+  }
+
+  // ---- block-mask bookkeeping.  Only the 4-wave instantiation (128-row q-blocks = one mask row) reads a mask; the
+  //      host never launches the 8-wave kernel with one.  The row's active KV tiles are compacted once into an LDS
+  //      list (wave 0, ballot + popcount), so the tile loop never chases mask bytes through global memory.
+  constexpr bool MASKED = (NT == 256);
+  constexpr int MAXL = MASKED ? 4096 : 1;
+  __shared__ uint16_t slist[MAXL];
+  __shared__ int s_nlist;
+  const int ntiles = (int)((p.sk + KT - 1) / KT);
+  const int8_t* mrow = nullptr;
+  bool use_list = false;
+  if constexpr (MASKED) {
+    if (p.mask != nullptr) {
+      const int64_t mb = ((int64_t)b * p.heads + head) * p.mask_nq;
+      mrow = p.mask + (mb + (int)(q0 / p.mask_bq)) * p.mask_nk;
+      use_list = ntiles <= MAXL;
+      if (use_list) {
+        if (wave == 0) {
+          int cnt = 0;
+          for (int base = 0; base < ntiles; base += 64) {
+            const int tt = base + lane;
+            const bool act = tt < ntiles && mrow[(tt * KT) / p.mask_bk] != 0;
+            const unsigned long long bal = __ballot(act);
+            if (act) slist[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)tt;
+            cnt += __popcll(bal);
+          }
+          if (lane == 0) s_nlist = cnt;
+        }
+        __syncthreads();
+      }
+    }
+  }
+  int lpos = 0;                                // position in the active list
+  const int n_list = use_list ? s_nlist : 0;
+  auto tile_active = [&](int t) -> bool {
+    if constexpr (!MASKED) return true;
+    return mrow == nullptr || mrow[(t * KT) / p.mask_bk] != 0;
+  };
+  // first active tile at or after t (list mode: the next list entry; the list is consumed in order)
+  auto next_active = [&](int t) -> int {
+    if constexpr (MASKED) {
+      if (use_list) {
+        while (lpos < n_list && (int)slist[lpos] < t) ++lpos;
+        return lpos < n_list ? (int)slist[lpos] : ntiles;
+      }
+    }
+    while (t < ntiles && !tile_active(t)) ++t;
+    return t;
+  };
+
+  // ---- K/V staging by LDS-DMA (global_load_lds, 16 B per lane).  A wave-instruction writes 64 consecutive 16-byte
+  //      slots, so the destination is linear: thread t, round i fills slot p = i*NT + t = (row p / CPR, position p % CPR);
+  //      the swizzle is applied on the SOURCE side (the slot at position pos of row r holds chunk pos ^ swz(r); both
+  //      swizzles are XOR involutions).  No staging VGPRs, no ds_write.
+  int srow[LD_PER_THREAD];
+  int64_t koff[LD_PER_THREAD], voff[LD_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < LD_PER_THREAD; ++i) {
+    const int pslot = tid + i * NT;
+    srow[i] = pslot / CPR;
+    const int pos = pslot % CPR;
+    koff[i] = (int64_t)Swz<D>::k(srow[i], pos) * 8;
+    voff[i] = (int64_t)Swz<D>::v(srow[i], pos) * 8;
+  }
+  auto stage_tile = [&](int t, int buf) {
+    uint8_t* sk_ = smem + buf * 2 * TILE_BYTES + wave * 1024;
+    uint8_t* sv_ = sk_ + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < LD_PER_THREAD; ++i) {
+      int64_t key = (int64_t)t * KT + srow[i];
+      if (key > p.sk - 1) key = p.sk - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + key * p.k_ts + koff[i]),
+                                       (__attribute__((address_space(3))) void*)(sk_ + i * (NT * 16)), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + key * p.v_ts + voff[i]),
+                                       (__attribute__((address_space(3))) void*)(sv_ + i * (NT * 16)), 16, 0, 0);
+    }
+  };
+
+  // ---- accumulators
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  // ---- LDS read bases (byte offsets into smem; the buffer bit is toggled with one XOR per tile, every other
+  //      term of an address is a compile-time immediate).  tr-read geometry: 16-lane group gi, lane li = 4*tq + tp.
+  constexpr uint32_t ROWB = D * 2;
+  const int gi = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  // K: chunk (2ks + h) ^ Y = (h ^ Y) ^ 2ks, so one base and a compile-time XOR per k-step
+  uint32_t kld0 = lq * ROWB + (uint32_t)Swz<D>::k(lq, h) * 16;
+  uint32_t vld[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+    vld[d] = TILE_BYTES + (4 * h + tq) * ROWB + (uint32_t)Swz<D>::v(4 * h + tq, d * 4 + 2 * (gi & 1) + (tp >> 1)) * 16 + 8 * (tp & 1);
+  constexpr float RESCALE_THR = 8.0f;  // lazy rescale: P <= 2^8 between rescales (exp2 domain)
+
+  // One KV tile for this wave.  TAIL: keys >= sk are masked (only the last tile of a sequence can need it).
+  auto process_tile = [&](auto tail_c, int t) {
+    constexpr bool TAIL = decltype(tail_c)::value;
+    // ---- S^T = K . Q^T  (two 32-key tiles)
+    f32x16 sacc[NKT];
+#if FDM_ATT_PRIO_QK
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int kt2 = 0; kt2 < NKT; ++kt2)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[kt2][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const i32x4 qfr = qf[ks];
+#pragma unroll
+      for (int kt2 = 0; kt2 < NKT; ++kt2) {
+        const i32x4 kf = *reinterpret_cast<const i32x4*>(smem + (kld0 ^ (uint32_t)(ks << 5)) + kt2 * 32 * ROWB);
+        sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qfr),
+                                                            sacc[kt2], 0, 0, 0);
+      }
+    }
+#if FDM_ATT_PRIO_QK
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    if constexpr (TAIL) {
+      const int rem = (int)(p.sk - (int64_t)t * KT) - 4 * h;  // keys of this tile that exist, shifted by the lane-half offset
+#pragma unroll
+      for (int kt2 = 0; kt2 < NKT; ++kt2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (kt2 * 32 + (e & 3) + 8 * (e >> 2) >= rem) sacc[kt2][e] = -INFINITY;
+    }
+    // ---- online softmax in the exp2 domain with lazy rescale: the running max only moves (and O, l are only
+    //      rescaled) when some row's tile max exceeds it by more than RESCALE_THR; the decision is taken before
+    //      this tile is exponentiated and after the previous tile's P.V has been issued (textbook order).
+    // (max as med3(a, b, +inf): hipcc turns the chain into v_max3_f32 without the canonicalising v_max x,x it puts in
+    // front of every fmaxf on an MFMA result -- 19 instead of 56 VALU instructions per tile)
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int kt2 = 0; kt2 < NKT; ++kt2)
+#pragma unroll
+      for (int e = (kt2 < 2 ? 1 : 0); e < 16; ++e) mx = __builtin_amdgcn_fmed3f(mx, sacc[kt2][e], __builtin_inff());
+    {
+      const int mi = __builtin_bit_cast(int, mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mi, mi, false, false);  // both halves of the query row
+      mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    }
+    const float mt = mx * p.scale_log2e;
+    if (__any(mt > m_run + RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+    }
+    float psum = 0.f;
+    i32x4 pf[NKT][2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < NKT; ++kt2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt2][e], p.scale_log2e, -m_run));
+        sacc[kt2][e] = pv;
+        psum += pv;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) pf[kt2][s][w2] = (int)pack2bf(sacc[kt2][8 * s + 2 * w2], sacc[kt2][8 * s + 2 * w2 + 1]);
+    }
+    l_run += psum;
+    // ---- O^T += V^T . P^T
+#if FDM_ATT_PRIO_PV
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int kt2 = 0; kt2 < NKT; ++kt2)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const uint8_t* a0 = smem + vld[d] + (kt2 * 32 + 16 * s) * ROWB;  // keys 4h+tq .. (+8 for the second group)
+          const i32x4 vf = tr_pair(a0, a0 + 8 * ROWB);
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[kt2][s]),
+                                                            oacc[d], 0, 0, 0);
+        }
+      }
+#if FDM_ATT_PRIO_PV
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+
+#ifdef FDM_ATT_STATIC_PRIO
+  if (wave >= NT / 128) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every arbitration otherwise
+#endif
+  // KV range of this work item: everything, or the part-th of `split` consecutive ranges
+  const int t_begin = is_part ? (int)((int64_t)part * ntiles / p.split) : 0;
+  const int t_end = is_part ? (int)((int64_t)(part + 1) * ntiles / p.split) : ntiles;
+  int t = next_active(t_begin);
+  int cur = 0;
+  if (t < t_end) stage_tile(t, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs (and its Q loads) have landed ...
+  __syncthreads();                                    // ... and everybody's
+
+  // Full tiles run the TAIL=false body in the loop; a partial last tile (sk % 64 != 0) is handled once, after
+  // the loop, by the masked body (keeping both bodies inside the loop costs > 90 VGPRs on this compiler).
+  const int n_main = (p.sk % KT == 0 || t_end < ntiles) ? t_end : ntiles - 1;
+  while (t < n_main) {
+    const int tn = next_active(t + 1);
+    if (tn < t_end) stage_tile(tn, cur ^ 1);    // the other buffer was last read before the previous barrier
+
+    process_tile(std::false_type{}, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+    kld0 ^= 2 * TILE_BYTES;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) vld[d] ^= 2 * TILE_BYTES;
+    t = tn;
+  }
+  if (t < t_end) process_tile(std::true_type{}, t);  // the partial tile is resident in buffer `cur`
+
+  // ---- finalize: l = own half + other half; O = O^T / l
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (is_part) {  // unnormalised partial: O (fp32), m, l -> workspace; attn_combine_kernel merges the parts
+    const int64_t slot = (int64_t)(blockIdx.x - p.n_full);
+    const int row = wave * 32 + lq;
+    float* wo = p.ws_o + (slot * QBT + row) * D;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 w;
+        w[0] = oacc[d][4 * g4]; w[1] = oacc[d][4 * g4 + 1]; w[2] = oacc[d][4 * g4 + 2]; w[3] = oacc[d][4 * g4 + 3];
+        *reinterpret_cast<f32x4*>(wo + 32 * d + 8 * g4 + 4 * h) = w;
+      }
+    if (h == 0) {
+      p.ws_ml[(slot * QBT + row) * 2] = m_run;
+      p.ws_ml[(slot * QBT + row) * 2 + 1] = l_tot;
+    }
+    return;
+  }
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  const int64_t qrow = q0 + wave * 32 + lq;
+  if (qrow < p.sq) {
+    bf16_t* op = p.o + ((int64_t)b * p.sq + qrow) * p.o_ts + (int64_t)head * D;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        // registers 4*g4 .. 4*g4+3 hold d = 32*d + 8*g4 + 4*h + (0..3): 8 contiguous bytes
+        i32x2 w;
+        w[0] = (int)pack2bf(oacc[d][4 * g4] * inv, oacc[d][4 * g4 + 1] * inv);
+        w[1] = (int)pack2bf(oacc[d][4 * g4 + 2] * inv, oacc[d][4 * g4 + 3] * inv);
+        *reinterpret_cast<i32x2*>(op + 32 * d + 8 * g4 + 4 * h) = w;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Dense path, software-pipelined.  Measured on gfx950 (tools/micro/coissue.hip): MFMA work of one wave and VALU work of
+// ANOTHER wave on the same SIMD barely overlap (743 vs 346 + 472 cycles), while one wave that interleaves both streams
+// hides the MFMAs almost completely (551).  The kernel above runs QK^T (MFMA only), the softmax (VALU only, apart from
+// the exp/P.V overlap the compiler finds) and P.V one after the other per wave and relies on the second wave of the SIMD
+// to fill the gaps -- which the hardware does not do.  Here each wave carries three INDEPENDENT strands through every
+// 64-key step i, in one basic block the scheduler interleaves:
+//     S(i+1) = K(i+1) . Q^T          16 MFMA (8 at D = 64)
+//     O     += V(i-1)^T . P(i-1)^T   16 MFMA
+//     P(i)   = exp2(S(i)*c - m)      the softmax VALU work of the step
+// K/V stages are 64 keys in a 4-slot LDS ring (slot (i+2)%4 is being filled by LDS-DMA while K(i+1) and V(i-1) are read),
+// one barrier per step.  The running max is examined before the block; the rare rescale (tile max more than 2^8 above
+// the running max) takes a serial path that first retires P(i-1).V(i-1).
+template <int D>
+__global__ void __launch_bounds__(512, 2) attn_fwd_pipe_kernel(const AttnParams p) {
+  constexpr int NT = 512, KT = 64, NS = 4;
+  constexpr int NKT = KT / 32;
+  constexpr int QBT = NT / 2;
+  constexpr int CPR = D / 8;
+  constexpr int TILE_BYTES = KT * D * 2;
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int LD_PER_THREAD = KT * CPR / NT;
+  constexpr int KSTEPS = D / 16;
+  constexpr int DT = D / 32;
+  __shared__ __attribute__((aligned(1024))) uint8_t smem[NS * STAGE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 31, h = lane >> 5;
+
+  const int BH = p.batch * p.heads;
+  int item = blockIdx.x, part = 0;
+  const bool is_part = item >= p.n_full;
+  if (is_part) {
+    part = (item - p.n_full) % p.split;
+    item = p.n_full + (item - p.n_full) / p.split;
+  }
+  const int xcd = item & 7, j = item >> 3;
+  const int bh = xcd + 8 * (j / p.n_qblocks);
+  if (bh >= BH) return;
+  const int qb = j % p.n_qblocks;
+  const int b = bh / p.heads, head = bh % p.heads;
+  const int kvh = head / (p.heads / p.kv_heads);
+  const int64_t q0 = (int64_t)qb * QBT;
+
+  const bf16_t* qbase = p.q + ((int64_t)b * p.sq) * p.q_ts + (int64_t)head * D;
+  const bf16_t* kbase = p.k + ((int64_t)b * p.sk) * p.k_ts + (int64_t)kvh * D;
+  const bf16_t* vbase = p.v + ((int64_t)b * p.sk) * p.v_ts + (int64_t)kvh * D;
+
+  i32x4 qf[KSTEPS];
+  {
+    int64_t qrow = q0 + wave * 32 + lq;
+    if (qrow > p.sq - 1) qrow = p.sq - 1;
+    const bf16_t* qp = qbase + qrow * p.q_ts + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = *reinterpret_cast<const i32x4*>(qp + 16 * ks);
+  }
+
+  // ---- staging (as in attn_fwd_kernel: lane-linear LDS-DMA destination, swizzle applied on the source side)
+  int srow[LD_PER_THREAD];
+  int64_t koff[LD_PER_THREAD], voff[LD_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < LD_PER_THREAD; ++i) {
+    const int pslot = tid + i * NT;
+    srow[i] = pslot / CPR;
+    const int pos = pslot % CPR;
+    koff[i] = (int64_t)Swz<D>::k(srow[i], pos) * 8;
+    voff[i] = (int64_t)Swz<D>::v(srow[i], pos) * 8;
+  }
+  auto stage_tile = [&](int t, int slot) {
+    uint8_t* sk_ = smem + slot * STAGE_BYTES + wave * 1024;
+    uint8_t* sv_ = sk_ + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < LD_PER_THREAD; ++i) {
+      int64_t key = (int64_t)t * KT + srow[i];
+      if (key > p.sk - 1) key = p.sk - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + key * p.k_ts + koff[i]),
+                                       (__attribute__((address_space(3))) void*)(sk_ + i * (NT * 16)), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + key * p.v_ts + voff[i]),
+                                       (__attribute__((address_space(3))) void*)(sv_ + i * (NT * 16)), 16, 0, 0);
+    }
+  };
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  constexpr uint32_t ROWB = D * 2;
+  const int gi = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  const uint32_t kld0 = lq * ROWB + (uint32_t)Swz<D>::k(lq, h) * 16;
+  uint32_t vld[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+    vld[d] = TILE_BYTES + (4 * h + tq) * ROWB + (uint32_t)Swz<D>::v(4 * h + tq, d * 4 + 2 * (gi & 1) + (tp >> 1)) * 16 + 8 * (tp & 1);
+  constexpr float RESCALE_THR = 8.0f;
+
+  // ---- the three strands of a 32-key step (stage = 64 keys = two steps; `sub` selects the half)
+  auto qk = [&](int slot, int sub, f32x16& sacc) {
+    const uint8_t* base = smem + slot * STAGE_BYTES + sub * 32 * ROWB;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const i32x4 kf = *reinterpret_cast<const i32x4*>(base + (kld0 ^ (uint32_t)(ks << 5)));
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[ks]), sacc, 0, 0, 0);
+    }
+  };
+  auto pv = [&](int slot, int sub, const i32x4 (&pf)[2]) {
+    const uint8_t* base = smem + slot * STAGE_BYTES + sub * 32 * ROWB;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const uint8_t* a0 = base + vld[d] + (16 * s) * ROWB;
+        const i32x4 vf = tr_pair(a0, a0 + 8 * ROWB);
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[s]), oacc[d], 0, 0, 0);
+      }
+    }
+  };
+  auto tile_max = [&](const f32x16& sacc) -> float {
+    float mx = fmaxf(sacc[0], sacc[1]);
+#pragma unroll
+    for (int e = 2; e < 16; ++e) mx = __builtin_amdgcn_fmed3f(mx, sacc[e], __builtin_inff());
+    const int mi = __builtin_bit_cast(int, mx);
+    const auto sw = __builtin_amdgcn_permlane32_swap(mi, mi, false, false);
+    return fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1])) * p.scale_log2e;
+  };
+  auto exp_pack = [&](f32x16& sacc, i32x4 (&pf)[2]) {
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[e], p.scale_log2e, -m_run));
+      sacc[e] = pe;
+      psum += pe;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) pf[s][w2] = (int)pack2bf(sacc[8 * s + 2 * w2], sacc[8 * s + 2 * w2 + 1]);
+    l_run += psum;
+  };
+  auto rescale = [&](float mt) {
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    l_run *= alpha;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+  };
+
+  const int ntiles = (int)((p.sk + KT - 1) / KT);   // 64-key stages
+  const int t_begin = is_part ? (int)((int64_t)part * ntiles / p.split) : 0;
+  const int t_end = is_part ? (int)((int64_t)(part + 1) * ntiles / p.split) : ntiles;
+  const int n = t_end - t_begin;
+  const int rem_last = (t_end == ntiles) ? (int)(p.sk - (int64_t)(ntiles - 1) * KT) : KT;   // keys present in this range's last stage
+
+  if (n > 0) {
+    stage_tile(t_begin, 0);
+    if (n > 1) stage_tile(t_begin + 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ping-pong register sets: even steps read S from s_a and write S(i+1) to s_b, odd steps the other way round
+    f32x16 s_a, s_b;
+    i32x4 pf_a[2], pf_b[2];
+    pf_a[0] = pf_a[1] = i32x4{0, 0, 0, 0};   // step 0 retires a zero P against the (finite) V of slot 0
+    qk(0, 0, s_a);
+
+    // step i = 2*j + sub over 32 keys: S(i) in s_cur, P(i-1) in pf_prev.  MASK: the range's last stage is partial.
+    auto step = [&](auto sub_c, int j, bool last, f32x16& s_cur, f32x16& s_next, const i32x4 (&pf_prev)[2], i32x4 (&pf_cur)[2]) {
+      constexpr int SUB = decltype(sub_c)::value;
+      const int slot = j & 3;
+      // strand addresses: K(i+1) and V(i-1)
+      const int nslot = SUB == 0 ? slot : ((j + 1) & 3), nsub = SUB ^ 1;
+      const int pslot = SUB == 1 ? slot : (j > 0 ? ((j - 1) & 3) : 0), psub = (SUB == 0 && j == 0) ? 0 : (SUB ^ 1);
+      if (last && rem_last < KT) {
+        const int rem = rem_last - SUB * 32 - 4 * h;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if ((e & 3) + 8 * (e >> 2) >= rem) s_cur[e] = -INFINITY;
+      }
+      const float mt = tile_max(s_cur);
+      const bool resc = __any(mt > m_run + RESCALE_THR);
+      const bool more = !(last && SUB == 1);
+      if (!resc && more) {
+        // steady state: three independent strands in one basic block
+        // Hand-interleaved: slot g = { read the operand fragment of slot g+2, one MFMA (P.V and QK^T alternate), a slice of
+        // the softmax: FMA + exp2 of this slot's elements, sum + bf16 pack of the previous slot's }.  sched_barrier pins the
+        // order -- left to itself the scheduler emits "ds_read, wait, MFMA" pairs and clusters the exps behind them.
+        constexpr int NSLOT = KSTEPS + 2 * DT;   // 16 (D = 128) or 8 (D = 64); KSTEPS == 2 * DT
+        constexpr int EPS = 16 / NSLOT;          // S elements per slot
+        const uint8_t* kb = smem + nslot * STAGE_BYTES + nsub * 32 * ROWB;
+        const uint8_t* vb = smem + pslot * STAGE_BYTES + psub * 32 * ROWB;
+        auto load_frag = [&](int g) -> i32x4 {
+#ifdef FDM_ATT_EXP_NOLDS_K
+          if (g & 1) return qf[(g >> 1) ^ 1];
+#endif
+#ifdef FDM_ATT_EXP_NOLDS_V
+          if (!(g & 1)) return qf[g >> 1];
+#endif
+          if (g & 1) return *reinterpret_cast<const i32x4*>(kb + (kld0 ^ (uint32_t)((g >> 1) << 5)));
+          const int idx = g >> 1, sv = idx / DT, d = idx % DT;
+          const uint8_t* a0 = vb + vld[d] + (16 * sv) * ROWB;
+          return tr_pair(a0, a0 + 8 * ROWB);
+        };
+        i32x4 fr[NSLOT];
+        fr[0] = load_frag(0);
+        fr[1] = load_frag(1);
+        float psum = 0.f;
+        const float nm = -m_run;
+#pragma unroll
+        for (int g = 0; g < NSLOT; ++g) {
+          if (g + 2 < NSLOT) fr[g + 2] = load_frag(g + 2);
+          if (g & 1) {
+            const int ks = g >> 1;
+            if (ks == 0) {
+              f32x16 z;
+#pragma unroll
+              for (int e = 0; e < 16; ++e) z[e] = 0.f;
+              s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[g]), __builtin_bit_cast(bf16x8, qf[ks]), z, 0, 0, 0);
+            } else {
+              s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[g]), __builtin_bit_cast(bf16x8, qf[ks]), s_next, 0, 0, 0);
+            }
+          } else {
+            const int idx = g >> 1, sv = idx / DT, d = idx % DT;
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[g]), __builtin_bit_cast(bf16x8, pf_prev[sv]), oacc[d], 0, 0, 0);
+          }
+#pragma unroll
+          for (int e = g * EPS; e < (g + 1) * EPS; ++e) s_cur[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e], p.scale_log2e, nm));
+          if (g > 0) {
+#pragma unroll
+            for (int e = (g - 1) * EPS; e < g * EPS; ++e) {
+              psum += s_cur[e];
+              if (e & 1) pf_cur[e >> 3][(e & 7) >> 1] = (int)pack2bf(s_cur[e - 1], s_cur[e]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int e = (NSLOT - 1) * EPS; e < 16; ++e) {
+          psum += s_cur[e];
+          if (e & 1) pf_cur[e >> 3][(e & 7) >> 1] = (int)pack2bf(s_cur[e - 1], s_cur[e]);
+        }
+        l_run += psum;
+      } else {
+        pv(pslot, psub, pf_prev);
+        if (resc) rescale(mt);
+        if (more) qk(nslot, nsub, s_next);
+        exp_pack(s_cur, pf_cur);
+      }
+    };
+    for (int j = 0; j < n; ++j) {
+#ifndef FDM_ATT_EXP_NODMA
+      if (j + 2 < n) stage_tile(t_begin + j + 2, (j + 2) & 3);   // slot last read (V of stage j-2) before the previous barrier
+#endif
+      const bool last = j + 1 == n;
+      step(std::integral_constant<int, 0>{}, j, last, s_a, s_b, pf_a, pf_b);
+      step(std::integral_constant<int, 1>{}, j, last, s_b, s_a, pf_b, pf_a);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef FDM_ATT_EXP_NOBAR
+      __syncthreads();
+#endif
+    }
+    pv((n - 1) & 3, 1, pf_a);   // P of the last 32 keys
+  }
+
+  // ---- finalize (identical to attn_fwd_kernel)
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (is_part) {
+    const int64_t slot = (int64_t)(blockIdx.x - p.n_full);
+    const int row = wave * 32 + lq;
+    float* wo = p.ws_o + (slot * QBT + row) * D;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 w;
+        w[0] = oacc[d][4 * g4]; w[1] = oacc[d][4 * g4 + 1]; w[2] = oacc[d][4 * g4 + 2]; w[3] = oacc[d][4 * g4 + 3];
+        *reinterpret_cast<f32x4*>(wo + 32 * d + 8 * g4 + 4 * h) = w;
+      }
+    if (h == 0) {
+      p.ws_ml[(slot * QBT + row) * 2] = m_run;
+      p.ws_ml[(slot * QBT + row) * 2 + 1] = l_tot;
+    }
+    return;
+  }
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  const int64_t qrow = q0 + wave * 32 + lq;
+  if (qrow < p.sq) {
+    bf16_t* op = p.o + ((int64_t)b * p.sq + qrow) * p.o_ts + (int64_t)head * D;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        i32x2 w;
+        w[0] = (int)pack2bf(oacc[d][4 * g4] * inv, oacc[d][4 * g4 + 1] * inv);
+        w[1] = (int)pack2bf(oacc[d][4 * g4 + 2] * inv, oacc[d][4 * g4 + 3] * inv);
+        *reinterpret_cast<i32x2*>(op + 32 * d + 8 * g4 + 4 * h) = w;
+      }
+  }
+}
+
+// Merge the split-KV parts of the tail q-blocks: O = sum_p 2^(m_p - M) O_p / sum_p 2^(m_p - M) l_p, M = max_p m_p.
+// One thread per (row, 8 consecutive d).
+template <int D>
+__global__ void __launch_bounds__(256) attn_combine_kernel(const AttnParams p, int n_tail) {
+  constexpr int CPR = D / 8;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)n_tail * QB * CPR) return;
+  const int ch = (int)(gid % CPR);
+  const int row = (int)((gid / CPR) % QB);
+  const int tail = (int)(gid / ((int64_t)CPR * QB));
+  const int item = p.n_full + tail;
+  const int xcd = item & 7, j = item >> 3;
+  const int bh = xcd + 8 * (j / p.n_qblocks);
+  const int qb = j % p.n_qblocks;
+  const int b = bh / p.heads, head = bh % p.heads;
+  const int64_t qrow = (int64_t)qb * QB + row;
+  if (bh >= p.batch * p.heads || qrow >= p.sq) return;
+  float M = -3.0e38f;
+  for (int s = 0; s < p.split; ++s) M = fmaxf(M, p.ws_ml[(((int64_t)tail * p.split + s) * QB + row) * 2]);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float L = 0.f;
+  for (int s = 0; s < p.split; ++s) {
+    const int64_t slot = (int64_t)tail * p.split + s;
+    const float w = __builtin_amdgcn_exp2f(p.ws_ml[(slot * QB + row) * 2] - M);
+    L += w * p.ws_ml[(slot * QB + row) * 2 + 1];
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p.ws_o + (slot * QB + row) * D + ch * 8);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(p.ws_o + (slot * QB + row) * D + ch * 8 + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[i] += w * a[i];
+      acc[4 + i] += w * c[i];
+    }
+  }
+  const float inv = L > 0.f ? 1.0f / L : 0.f;
+  i32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (int)pack2bf(acc[2 * i] * inv, acc[2 * i + 1] * inv);
+  *reinterpret_cast<i32x4*>(p.o + ((int64_t)b * p.sq + qrow) * p.o_ts + (int64_t)head * D + ch * 8) = o;
+}
+
+}  // namespace fdm
+
+using namespace fdm;
+
+// FDM_ATT_PIPE=0 selects the unpipelined dense kernel (kept for A/B measurements)
+static bool attn_use_pipe() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FDM_ATT_PIPE");
+    v = (e == nullptr || e[0] != '0') ? 1 : 0;
+  }
+  return v == 1;
+}
+
+extern "C" int64_t fdm_attn_fwd_workspace_bytes(int head_dim) {
+  // 1024 part slots x 256 rows x (D + 2) floats (136 MB at D = 128); fdm_attn_fwd only picks splits that fit
+  return (int64_t)1024 * QB * (head_dim + 2) * 4;
+}
+
+extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v, int64_t batch, int64_t sq, int64_t sk,
+                            int q_heads, int kv_heads, int head_dim, int64_t q_tok_stride, int64_t k_tok_stride,
+                            int64_t v_tok_stride, int64_t o_tok_stride, float scale, const int8_t* block_mask, int block_q,
+                            int block_k, void* workspace, int64_t workspace_bytes, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (!o || !q || !k || !v || batch <= 0 || sq <= 0 || sk <= 0 || q_heads <= 0 || kv_heads <= 0 || q_heads % kv_heads)
+    return FDM_ERR_INVALID;
+  if (head_dim != 64 && head_dim != 128) return FDM_ERR_UNSUPPORTED;
+  if ((q_tok_stride & 7) || (k_tok_stride & 7) || (v_tok_stride & 7) || (o_tok_stride & 7)) return FDM_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(q) & 15) || (reinterpret_cast<uintptr_t>(k) & 15) || (reinterpret_cast<uintptr_t>(v) & 15) ||
+      (reinterpret_cast<uintptr_t>(o) & 15))
+    return FDM_ERR_INVALID;
+  AttnParams p;
+  p.o = (bf16_t*)o;
+  p.q = (const bf16_t*)q;
+  p.k = (const bf16_t*)k;
+  p.v = (const bf16_t*)v;
+  p.mask = block_mask;
+  p.sq = sq;
+  p.sk = sk;
+  p.q_ts = q_tok_stride;
+  p.k_ts = k_tok_stride;
+  p.v_ts = v_tok_stride;
+  p.o_ts = o_tok_stride;
+  p.batch = (int)batch;
+  p.heads = q_heads;
+  p.kv_heads = kv_heads;
+  const int qb_rows = block_mask != nullptr ? 128 : QB;   // block-sparse: 4-wave blocks, one mask row each
+  p.n_qblocks = (int)((sq + qb_rows - 1) / qb_rows);
+  p.mask_bq = p.mask_bk = 1;
+  p.mask_nq = p.mask_nk = 0;
+  if (block_mask != nullptr) {
+    if (block_q <= 0 || block_k <= 0 || block_q % 128 || block_k % 64) return FDM_ERR_UNSUPPORTED;
+    p.mask_bq = block_q;
+    p.mask_bk = block_k;
+    p.mask_nq = (int)((sq + block_q - 1) / block_q);
+    p.mask_nk = (int)((sk + block_k - 1) / block_k);
+  }
+  p.scale_log2e = scale * 1.4426950408889634f;
+  const int64_t bh = batch * q_heads;
+  int64_t grid = 8 * ((bh + 7) / 8) * p.n_qblocks;
+  hipStream_t s = to_stream(stream);
+  // Split-KV tail balancing: q-blocks are equal-sized work items, one per CU at a time; when the last round would
+  // fill less than half of the chip (FLUX 1024x2048: 816 items on 256 CUs = 3.19 rounds), the items of that round
+  // are split along KV into S parts that run side by side and are merged by a small combine kernel.
+  p.n_full = (int)grid;
+  p.split = 1;
+  p.ws_o = nullptr;
+  p.ws_ml = nullptr;
+  int n_tail = 0;
+  if (block_mask == nullptr && workspace != nullptr && (bh % 8) == 0) {
+    static int num_cu = 0;
+    if (num_cu == 0) {
+      int dev = 0, cu = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+      num_cu = cu * (512 / ATT_THREADS);  // concurrent work-item slots on the chip
+    }
+    const int rem = (int)(grid % num_cu);
+    const int kt_dense = head_dim == 128 ? KT_DENSE : KT_MASK;
+    const int ntiles = (int)((sk + kt_dense - 1) / kt_dense);
+    if (rem > 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+      // time of the last round in units of one whole item: ceil(rem*S / CUs) rounds of 1/S-sized parts, plus a
+      // per-part overhead (Q load, prologue, fp32 partial write + merge) priced at 2% of an item
+      // (a split must save >= 0.3 item-times: measured at 432 items, a predicted 0.17 saving was a 5% loss -- a
+      // partly filled last round runs faster per item than the model assumes)
+      int best = 1;
+      float best_cost = 0.75f;
+      for (int S = 2; S <= 8 && S * 8 <= ntiles; ++S) {
+        const int64_t need = (int64_t)rem * S * QB * (head_dim + 2) * 4;
+        if (need > workspace_bytes) break;
+        const float cost = (float)(((int64_t)rem * S + num_cu - 1) / num_cu) / (float)S + 0.02f * (float)S;
+        if (cost < best_cost - 0.05f) {
+          best = S;
+          best_cost = cost;
+        }
+      }
+      if (best > 1) {
+        n_tail = rem;
+        p.split = best;
+        p.n_full = (int)(grid - rem);
+        p.ws_o = reinterpret_cast<float*>(workspace);
+        p.ws_ml = p.ws_o + (int64_t)rem * best * QB * head_dim;
+        grid = p.n_full + (int64_t)rem * best;
+      }
+    }
+  }
+  if (block_mask != nullptr) {
+    if (head_dim == 128) attn_fwd_kernel<128, 256, KT_MASK><<<(unsigned)grid, 256, 0, s>>>(p);
+    else attn_fwd_kernel<64, 256, KT_MASK><<<(unsigned)grid, 256, 0, s>>>(p);
+  } else if (attn_use_pipe()) {
+    if (head_dim == 128) attn_fwd_pipe_kernel<128><<<(unsigned)grid, 512, 0, s>>>(p);
+    else attn_fwd_pipe_kernel<64><<<(unsigned)grid, 512, 0, s>>>(p);
+  } else {
+    if (head_dim == 128) attn_fwd_kernel<128, 512, KT_DENSE><<<(unsigned)grid, 512, 0, s>>>(p);
+    else attn_fwd_kernel<64, 512, KT_MASK><<<(unsigned)grid, 512, 0, s>>>(p);    // head_dim 64: 64-key tiles measured faster
+  }
+  FDM_CHECK_LAUNCH();
+  if (n_tail > 0) {
+    const int64_t threads = (int64_t)n_tail * QB * (head_dim / 8);
+    const unsigned cgrid = (unsigned)((threads + 255) / 256);
+    if (head_dim == 128) attn_combine_kernel<128><<<cgrid, 256, 0, s>>>(p, n_tail);
+    else attn_combine_kernel<64><<<cgrid, 256, 0, s>>>(p, n_tail);
+    FDM_CHECK_LAUNCH();
+  }
+  return FDM_OK;
+}
