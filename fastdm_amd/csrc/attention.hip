@@ -1,21 +1,25 @@
 // Dense / block-sparse flash-attention forward for gfx950 (bf16, head_dim 64 or 128, non-causal).
 //
-//   block     512 threads = 8 waves; one 256-row Q block of one (batch, head); wave w owns rows
-//             [32w, 32w+32).  KV tile = 64 keys, K and V staged global -> VGPR -> LDS (split
-//             issue-early / write-late), double buffered: 2 x (K + V) = 64 KiB at D = 128.
-//   QK^T      swapped: S^T[key][q] = K . Q^T on v_mfma_f32_32x32x16_bf16, so lane (q = lane&31,
-//             h = lane>>5) holds 16 of each 32 keys of ITS query row: row max / sum are in-lane plus
-//             one cross-half exchange (lane ^ 32).
-//   PV        O^T[d][q] += V^T[d][key] . P^T[key][q].  The S^T accumulator, converted pairwise to
-//             bf16, IS the B operand (no lane movement); the matching (permuted-k) A operand comes
-//             from the row-major V tile with ds_read_b64_tr_b16 (hardware transpose).
+//   block     dense: 512 threads = 8 waves, one 256-row Q block of one (batch, head); block-sparse: 256 threads, one
+//             128-row Q block = one mask row.  Wave w owns rows [32w, 32w+32).
+//   K/V       tiles of 128 keys (dense, head_dim 128) or 64 keys, staged global -> LDS by LDS-DMA (global_load_lds, 16 B
+//             per lane, no staging VGPRs), double buffered: 2 x (K + V) = 128 KiB at D = 128.
+//   QK^T      swapped: S^T[key][q] = K . Q^T on v_mfma_f32_32x32x16_bf16, so lane (q = lane&31, h = lane>>5) holds 16 of
+//             each 32 keys of ITS query row: row max / sum are in-lane plus one cross-half exchange (permlane32_swap).
+//   PV        O^T[d][q] += V^T[d][key] . P^T[key][q].  The S^T accumulator, converted pairwise to bf16, IS the B operand
+//             (no lane movement); the matching (permuted-k) A operand comes from the row-major V tile with
+//             ds_read_b64_tr_b16 (hardware transpose).
 //   LDS       K rows: chunk c of key r at slot c ^ (r & 15) (D=128) -> conflict-free ds_read_b128;
-//             V rows: chunk c of key r at slot c ^ ((r & 3) << 2)  -> conflict-free transposed reads.
-//   softmax   fp32 running max / sum in the exp2 domain (scale * log2 e folded into one FMA).
-//   grid      block id -> (xcd = id % 8): every q-block of a (batch, head) runs on one XCD so that
-//             K/V (4.4 MB per head at S = 8704) is fetched from HBM once and re-read from that L2.
-//   mask      optional int8 block mask [B, H, ceil(Sq/bq), ceil(Sk/bk)] (1 = compute): tiles masked
-//             for both 128-row halves of the Q block are skipped entirely (no loads, no barrier).
+//             V rows: chunk c of key r at slot c ^ ((r & 3) << 2)  -> conflict-free transposed reads.  LDS-DMA writes are
+//             lane-linear, so both swizzles are applied to the per-lane SOURCE address.
+//   softmax   fp32 running max / sum in the exp2 domain (scale * log2 e folded into one FMA), lazy rescale.
+//   grid      block id -> (xcd = id % 8): every q-block of a (batch, head) runs on one XCD so that K/V (4.4 MB per head at
+//             S = 8704) is fetched from HBM once and re-read from that L2.  Split-KV: the q-blocks of a short last round
+//             are cut along KV into parts that run side by side and are merged by attn_combine_kernel.
+//   mask      optional int8 block mask [B, H, ceil(Sq/bq), ceil(Sk/bk)] (1 = compute): the active tiles of the block's mask
+//             row are compacted once into an LDS list; skipped tiles cost no loads and no barrier.
+//   bound     LDS operand traffic (1 KB per MFMA at 32 query rows per wave) -- DESIGN.md 4.5.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 
