@@ -79,6 +79,19 @@ class AutoCache:
         raise NotImplementedError("Subclasses must implement apply_cache method")
 
 
+def _block_forward(model_type, block, hidden_states, encoder_hidden_states, temb, image_rotary_emb, attention_kwargs, encoder_mask=None):
+    """One transformer block with the argument list its model family uses (xcaching.py:98-136,284-321): returns
+    (encoder_hidden_states, hidden_states); Wan blocks have no text-stream output."""
+    if model_type == "wan":
+        return None, block.forward(hidden_states, encoder_hidden_states, temb, image_rotary_emb)
+    kw = dict(hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states, temb=temb, joint_attention_kwargs=attention_kwargs)
+    if model_type != "sd35":
+        kw["image_rotary_emb"] = image_rotary_emb
+    if model_type == "qwenimage":
+        kw["encoder_hidden_states_mask"] = encoder_mask
+    return block.forward(**kw)
+
+
 @AutoCache.register("teacache")
 class TeaCache(AutoCache):
     def __init__(self, config):
@@ -91,13 +104,13 @@ class TeaCache(AutoCache):
         if model_type == "qwenimage":
             return transformer_blocks[0].txt_modulated(encoder_hidden_states, temb)
         if model_type not in ("flux", "sd35"):
-            raise ValueError(f"TeaCache unsupported model type: {model_type}. Supported types: qwenimage, flux")
+            raise ValueError(f"TeaCache unsupported model type: {model_type}. Supported types: qwenimage, flux, sd35")
         return transformer_blocks[0].norm1.forward(hidden_states, emb=temb)[0]
 
     def apply_cache(self, model_type: str, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
                     temb: torch.Tensor = None, image_rotary_emb: torch.Tensor = None, attention_kwargs: Optional[Dict[str, Any]] = None,
                     transformer_blocks=None, single_transformer_blocks=None, core=None, **_):
-        """xcaching.py:187-276 (FLUX and Qwen-Image branches; the blocks run through `core.run_blocks`)."""
+        """xcaching.py:187-276 (FLUX, Qwen-Image and SD3.5 branches; the blocks run through `core.run_blocks`)."""
         current_step = self.get_current_step()
         modulated_inp = self._get_modulated_input(model_type, hidden_states, temb, transformer_blocks, encoder_hidden_states)
         cache_key = self.get_cache_key()
@@ -134,14 +147,11 @@ class FBCache(AutoCache):
                     encoder_hidden_states_mask=None, temb: torch.Tensor = None, image_rotary_emb: torch.Tensor = None,
                     attention_kwargs: Optional[Dict[str, Any]] = None, transformer_blocks=None, single_transformer_blocks=None,
                     core=None, **_):
-        if model_type not in ("flux", "qwenimage"):
-            raise ValueError(f"FBCache unsupported model type: {model_type}. Supported types: qwenimage, flux")
+        if model_type not in ("flux", "qwenimage", "sd35", "wan"):
+            raise ValueError(f"FBCache unsupported model type: {model_type}. Supported types: qwenimage, flux, sd35, wan")
         current_step = self.get_current_step()
-        kw = dict(hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states, temb=temb, image_rotary_emb=image_rotary_emb,
-                  joint_attention_kwargs=attention_kwargs)
-        if model_type == "qwenimage":
-            kw["encoder_hidden_states_mask"] = encoder_hidden_states_mask
-        first_encoder, first_hidden = transformer_blocks[0].forward(**kw)     # returns fresh tensors: the inputs stay intact
+        first_encoder, first_hidden = _block_forward(model_type, transformer_blocks[0], hidden_states, encoder_hidden_states, temb,
+                                                     image_rotary_emb, attention_kwargs, encoder_hidden_states_mask)
         cache_key = self.get_cache_key()
         prev = self.previous_modulated_input_dict[cache_key]
         rel = None
@@ -160,8 +170,8 @@ class FBCache(AutoCache):
         self.previous_modulated_input_dict[cache_key] = first_hidden.clone()   # later blocks update the stream in place
         if not should_calc:
             return hidden_states + self.previous_residual_dict[cache_key]
-        out = core.run_blocks(first_hidden, first_encoder, temb, image_rotary_emb, attention_kwargs, start_block=1,
-                              encoder_hidden_states_mask=encoder_hidden_states_mask)
+        out = core.run_blocks(first_hidden, encoder_hidden_states if model_type == "wan" else first_encoder, temb, image_rotary_emb,
+                              attention_kwargs, start_block=1, encoder_hidden_states_mask=encoder_hidden_states_mask)
         self.previous_residual_dict[cache_key] = out - hidden_states
         return out
 
@@ -184,8 +194,12 @@ class DiCache(AutoCache):
                     encoder_hidden_states_mask=None, temb: torch.Tensor = None, image_rotary_emb: torch.Tensor = None,
                     attention_kwargs: Optional[Dict[str, Any]] = None, transformer_blocks=None, single_transformer_blocks=None,
                     core=None, **_):
-        if model_type not in ("flux", "qwenimage"):
-            raise ValueError(f"DiCache unsupported model type: {model_type}. Supported types: qwenimage, flux")
+        if model_type == "wan":
+            # upstream's wan branch calls _forward_wan_blocks without its sparse_attn argument (xcaching.py:468,514) and raises
+            # a TypeError: there is no reference behaviour to reproduce
+            raise NotImplementedError("DiCache for Wan: the reference's own call is broken (caching/xcaching.py:468); use FBCache")
+        if model_type not in ("flux", "qwenimage", "sd35"):
+            raise ValueError(f"DiCache unsupported model type: {model_type}. Supported types: qwenimage, flux, sd35")
         current_step = self.get_current_step()
         tcb = self.config.total_steps_callback
         total_steps = tcb() if tcb is not None and tcb() is not None else 25
@@ -193,11 +207,8 @@ class DiCache(AutoCache):
         ori = hidden_states
         probe_h, probe_e = hidden_states, encoder_hidden_states
         for blk in transformer_blocks[: self.config.probe_depth]:          # blocks return fresh tensors: `ori` stays intact
-            kw = dict(hidden_states=probe_h, encoder_hidden_states=probe_e, temb=temb, image_rotary_emb=image_rotary_emb,
-                      joint_attention_kwargs=attention_kwargs)
-            if model_type == "qwenimage":
-                kw["encoder_hidden_states_mask"] = encoder_hidden_states_mask
-            probe_e, probe_h = blk.forward(**kw)
+            probe_e, probe_h = _block_forward(model_type, blk, probe_h, probe_e, temb, image_rotary_emb, attention_kwargs,
+                                              encoder_hidden_states_mask)
         err = None
         if current_step <= int(self.config.ret_ratio * total_steps):
             should_calc = True

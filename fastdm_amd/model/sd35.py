@@ -60,8 +60,6 @@ class SD3TransformerModelCore(BaseModelCore):
                  pos_embed_max_size: int = 384, dual_attention_layers: Tuple[int, ...] = tuple(range(13)),
                  qk_norm: Optional[str] = "rms_norm", data_type=BF16, quant_dtype: Optional[torch.dtype] = torch.float8_e4m3fn, cache=None):
         super().__init__(type="DiT")
-        if cache is not None and cache.config.enable_caching:
-            raise NotImplementedError("step caching for SD3.5 is not built (SURVEY.md §8f)")
         cfg = _Config()
         (cfg.in_channels, cfg.joint_attention_dim, cfg.sample_size, cfg.num_attention_heads, cfg.attention_head_dim, cfg.patch_size,
          cfg.pooled_projection_dim, cfg.caption_projection_dim, cfg.num_layers) = (
@@ -72,7 +70,9 @@ class SD3TransformerModelCore(BaseModelCore):
         self.inner_dim = num_attention_heads * attention_head_dim
         assert caption_projection_dim == self.inner_dim, "the context embedder feeds the joint attention directly"
         self.quant_dtype = quant_dtype
-        self.cache, self.cache_config, self.enable_caching = cache, None, False
+        self.cache = cache
+        self.cache_config = cache.config if cache is not None else None
+        self.enable_caching = bool(self.cache_config.enable_caching) if cache is not None else False
         self.pos_embed = PatchEmbed(height=sample_size, width=sample_size, patch_size=patch_size, in_channels=in_channels,
                                     embed_dim=self.inner_dim, pos_embed_max_size=pos_embed_max_size, data_type=data_type)
         self.time_text_embed = CombinedTimestepTextProjEmbeddings(embedding_dim=self.inner_dim, pooled_projection_dim=pooled_projection_dim,
@@ -136,6 +136,13 @@ class SD3TransformerModelCore(BaseModelCore):
             layers += [blk.norm1, blk.norm1_context]
         self.mod_table = ModulationTable(layers)
 
+    def run_blocks(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb=None, joint_attention_kwargs=None, start_block: int = 0, **_):
+        """Blocks [start_block:] (the step caches run the first block(s) themselves)."""
+        for block in self.transformer_blocks[start_block:]:
+            encoder_hidden_states, hidden_states = block.forward(hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                                                 temb=temb, joint_attention_kwargs=joint_attention_kwargs)
+        return hidden_states
+
     # ------------------------------------------------------------------ forward (sd35.py:335-422)
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None, pooled_projections: torch.Tensor = None,
                 timestep: torch.Tensor = None, block_controlnet_hidden_states: List = None,
@@ -150,9 +157,11 @@ class SD3TransformerModelCore(BaseModelCore):
         enc = self.context_embedder.forward(encoder_hidden_states)
         self.mod_table.begin_step(temb)
         try:
-            for block in self.transformer_blocks:
-                enc, x = block.forward(hidden_states=x, encoder_hidden_states=enc if enc is not None else None, temb=temb,
-                                       joint_attention_kwargs=joint_attention_kwargs)
+            if self.enable_caching:       # sd35.py:384-392
+                x = self.cache.apply_cache(model_type="sd35", hidden_states=x, encoder_hidden_states=enc, temb=temb,
+                                           attention_kwargs=joint_attention_kwargs, transformer_blocks=self.transformer_blocks, core=self)
+            else:
+                x = self.run_blocks(x, enc, temb, None, joint_attention_kwargs)
         finally:
             self.mod_table.end_step()
         x = self.norm_out.forward(x.contiguous(), temb)

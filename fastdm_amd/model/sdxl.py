@@ -6,7 +6,8 @@ the narrow configuration of the parity fixtures goes through the same code.  Tra
 kernels (layer/unetblock.py); convolutions, group-norm and nearest upsampling are MIOpen / PyTorch-ROCm library calls as
 they are cuDNN calls in the reference.  `channels_last=True` keeps the convolution activations in NHWC (the token <-> image
 permutes become views); measured on MI355X at 1024x1024 the NCHW MIOpen kernels win by 1.5 ms of a 42 ms step, so NCHW is
-the default.
+the default.  (MIOpen's NCHW solvers answer the first call of a shape differently from later calls -- rounding-level, amplified to
+~0.06 by the UNet; channels-last was bit-stable run to run in the same experiment, tools/diag_sdxl.py.)
 """
 from typing import Any, Dict, Tuple
 

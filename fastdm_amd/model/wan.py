@@ -103,8 +103,6 @@ class WanTransformer3DModelCore(BaseModelCore):
                  pos_embed_seq_len: Optional[int] = None, data_type=BF16, quant_dtype: Optional[torch.dtype] = torch.float8_e4m3fn,
                  cache=None, sparse_attn=None) -> None:
         super().__init__("DiT")
-        if cache is not None and cache.config.enable_caching:
-            raise NotImplementedError("step caching for Wan is not built (SURVEY.md §8f)")
         self.quant_dtype = quant_dtype
         inner_dim = num_attention_heads * attention_head_dim
         self.inner_dim, self.eps = inner_dim, eps
@@ -120,7 +118,10 @@ class WanTransformer3DModelCore(BaseModelCore):
         self.norm_out = FP32LayerNorm(inner_dim, eps, elementwise_affine=False)
         self.proj_out = QLinear(inner_dim, self.out_channels * math.prod(patch_size), data_type=data_type)
         self.scale_shift_table = None
-        self.cache, self.cache_config, self.enable_caching = cache, None, False
+        self.cache = cache
+        self.cache_config = cache.config if cache is not None else None
+        self.enable_caching = bool(self.cache_config.enable_caching) if cache is not None else False
+        self._enc_q = None
         self.sparse_attn = sparse_attn
 
     # ------------------------------------------------------------------ loading (wan.py:225-281)
@@ -162,6 +163,14 @@ class WanTransformer3DModelCore(BaseModelCore):
         self.scale_shift_table = self.init_weight(["scale_shift_table"])
 
     # ------------------------------------------------------------------ forward (wan.py:283-379)
+    def run_blocks(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb, joint_attention_kwargs=None, start_block: int = 0, **_):
+        """Blocks [start_block:] with their absolute layer index (the sparse-attention schedule depends on it; the reference's
+        cache path numbers the remaining blocks from 1, caching/xcaching.py:91-96)."""
+        for layer_index in range(start_block, len(self.blocks)):
+            hidden_states = self.blocks[layer_index].forward(hidden_states, encoder_hidden_states, temb, image_rotary_emb, self.sparse_attn,
+                                                             layer_index, encoder_q=self._enc_q)
+        return hidden_states
+
     def forward(self, hidden_states: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
                 encoder_hidden_states_image: Optional[torch.Tensor] = None, return_dict: bool = True,
                 attention_kwargs: Optional[Dict[str, Any]] = None) -> Union[torch.Tensor, Tuple[torch.Tensor]]:
@@ -184,8 +193,15 @@ class WanTransformer3DModelCore(BaseModelCore):
         e2 = enc.reshape(B * enc.shape[1], -1).contiguous()
         # every block quantises the same text rows for its to_kv projection: do it once
         enc_q = a2.to_kv.quantize_input(e2) if a2.to_kv.quant_type is not None else e2
-        for layer_index, block in enumerate(self.blocks):
-            x = block.forward(x, enc, timestep_proj, rope, self.sparse_attn, layer_index, encoder_q=enc_q)
+        self._enc_q = enc_q
+        try:
+            if self.enable_caching:       # wan.py:339-349
+                x = self.cache.apply_cache(model_type="wan", hidden_states=x, encoder_hidden_states=enc, temb=timestep_proj, image_rotary_emb=rope,
+                                           attention_kwargs=attention_kwargs, transformer_blocks=self.blocks, sparse_attn=self.sparse_attn, core=self)
+            else:
+                x = self.run_blocks(x, enc, timestep_proj, rope)
+        finally:
+            self._enc_q = None
         # output norm: (scale_shift_table + temb) in bf16, `1 + scale` rounded to bf16 by the reference's type promotion (wan.py:353-362)
         shift, scale = (self.scale_shift_table + temb.unsqueeze(1)).chunk(2, dim=1)
         scale_f = (1 + scale.squeeze(1)).float() - 1.0

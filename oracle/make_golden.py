@@ -421,13 +421,13 @@ def gen_qwen_full(n_blocks=4, img_h=83, img_w=83, n_txt=128, seed=0):
 
 
 # ------------------------------------------------------------------ Wan2.x
-def ref_wan_core(cfg, quant, sd):
+def ref_wan_core(cfg, quant, sd, cache=None):
     from fastdm.model.wan import WanTransformer3DModelCore
     core = WanTransformer3DModelCore(
         patch_size=cfg.patch_size, num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim,
         in_channels=cfg.in_channels, out_channels=cfg.out_channels, text_dim=cfg.text_dim, freq_dim=cfg.freq_dim, ffn_dim=cfg.ffn_dim,
         num_layers=cfg.num_layers, cross_attn_norm=True, eps=cfg.eps, rope_max_seq_len=cfg.rope_max_seq_len,
-        data_type=torch.bfloat16, quant_dtype=quant, cache=None, sparse_attn=None)
+        data_type=torch.bfloat16, quant_dtype=quant, cache=cache, sparse_attn=None)
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -528,14 +528,14 @@ def gen_fbcache():
 
 
 # ------------------------------------------------------------------ SD3.5
-def ref_sd3_core(cfg, quant, sd):
+def ref_sd3_core(cfg, quant, sd, cache=None):
     from fastdm.model.sd35 import SD3TransformerModelCore
     core = SD3TransformerModelCore(
         sample_size=cfg.sample_size, patch_size=cfg.patch_size, in_channels=cfg.in_channels, num_layers=cfg.num_layers,
         attention_head_dim=cfg.attention_head_dim, num_attention_heads=cfg.num_attention_heads, joint_attention_dim=cfg.joint_attention_dim,
         caption_projection_dim=cfg.caption_projection_dim, pooled_projection_dim=cfg.pooled_projection_dim, out_channels=cfg.out_channels,
         pos_embed_max_size=cfg.pos_embed_max_size, dual_attention_layers=cfg.dual_attention_layers, qk_norm="rms_norm",
-        data_type=torch.bfloat16, quant_dtype=quant, cache=None)
+        data_type=torch.bfloat16, quant_dtype=quant, cache=cache)
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -559,6 +559,71 @@ def gen_tiny_sd3():
             d[f"out_{tag}_t{ti}"] = out[0] if isinstance(out, (tuple, list)) else out
     use_backend("torch")
     save("tiny_sd3.npz", d)
+
+
+CACHE_SD3_WAN = {   # thresholds with the widest decision margins on these 12-step trajectories (searched with the oracle)
+    "sd3_teacache": {"cache_algorithm": "teacache", "enable_caching": True, "threshold": 0.25, "coefficients": [1.0, 0.0]},
+    "sd3_fbcache": {"cache_algorithm": "fbcache", "enable_caching": True, "threshold": 0.14, "warmup_steps": 2},
+    "sd3_dicache": {"cache_algorithm": "dicache", "enable_caching": True, "threshold": 0.22, "probe_depth": 1, "ret_ratio": 0.2,
+                    "rel_l1_distance_algo": "delta_y"},
+    "wan_fbcache": {"cache_algorithm": "fbcache", "enable_caching": True, "threshold": 0.14, "warmup_steps": 2},
+}
+
+
+def gen_cache_sd3_wan():
+    """Step caches on the SD3.5 and Wan cores through the reference (caching/xcaching.py sd35 and wan branches): decisions and
+    final latents of 12-step trajectories.  TeaCache uses a linear rescale polynomial here: the published SD3.5 coefficients are
+    fitted to distances of 0.01-0.05 and evaluate to ~0 on the tiny random model's 0.1 (it would skip every step)."""
+    import contextlib
+    import io
+    import_reference()
+    from fastdm.caching.xcaching import AutoCache
+    from oracle import sd35 as OS, wan as OW
+    state = {"step": 0}
+    sig = torch.linspace(1.0, 1.0 / 12, 12)
+    d = {}
+
+    def make(name):
+        c = AutoCache.from_dict(dict(CACHE_SD3_WAN[name]))
+        c.config.current_steps_callback = lambda: state["step"]
+        c.config.total_steps_callback = lambda: 12
+        return c
+
+    def run(core_forward, lat):
+        dec = []
+        for i in range(12):
+            state["step"] = i
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                out = core_forward(lat, sig[i:i + 1] * 1000)
+            dec.append(0 if "Skipping" in buf.getvalue() else 1)
+            dt = (sig[i + 1] - sig[i]) if i + 1 < 12 else -sig[i]
+            lat = (lat.float() + dt * out.float()).to(torch.bfloat16)
+        return np.array(dec, dtype=np.int8), lat
+
+    use_backend("torch")
+    cfg = OS.TINY
+    sd = OS.synth_state_dict(cfg, seed=31)
+    inp = OS.synth_inputs(cfg, batch=1, height=8, width=12, n_txt=9, seed=33)
+    for name in ("sd3_teacache", "sd3_fbcache", "sd3_dicache"):
+        core = ref_sd3_core(cfg, None, sd, cache=make(name))
+        fwd = lambda lat, t: core.forward(hidden_states=lat, encoder_hidden_states=inp["encoder_hidden_states"],
+                                          pooled_projections=inp["pooled_projections"], timestep=t, return_dict=False)[0]
+        d[f"{name}_should_calc"], d[f"{name}_final"] = run(fwd, inp["hidden_states"].clone())
+        print(name, d[f"{name}_should_calc"].tolist())
+    use_backend("cpu_fp8")
+    wcfg = OW.TINY
+    wsd = OW.synth_state_dict(wcfg, seed=21)
+    winp = OW.synth_inputs(wcfg, batch=1, frames=3, height=8, width=8, n_txt=9, seed=23)
+    core = ref_wan_core(wcfg, torch.float8_e4m3fn, wsd, cache=make("wan_fbcache"))
+
+    def wfwd(lat, t):
+        out = core.forward(hidden_states=lat, timestep=t, encoder_hidden_states=winp["encoder_hidden_states"], return_dict=False)
+        return out[0] if isinstance(out, (tuple, list)) else out
+    d["wan_fbcache_should_calc"], d["wan_fbcache_final"] = run(wfwd, winp["hidden_states"].clone())
+    print("wan_fbcache", d["wan_fbcache_should_calc"].tolist())
+    use_backend("torch")
+    save("cache_sd3_wan.npz", d)
 
 
 # ------------------------------------------------------------------ SDXL UNet (SURVEY §8 f4, BASELINE configs[0])
@@ -850,7 +915,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sdxl", "sdxl_full", "c3"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_wan_cache", "sdxl", "sdxl_full", "c3"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     args = ap.parse_args()
@@ -873,6 +938,8 @@ def main():
         gen_dicache()
     if args.what in ("small", "sd3"):
         gen_tiny_sd3()
+    if args.what in ("small", "sd3_wan_cache"):
+        gen_cache_sd3_wan()
     if args.what in ("small", "sdxl"):
         gen_tiny_sdxl()
     if args.what == "sdxl_full":

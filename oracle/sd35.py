@@ -163,7 +163,13 @@ class JointTransformerBlock:
         self.ff = L.FeedForwardGeluTanh(sd, f"{b}.ff", quant)
         self.ff_context = None if self.last else L.FeedForwardGeluTanh(sd, f"{b}.ff_context", quant)
 
-    def __call__(self, hidden, encoder, temb):
+    def norm1_modulated(self, hidden, temb):
+        """norm1's first output, what TeaCache probes (caching/xcaching.py:181-183)."""
+        emb = self.norm1(F.silu(temb))
+        chunks = emb.chunk(9 if self.dual else 6, dim=1)
+        return L.layer_norm_noaffine(hidden, 1e-5 if self.dual else 1e-6) * (1 + chunks[1][:, None]) + chunks[0][:, None]
+
+    def __call__(self, hidden, encoder, temb, rope=None):
         emb = self.norm1(F.silu(temb))
         if self.dual:   # SD35AdaLayerNormZeroX (normalization.py:45-88), eps 1e-5
             shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp, shift_msa2, scale_msa2, gate_msa2 = emb.chunk(9, dim=1)
@@ -206,6 +212,8 @@ class SD3Core:
         self.p2 = L.linear_from(sd, ["time_text_embed.text_embedder.linear_2"])
         self.context_embedder = L.linear_from(sd, ["context_embedder"])
         self.blocks = [JointTransformerBlock(sd, i, cfg, quant) for i in range(cfg.num_layers)]
+        self.transformer_blocks = self.blocks        # the name the cache oracles use
+        self.cache_fn = None                         # step cache hook: f(core, hidden, encoder, temb) -> hidden (sd35.py:384-392)
         self.norm_out = L.linear_from(sd, ["norm_out.linear"], quant)
         self.proj_out = L.linear_from(sd, ["proj_out"], quant)
 
@@ -226,8 +234,11 @@ class SD3Core:
         te = self.t2(F.silu(self.t1(L.timestep_embedding(timestep).to(pooled_projections.dtype))))
         temb = te + self.p2(F.silu(self.p1(pooled_projections)))
         enc = self.context_embedder(encoder_hidden_states)
-        for blk in self.blocks:
-            enc, x = blk(x, enc, temb)
+        if self.cache_fn is not None:
+            x = self.cache_fn(self, x, enc, temb)
+        else:
+            for blk in self.blocks:
+                enc, x = blk(x, enc, temb)
         emb = self.norm_out(F.silu(temb).to(x.dtype))
         scale, shift = emb.chunk(2, dim=1)
         x = L.layer_norm_noaffine(x, 1e-6) * (1 + scale)[:, None, :] + shift[:, None, :]

@@ -74,6 +74,29 @@ class TeaCache:
         return out
 
 
+class TeaCacheSD3(TeaCache):
+    """The sd35 branch (xcaching.py:181-183,262-270): same probe as FLUX (block 0's norm1 output), blocks return
+    (encoder, hidden) and the last one has no encoder output."""
+
+    def apply_cache_sd35(self, core, hidden, encoder, temb):
+        step = self.config.current_steps_callback()
+        step = 0 if step is None else step
+        modulated = core.transformer_blocks[0].norm1_modulated(hidden.clone(), temb.clone())
+        rel = None
+        if step != 0:
+            rel = ((modulated - self.prev_modulated).abs().mean() / self.prev_modulated.abs().mean()).cpu().item()
+        should_calc = self.decision.step(step, rel)
+        self.trace.append((step, rel, float(self.decision.acc), should_calc))
+        self.prev_modulated = modulated
+        if not should_calc:
+            return hidden + self.prev_residual
+        x, enc = hidden, encoder
+        for blk in core.transformer_blocks:
+            enc, x = blk(x, enc, temb)
+        self.prev_residual = x - hidden
+        return x
+
+
 class TeaCacheQwen:
     """fastdm/caching/xcaching.py:156-276, Qwen-Image branch: the modulated input is the TEXT stream of block 0
     (xcaching.py:171-180) and, with `negtive_cache`, cond / uncond forwards alternate between two cache keys with
@@ -163,7 +186,17 @@ class FBCacheOracle:
         self.prev_residual = out - hidden
         return out
 
-    def apply_cache_qwen(self, core, hidden, encoder, temb, rope):     # Qwen-Image core
+    def apply_cache_wan(self, core, hidden, encoder, temb6, rope):     # Wan core: blocks return the hidden states only
+        hid1 = core.blocks[0](hidden, encoder, temb6, rope)             # xcaching.py:288-290: no sparse mask on the probe block
+        if not self._decide(hid1):
+            return hidden + self.prev_residual
+        frames = getattr(core, "_cache_frames", None)
+        for li, blk in enumerate(core.blocks[1:], start=1):
+            hid1 = blk(hid1, encoder, temb6, rope, core.block_mask(li, hid1.shape[1], frames, hid1.shape[0]) if frames else None)
+        self.prev_residual = hid1 - hidden
+        return hid1
+
+    def apply_cache_qwen(self, core, hidden, encoder, temb, rope):     # Qwen-Image and SD3.5 cores
         enc1, hid1 = core.transformer_blocks[0](hidden, encoder, temb, rope)
         if not self._decide(hid1):
             return hidden + self.prev_residual

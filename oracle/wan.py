@@ -326,8 +326,11 @@ class WanCore:
         x = x.flatten(2).transpose(1, 2)
         temb, tproj, enc = self.cond(timestep, encoder_hidden_states)
         tproj = tproj.unflatten(1, (6, -1))
-        for li, blk in enumerate(self.blocks):
-            x = blk(x, enc, tproj, rope, self.block_mask(li, x.shape[1], ppf, B))
+        if getattr(self, "cache_fn", None) is not None:      # step cache hook (wan.py:339-349): f(core, hidden, encoder, temb6, rope)
+            x = self.cache_fn(self, x, enc, tproj, rope)
+        else:
+            for li, blk in enumerate(self.blocks):
+                x = blk(x, enc, tproj, rope, self.block_mask(li, x.shape[1], ppf, B))
         shift, scale = (self.table + temb.unsqueeze(1)).chunk(2, dim=1)
         x = (fp32_layer_norm(x, eps=cfg.eps) * (1 + scale) + shift).type_as(x)
         x = self.proj_out(x)

@@ -416,3 +416,53 @@ def test_dicache_trace_flux_and_qwen():
     assert [int(t[2]) for t in cache.trace] == want, cache.trace
     d = (lat.float() - g["qwen_final"].float()).abs()
     assert d.max() <= 6e-2 and d.mean() <= 8e-3, (d.max().item(), d.mean().item())
+
+
+def test_step_caches_sd3_and_wan_traces():
+    """caching/xcaching.py sd35 branches (TeaCache, FBCache, DiCache) and the Wan FBCache branch: the oracle reproduces the
+    reference's skip decisions on 12-step trajectories and lands on the same final latents."""
+    from oracle import sd35 as OS, wan as OW
+    from oracle.make_golden import CACHE_SD3_WAN as C
+    g = load("cache_sd3_wan.npz")
+    state = {"step": 0}
+    cb = lambda: state["step"]
+    sig = torch.linspace(1.0, 1.0 / 12, 12)
+
+    def run(forward, lat):
+        for i in range(12):
+            state["step"] = i
+            out = forward(lat, sig[i:i + 1] * 1000)
+            dt = (sig[i + 1] - sig[i]) if i + 1 < 12 else -sig[i]
+            lat = (lat.float() + dt * out.float()).to(torch.bfloat16)
+        return lat
+
+    cfg = OS.TINY
+    sd = OS.synth_state_dict(cfg, seed=31)
+    inp = OS.synth_inputs(cfg, 1, 8, 12, 9, seed=33)
+    caches = {
+        "sd3_teacache": (TC.TeaCacheSD3(TC.TeaCacheConfig(threshold=C["sd3_teacache"]["threshold"], coefficients=C["sd3_teacache"]["coefficients"],
+                                                        current_steps_callback=cb)), lambda c, core, x, e, t: c.apply_cache_sd35(core, x, e, t)),
+        "sd3_fbcache": (TC.FBCacheOracle(C["sd3_fbcache"]["threshold"], C["sd3_fbcache"]["warmup_steps"], cb),
+                        lambda c, core, x, e, t: c.apply_cache_qwen(core, x, e, t, None)),
+        "sd3_dicache": (TC.DiCacheOracle(C["sd3_dicache"]["threshold"], 1, C["sd3_dicache"]["ret_ratio"], "delta_y", cb, 12),
+                        lambda c, core, x, e, t: c.apply_cache_qwen(core, x, e, t, None)),
+    }
+    for name, (cache, hook) in caches.items():
+        core = OS.SD3Core(sd, cfg, None)
+        core.cache_fn = lambda c, x, e, t, cache=cache, hook=hook: hook(cache, c, x, e, t)
+        lat = run(lambda lat, t: core.forward(hidden_states=lat, encoder_hidden_states=inp["encoder_hidden_states"],
+                                              pooled_projections=inp["pooled_projections"], timestep=t)[0], inp["hidden_states"].clone())
+        assert [int(t[-1]) for t in cache.trace] == g[f"{name}_should_calc"].tolist(), (name, cache.trace)
+        d = (lat.float() - g[f"{name}_final"].float()).abs()
+        assert d.max() <= 6e-2 and d.mean() <= 8e-3, (name, d.max().item(), d.mean().item())
+
+    wcfg = OW.TINY
+    wsd = OW.synth_state_dict(wcfg, seed=21)
+    winp = OW.synth_inputs(wcfg, 1, 3, 8, 8, 9, seed=23)
+    cache = TC.FBCacheOracle(C["wan_fbcache"]["threshold"], C["wan_fbcache"]["warmup_steps"], cb)
+    core = OW.WanCore(wsd, wcfg, torch.float8_e4m3fn)
+    core.cache_fn = lambda c, x, e, t, r: cache.apply_cache_wan(c, x, e, t, r)
+    lat = run(lambda lat, t: core.forward(lat, t, winp["encoder_hidden_states"])[0], winp["hidden_states"].clone())
+    assert [int(t[-1]) for t in cache.trace] == g["wan_fbcache_should_calc"].tolist(), cache.trace
+    d = (lat.float() - g["wan_fbcache_final"].float()).abs()
+    assert d.max() <= 1e-1 and d.mean() <= 1.5e-2, (d.max().item(), d.mean().item())

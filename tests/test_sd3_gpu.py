@@ -10,11 +10,11 @@ pytestmark = pytest.mark.gpu
 BF16, FP8 = torch.bfloat16, torch.float8_e4m3fn
 
 
-def tiny_core(quant, seed=31):
+def tiny_core(quant, seed=31, cache=None):
     from fastdm_amd.model_entry import create_model
     cfg = OS.TINY
     sd = OS.synth_state_dict(cfg, seed=seed)
-    return create_model("sd35", ckpt_path=sd, dtype=BF16, quant_type=quant, kernel_backend="hip", sample_size=cfg.sample_size,
+    return create_model("sd35", ckpt_path=sd, dtype=BF16, quant_type=quant, kernel_backend="hip", cache=cache, sample_size=cfg.sample_size,
                         patch_size=cfg.patch_size, in_channels=cfg.in_channels, out_channels=cfg.out_channels, num_layers=cfg.num_layers,
                         attention_head_dim=cfg.attention_head_dim, num_attention_heads=cfg.num_attention_heads,
                         joint_attention_dim=cfg.joint_attention_dim, caption_projection_dim=cfg.caption_projection_dim,
@@ -56,3 +56,29 @@ def test_sd3_pos_embed_crop_and_errors():
     with pytest.raises(NotImplementedError):
         from fastdm_amd.model.sd35 import JointTransformerBlock
         JointTransformerBlock(128, 2, 64, qk_norm=None)
+
+
+@pytest.mark.parametrize("name", ["sd3_teacache", "sd3_fbcache", "sd3_dicache"])
+def test_sd3_step_caches_match_reference_traces(name):
+    """caching/xcaching.py sd35 branches on the HIP path: the skip decisions of a 12-step trajectory equal the reference's and
+    the final latents agree (tests/golden/cache_sd3_wan.npz)."""
+    from fastdm_amd.caching import AutoCache
+    from oracle.make_golden import CACHE_SD3_WAN
+    g = load("cache_sd3_wan.npz")
+    state = {"step": 0}
+    cache = AutoCache.from_dict(dict(CACHE_SD3_WAN[name]))
+    cache.config.current_steps_callback = lambda: state["step"]
+    cache.config.total_steps_callback = lambda: 12
+    model = tiny_core(None, seed=31, cache=cache)
+    inp = {k: v.cuda() for k, v in OS.synth_inputs(OS.TINY, 1, 8, 12, 9, seed=33).items()}
+    sig = torch.linspace(1.0, 1.0 / 12, 12)
+    lat = inp["hidden_states"].clone()
+    for i in range(12):
+        state["step"] = i
+        out = model(hidden_states=lat, encoder_hidden_states=inp["encoder_hidden_states"], pooled_projections=inp["pooled_projections"],
+                    timestep=(sig[i:i + 1] * 1000).cuda(), return_dict=False)[0]
+        dt = (sig[i + 1] - sig[i]) if i + 1 < 12 else -sig[i]
+        lat = (lat.float() + float(dt) * out.float()).to(BF16)
+    assert [int(t[3]) for t in cache.trace] == g[f"{name}_should_calc"].tolist(), cache.trace
+    d = (lat.float().cpu() - g[f"{name}_final"].float()).abs()
+    assert d.max() <= 8e-2 and d.mean() <= 1e-2, (name, d.max().item(), d.mean().item())

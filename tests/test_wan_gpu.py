@@ -131,13 +131,14 @@ def test_radial_masks_generated_on_gpu_match_reference():
 
 
 # ------------------------------------------------------------------ tiny core vs the reference's own outputs
-def tiny_core(quant, seed=21, sparse_attn=None, cfg=OW.TINY):
+def tiny_core(quant, seed=21, sparse_attn=None, cfg=OW.TINY, cache=None):
     from fastdm_amd.model_entry import create_model
     sd = OW.synth_state_dict(cfg, seed=seed)
     mc = dict(patch_size=cfg.patch_size, num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim,
               in_channels=cfg.in_channels, out_channels=cfg.out_channels, text_dim=cfg.text_dim, freq_dim=cfg.freq_dim, ffn_dim=cfg.ffn_dim,
               num_layers=cfg.num_layers, eps=cfg.eps, rope_max_seq_len=cfg.rope_max_seq_len)
-    return create_model("wan", ckpt_path=sd, dtype=BF16, quant_type=quant, kernel_backend="hip", model_config=mc, sparse_attn=sparse_attn).eval()
+    return create_model("wan", ckpt_path=sd, dtype=BF16, quant_type=quant, kernel_backend="hip", model_config=mc, sparse_attn=sparse_attn,
+                        cache=cache).eval()
 
 
 @pytest.mark.parametrize("tag,qt", [("bf16", None), ("fp8", FP8), ("int8", torch.int8)])
@@ -209,3 +210,31 @@ def test_engine_wan_synthetic_pipeline_cfg_and_sparse_steps(tmp_path):
     assert seen and min(seen) == 1 and set(seen) == {1, 2}, seen          # step 0 dense, steps 1-2 sparse, every layer (dense_layers 0)
     with pytest.raises(ValueError):
         FastDMEngine("", architecture="flux", sparse_attn_config=str(sp))
+
+
+def test_wan_fbcache_matches_reference_trace():
+    """caching/xcaching.py wan branch of FBCache (block 0 probes without a sparse mask, the remaining blocks keep their layer
+    index) against a 12-step trajectory of the reference; DiCache's wan branch cannot run upstream and is refused."""
+    from fastdm_amd.caching import AutoCache
+    from oracle.make_golden import CACHE_SD3_WAN, load
+    g = load("cache_sd3_wan.npz")
+    state = {"step": 0}
+    cache = AutoCache.from_dict(dict(CACHE_SD3_WAN["wan_fbcache"]))
+    cache.config.current_steps_callback = lambda: state["step"]
+    model = tiny_core(torch.float8_e4m3fn, seed=21, cache=cache)
+    inp = OW.synth_inputs(OW.TINY, 1, 3, 8, 8, 9, seed=23)
+    enc = inp["encoder_hidden_states"].cuda()
+    sig = torch.linspace(1.0, 1.0 / 12, 12)
+    lat = inp["hidden_states"].cuda()
+    for i in range(12):
+        state["step"] = i
+        out = model(hidden_states=lat, timestep=(sig[i:i + 1] * 1000).cuda(), encoder_hidden_states=enc, return_dict=False)[0]
+        dt = (sig[i + 1] - sig[i]) if i + 1 < 12 else -sig[i]
+        lat = (lat.float() + float(dt) * out.float()).to(BF16)
+    assert [int(t[3]) for t in cache.trace] == g["wan_fbcache_should_calc"].tolist(), cache.trace
+    close(lat, g["wan_fbcache_final"], 1.2e-1, 2e-2, "wan fbcache final latents")
+    di = AutoCache.from_dict({"cache_algorithm": "dicache", "enable_caching": True, "threshold": 0.2, "probe_depth": 1, "ret_ratio": 0.2})
+    di.config.current_steps_callback = lambda: 5
+    bad = tiny_core(None, seed=21, cache=di)
+    with pytest.raises(NotImplementedError, match="reference's own call is broken"):
+        bad(hidden_states=inp["hidden_states"].cuda(), timestep=torch.tensor([500.0]).cuda(), encoder_hidden_states=enc, return_dict=False)
