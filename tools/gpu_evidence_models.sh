@@ -1,0 +1,12 @@
+#!/bin/bash
+# Bench lines of the widened model families (SURVEY.md §8 f): usage tools/gpu_evidence_models.sh <tag>
+tag=${1:-r01}
+out=$PWD/gpurun_out
+mkdir -p "$out"
+python3 bench.py --model qwen > "$out/${tag}_qwen_bench.json" 2> "$out/${tag}_qwen.err"
+python3 bench.py --model sd35 > "$out/${tag}_sd35_bench.json" 2> "$out/${tag}_sd35.err"
+python3 bench.py --model sdxl > "$out/${tag}_sdxl_bench.json" 2> "$out/${tag}_sdxl.err"
+python3 bench.py --model sdxl --graph > "$out/${tag}_sdxl_graph_bench.json" 2> "$out/${tag}_sdxl_graph.err"
+python3 bench.py --model wan > "$out/${tag}_wan_dense_bench.json" 2> "$out/${tag}_wan_dense.err"
+python3 bench.py --model wan --start-step 11 --sparse-config examples/sparse/radial_attn_wan.json > "$out/${tag}_wan_sparse_bench.json" 2> "$out/${tag}_wan_sparse.err"
+for f in qwen sd35 sdxl sdxl_graph wan_dense wan_sparse; do echo "$f: $(tail -1 $out/${tag}_${f}_bench.json | cut -c1-60) ... $(tail -1 $out/${tag}_${f}_bench.json | grep -o '"ms_per_step": [0-9.]*')"; done
