@@ -2,10 +2,12 @@
 """Text-to-image driver with the reference's flags (examples/demo/gen.py of the reference):
 
     python examples/demo/gen.py --architecture flux --height 1024 --width 2048 --steps 25 --use-fp8
+    python examples/demo/gen.py --architecture sdxl --height 1024 --width 1024 --steps 30 --guidance-scale 5.0 --max-seq-len 77 --use-fp8
+    python examples/demo/gen.py --architecture sd35 --height 1024 --width 1024 --steps 28 --guidance-scale 4.5 --max-seq-len 333 --use-fp8
     python examples/demo/gen.py --model-path /path/to/FLUX.1-dev --use-fp8 --output-path flux-fp8.png   # needs diffusers
 
-Without --model-path (no checkpoints / diffusers in this image) the engine denoises with synthetic FLUX.1-dev
-weights and synthetic prompt embeddings; the output is then the final packed latent tensor, saved with torch.save.
+Without --model-path (no checkpoints / diffusers in this image) the engine denoises with synthetic weights of the chosen
+architecture (flux, qwen, wan, sd35, sdxl) and synthetic prompt embeddings; the output is then the final packed latent tensor, saved with torch.save.
 """
 import os
 import sys

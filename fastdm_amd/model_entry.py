@@ -239,7 +239,7 @@ class FastDMEngine:
     def __init__(self, model_path, architecture="flux", device=0, data_type="bfloat16", use_fp8=False, use_int8=False,
                  kernel_backend="hip", cache_config=None, oom_resolve=False, use_diffusers=True, task="t2i",
                  sparse_attn_config=None, synthetic_seed=0, **model_kwargs):
-        if architecture not in ("flux", "qwen", "wan"):
+        if architecture not in ("flux", "qwen", "wan", "sd35", "sdxl"):
             raise NotImplementedError(f"architecture '{architecture}' is not built yet (SURVEY.md §8f)")
         if data_type != "bfloat16":
             raise NotImplementedError("bfloat16 activations only in this build")
@@ -262,8 +262,12 @@ class FastDMEngine:
             if self.cache:
                 self.cache.config.current_steps_callback = lambda: self.pipe.scheduler.step_index
                 self.cache.config.total_steps_callback = lambda: self.pipe.scheduler.timesteps.shape[0]
-            self.pipe.transformer = create_model(architecture, ckpt_path=self.pipe.transformer.state_dict(), dtype=self.dtype,
-                                                 quant_type=self.quant_type, kernel_backend=kernel_backend, cache=self.cache).eval()
+            if architecture == "sdxl":    # model_entry.py:640-655: the UNet is the swapped module and has no step cache
+                self.pipe.unet = create_model("sdxl", ckpt_path=self.pipe.unet.state_dict(), dtype=self.dtype, quant_type=self.quant_type,
+                                              kernel_backend=kernel_backend).eval()
+            else:
+                self.pipe.transformer = create_model(architecture, ckpt_path=self.pipe.transformer.state_dict(), dtype=self.dtype,
+                                                     quant_type=self.quant_type, kernel_backend=kernel_backend, cache=self.cache).eval()
             self.pipe.to("cuda")
         elif architecture == "wan":
             from fastdm_amd.pipeline import SyntheticWanPipeline
@@ -276,6 +280,27 @@ class FastDMEngine:
             self.pipe = SyntheticWanPipeline(transformer, seed=synthetic_seed)
             if self.sparse_attn:
                 self.sparse_attn.config.current_steps_callback = lambda: self.pipe.scheduler_step_index
+        elif architecture == "sd35":
+            from fastdm_amd.pipeline import SyntheticSD3Pipeline
+            from fastdm_amd.synthetic import SyntheticSD3StateDict
+            arch = dict(num_layers=38, num_attention_heads=38, attention_head_dim=64, caption_projection_dim=2432, pos_embed_max_size=192,
+                        dual_attention_layers=())                                     # SD3.5-large unless overridden
+            arch.update(model_kwargs)
+            transformer = create_model("sd35", ckpt_path=SyntheticSD3StateDict(seed=synthetic_seed, **arch), dtype=self.dtype,
+                                       quant_type=self.quant_type, kernel_backend=kernel_backend, cache=self.cache, **arch).eval()
+            self.pipe = SyntheticSD3Pipeline(transformer, seed=synthetic_seed)
+            if self.cache:
+                self.cache.config.current_steps_callback = lambda: self.pipe.scheduler_step_index
+                self.cache.config.total_steps_callback = lambda: self.pipe.num_steps
+        elif architecture == "sdxl":
+            from fastdm_amd.pipeline import SyntheticSDXLPipeline
+            from fastdm_amd.synthetic import SyntheticSDXLStateDict
+            if self.cache:
+                raise ValueError("the SDXL UNet has no step cache (the reference has none either, README perf table)")
+            use_graph = bool(model_kwargs.pop("use_graph", False))
+            unet = create_model("sdxl", ckpt_path=SyntheticSDXLStateDict(seed=synthetic_seed, **model_kwargs), dtype=self.dtype,
+                                quant_type=self.quant_type, kernel_backend=kernel_backend, **model_kwargs).eval()
+            self.pipe = SyntheticSDXLPipeline(unet, seed=synthetic_seed, use_graph=use_graph)
         elif architecture == "qwen":
             from fastdm_amd.pipeline import SyntheticQwenPipeline
             from fastdm_amd.synthetic import SyntheticQwenStateDict
@@ -303,7 +328,11 @@ class FastDMEngine:
 
     def generate(self, prompt=None, negative_prompt=None, src_image=None, num_frames=None, steps=50, guidance_scale=3.5,
                  true_cfg_scale=None, gen_seed=42, gen_width=512, gen_height=512, max_seq_len=512):
-        from fastdm_amd.pipeline import SyntheticFluxPipeline, SyntheticQwenPipeline, SyntheticWanPipeline
+        from fastdm_amd.pipeline import (SyntheticFluxPipeline, SyntheticQwenPipeline, SyntheticSD3Pipeline, SyntheticSDXLPipeline,
+                                         SyntheticWanPipeline)
+        if isinstance(self.pipe, (SyntheticSD3Pipeline, SyntheticSDXLPipeline)):
+            return self.pipe(num_inference_steps=steps, guidance_scale=guidance_scale, width=gen_width, height=gen_height,
+                             max_sequence_length=max_seq_len, seed=gen_seed)
         if isinstance(self.pipe, SyntheticWanPipeline):
             return self.pipe(num_inference_steps=steps, guidance_scale=guidance_scale, width=gen_width, height=gen_height,
                              num_frames=num_frames or 81, max_sequence_length=max_seq_len, seed=gen_seed)

@@ -188,3 +188,104 @@ class SyntheticWanPipeline:
             lat = self.step(lat, inp, sig[i], sig[i + 1], guidance_scale)
         self.scheduler_step_index = None
         return lat
+
+
+class SyntheticSD3Pipeline:
+    """What diffusers' StableDiffusion3Pipeline does around `pipe.transformer`: latents [B, 16, H/8, W/8], classifier-free
+    guidance as ONE batch-2 forward ([uncond ; cond] concatenated along the batch), `timestep = sigma * 1000`, flow-match Euler
+    update with shift 3."""
+
+    def __init__(self, transformer, seed: int = 0):
+        self.transformer = transformer
+        self.seed = seed
+        self.scheduler_step_index = None
+        self.num_steps = 0
+
+    def prepare(self, height, width, max_sequence_length, seed):
+        c = self.transformer.config
+        return synthetic.sd3_step_inputs(2, height // 8, width // 8, max_sequence_length, c.in_channels, c.joint_attention_dim,
+                                         c.pooled_projection_dim, seed=seed)
+
+    @staticmethod
+    def sigmas(num_steps: int, shift: float = 3.0):
+        s = np.linspace(1.0, 1.0 / num_steps, num_steps)
+        s = shift * s / (1.0 + (shift - 1.0) * s)
+        return np.concatenate([s, [0.0]]).astype(np.float32)
+
+    @torch.no_grad()
+    def step(self, latents, inp, sigma, sigma_next, guidance_scale):
+        """latents [1, C, h, w] -> next latents; rows 0 / 1 of the prompt tensors are the unconditional / conditional prompt."""
+        t = torch.full((2,), float(sigma) * 1000.0, device=latents.device, dtype=torch.float32)
+        v = self.transformer(hidden_states=latents.expand(2, -1, -1, -1).contiguous(), encoder_hidden_states=inp["encoder_hidden_states"],
+                             pooled_projections=inp["pooled_projections"], timestep=t, return_dict=False)[0].float()
+        noise = v[0:1] + guidance_scale * (v[1:2] - v[0:1])
+        return (latents.float() + float(sigma_next - sigma) * noise).to(latents.dtype)
+
+    @torch.no_grad()
+    def __call__(self, num_inference_steps=28, guidance_scale=4.5, width=1024, height=1024, max_sequence_length=333, seed=None, latents=None, **_):
+        seed = self.seed if seed is None else seed
+        inp = self.prepare(height, width, max_sequence_length, seed)
+        lat = inp["hidden_states"][0:1].clone() if latents is None else latents
+        sig = self.sigmas(num_inference_steps)
+        self.num_steps = num_inference_steps
+        for i in range(num_inference_steps):
+            self.scheduler_step_index = i
+            lat = self.step(lat, inp, sig[i], sig[i + 1], guidance_scale)
+        self.scheduler_step_index = None
+        return lat
+
+
+class SyntheticSDXLPipeline:
+    """What diffusers' StableDiffusionXLPipeline does around `pipe.unet`: latents [B, 4, H/8, W/8], classifier-free guidance
+    as one batch-2 UNet forward, epsilon prediction on a linearly spaced discrete-timestep grid with an Euler update in sigma
+    space (sigma_t from the scaled-linear beta schedule, as EulerDiscreteScheduler does).  `use_graph=True` replays the UNet
+    from a HIP graph (fastdm_amd/graph.py): the step is launch-bound."""
+
+    def __init__(self, unet, seed: int = 0, use_graph: bool = False):
+        self.unet = unet
+        self.seed = seed
+        self.use_graph = use_graph
+        self.scheduler_step_index = None
+        self.num_steps = 0
+        self._graph_key, self._graphed = None, None
+
+    @staticmethod
+    def schedule(num_steps: int):
+        betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2
+        alphas = np.cumprod(1.0 - betas)
+        sig_all = ((1.0 - alphas) / alphas) ** 0.5
+        ts = np.linspace(999, 0, num_steps).round().astype(np.int64)
+        return ts, np.concatenate([sig_all[ts], [0.0]]).astype(np.float32)
+
+    def prepare(self, height, width, max_sequence_length, seed):
+        return synthetic.sdxl_step_inputs(2, height // 8, width // 8, max_sequence_length, self.unet.config.in_channels, seed=seed)
+
+    def _forward(self, sample, t, inp):
+        fn = lambda s, tt: self.unet(s, tt, inp["encoder_hidden_states"], inp["added_cond_kwargs"])[0]
+        if not self.use_graph:
+            return fn(sample, t)
+        key = (tuple(sample.shape), id(inp))
+        if key != self._graph_key:
+            from fastdm_amd.graph import GraphedForward
+            self._graphed, self._graph_key = GraphedForward(fn, sample, t), key
+        return self._graphed(sample, t)
+
+    @torch.no_grad()
+    def step(self, latents, inp, timestep, sigma, sigma_next, guidance_scale):
+        x = (latents.float() / ((sigma ** 2 + 1.0) ** 0.5)).to(latents.dtype)              # scale_model_input
+        eps = self._forward(x.expand(2, -1, -1, -1).contiguous(), torch.tensor(float(timestep), device=latents.device), inp).float()
+        noise = eps[0:1] + guidance_scale * (eps[1:2] - eps[0:1])
+        return (latents.float() + float(sigma_next - sigma) * noise).to(latents.dtype)
+
+    @torch.no_grad()
+    def __call__(self, num_inference_steps=30, guidance_scale=5.0, width=1024, height=1024, max_sequence_length=77, seed=None, latents=None, **_):
+        seed = self.seed if seed is None else seed
+        inp = self.prepare(height, width, max_sequence_length, seed)
+        ts, sig = self.schedule(num_inference_steps)
+        lat = (inp["sample"][0:1].float() * float(sig[0])).to(torch.bfloat16) if latents is None else latents    # init_noise_sigma
+        self.num_steps = num_inference_steps
+        for i in range(num_inference_steps):
+            self.scheduler_step_index = i
+            lat = self.step(lat, inp, ts[i], float(sig[i]), float(sig[i + 1]), guidance_scale)
+        self.scheduler_step_index = None
+        return lat

@@ -119,3 +119,36 @@ def test_hip_graph_replay_equals_eager_forward():
         want = unet(lat, tt).clone()
         got = graphed(lat, tt)
         assert torch.equal(got, want), t
+
+
+def test_engine_sdxl_and_sd35_synthetic_pipelines(tmp_path):
+    """FastDMEngine(architecture='sdxl' | 'sd35') without a checkpoint: CFG as one batch-2 forward per step on synthetic weights;
+    the SDXL engine with use_graph replays the UNet from a HIP graph and lands on the eager trajectory's latents."""
+    import json
+    from fastdm_amd.model_entry import FastDMEngine
+    cfg = OX.TINY
+    kw = dict(block_out_channels=cfg.block_out_channels, transformer_layers=cfg.transformer_layers, mid_layers=cfg.mid_layers)
+    eager = FastDMEngine("", architecture="sdxl", use_fp8=True, kernel_backend="hip", **kw)
+    lat = eager.generate(steps=4, guidance_scale=5.0, gen_seed=3, gen_width=192, gen_height=128, max_seq_len=11)
+    assert lat.shape == (1, 4, 16, 24) and torch.isfinite(lat.float()).all()
+    lat = eager.generate(steps=4, guidance_scale=5.0, gen_seed=3, gen_width=192, gen_height=128, max_seq_len=11)     # MIOpen settled (see sdxl.py)
+    graphed = FastDMEngine("", architecture="sdxl", use_fp8=True, kernel_backend="hip", use_graph=True, **kw)
+    lat_g = graphed.generate(steps=4, guidance_scale=5.0, gen_seed=3, gen_width=192, gen_height=128, max_seq_len=11)
+    assert (lat_g.float() - lat.float()).abs().max() <= 0.25 * lat.float().abs().max()
+    cc = tmp_path / "tea.json"
+    cc.write_text(json.dumps({"cache_algorithm": "teacache", "enable_caching": True, "threshold": 0.25, "coefficients": [1.0, 0.0]}))
+    with pytest.raises(ValueError, match="no step cache"):
+        FastDMEngine("", architecture="sdxl", cache_config=str(cc), **kw)
+
+    from oracle import sd35 as OS
+    c3 = OS.TINY
+    arch = dict(sample_size=c3.sample_size, patch_size=c3.patch_size, in_channels=c3.in_channels, out_channels=c3.out_channels,
+                num_layers=c3.num_layers, attention_head_dim=c3.attention_head_dim, num_attention_heads=c3.num_attention_heads,
+                joint_attention_dim=c3.joint_attention_dim, caption_projection_dim=c3.caption_projection_dim,
+                pooled_projection_dim=c3.pooled_projection_dim, pos_embed_max_size=c3.pos_embed_max_size,
+                dual_attention_layers=c3.dual_attention_layers)
+    eng = FastDMEngine("", architecture="sd35", use_fp8=True, kernel_backend="hip", cache_config=str(cc), **arch)
+    lat = eng.generate(steps=6, guidance_scale=4.5, gen_seed=5, gen_width=96, gen_height=64, max_seq_len=9)
+    assert lat.shape == (1, 16, 8, 12) and torch.isfinite(lat.float()).all()
+    calc = [t[3] for t in eng.cache.trace]
+    assert len(calc) == 6 and calc[0] and not all(calc), calc        # TeaCache driven by the pipeline's step index skipped something
