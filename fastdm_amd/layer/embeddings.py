@@ -231,25 +231,47 @@ class WanRotaryPosEmbed:
         return self._merged[key]
 
 
+class WanImageEmbedding:
+    """embeddings.py:925-947 (Wan2.1-I2V): FP32LayerNorm -> FeedForward(mult 1, erf GELU) -> FP32LayerNorm on the CLIP image
+    tokens; never quantised (wan.py:237-238).  The first/last-frame positional table (`pos_embed_seq_len`) is not built --
+    upstream cannot load it either (`self.init(...)`, wan.py:243)."""
+
+    def __init__(self, in_features: int, out_features: int, pos_embed_seq_len=None, data_type=BF16):
+        from fastdm_amd.layer.normalization import FP32LayerNorm
+        from fastdm_amd.layer.transformer import FeedForward
+        if pos_embed_seq_len is not None:
+            raise NotImplementedError("WanImageEmbedding.pos_embed (FLF2V) is not built")
+        self.norm1 = FP32LayerNorm(in_features)
+        self.ff = FeedForward(in_features, out_features, mult=1, activation_fn="gelu", data_type=data_type)
+        self.norm2 = FP32LayerNorm(out_features)
+        self.pos_embed = None
+
+    def forward(self, encoder_hidden_states_image: torch.Tensor) -> torch.Tensor:
+        b, n, c = encoder_hidden_states_image.shape
+        h = self.norm1.forward_bf16(encoder_hidden_states_image.reshape(b * n, c).contiguous())[0]
+        h = self.ff.forward(h)
+        return self.norm2.forward_bf16(h.contiguous())[0].view(b, n, -1)
+
+
 class WanTimeTextImageEmbedding:
-    """embeddings.py:949-992 (T2V: no image embedder).  The time embedder is an fp32 layer."""
+    """embeddings.py:949-992.  The time embedder is an fp32 layer; the image embedder exists for Wan2.1-I2V checkpoints."""
 
     def __init__(self, dim: int, time_freq_dim: int, time_proj_dim: int, text_embed_dim: int, image_embed_dim=None,
                  pos_embed_seq_len=None, data_type=BF16):
-        if image_embed_dim is not None:
-            raise NotImplementedError("the I2V image embedder is not built (SURVEY.md §8f)")
         self.timesteps_proj = Timesteps(num_channels=time_freq_dim, flip_sin_to_cos=True, downscale_freq_shift=0)
         self.time_embedder = TimestepEmbedding(in_features=time_freq_dim, out_features=dim, data_type=torch.float32)
         self.time_proj = QLinear(dim, time_proj_dim, data_type=data_type)
         self.text_embedder = PixArtAlphaTextProjection(text_embed_dim, dim, act_fn="gelu_tanh", data_type=data_type)
-        self.image_embedder = None
+        self.image_embedder = (WanImageEmbedding(image_embed_dim, dim, pos_embed_seq_len=pos_embed_seq_len, data_type=data_type)
+                               if image_embed_dim is not None else None)
 
     def forward(self, timestep, encoder_hidden_states, encoder_hidden_states_image=None, timestep_seq_len=None):
         assert timestep_seq_len is None, "per-token timesteps (wan2.2 ti2v) are not built"
         ts = self.timesteps_proj.forward(timestep).to(torch.float32)
         temb = self.time_embedder.forward(ts).type_as(encoder_hidden_states)
         timestep_proj = self.time_proj.forward(F.silu(temb))
-        return temb, timestep_proj, self.text_embedder.forward(encoder_hidden_states), None
+        img = self.image_embedder.forward(encoder_hidden_states_image) if encoder_hidden_states_image is not None else None
+        return temb, timestep_proj, self.text_embedder.forward(encoder_hidden_states), img
 
 
 class PatchEmbed:

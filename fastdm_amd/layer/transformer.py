@@ -154,17 +154,18 @@ class Attention:
 
 
 class WanAttention:
-    """transformer.py:393-534 (T2V: no added image K/V).  q/k RMS-norm runs ACROSS heads (over the whole inner dim),
-    RoPE is GPT-J style on the merged [cos | sin] table, self-attention may be block-sparse (radial)."""
+    """transformer.py:393-534.  q/k RMS-norm runs ACROSS heads (over the whole inner dim), RoPE is GPT-J style on the merged
+    [cos | sin] table, self-attention may be block-sparse (radial).  With `added_kv_proj_dim` (Wan2.1-I2V) the cross-attention
+    also attends the image-context tokens -- the rows in front of the 512 text tokens -- through add_k_proj / add_v_proj and
+    adds that result."""
+    TEXT_LEN = 512          # "512 is the context length of the text encoder, hardcoded for now" (transformer.py:473-474)
 
     def __init__(self, dim: int, heads: int = 8, dim_head: int = 64, eps: float = 1e-5, dropout: float = 0.0,
                  added_kv_proj_dim: Optional[int] = None, cross_attention_dim_head: Optional[int] = None, processor=None,
                  is_cross_attention=None, is_causal: bool = False, data_type=BF16):
-        if added_kv_proj_dim is not None:
-            raise NotImplementedError("the I2V image K/V branch is not built (SURVEY.md §8f)")
         self.inner_dim = dim_head * heads
         self.heads, self.head_dim, self.eps = heads, dim_head, eps
-        self.added_kv_proj_dim = None
+        self.added_kv_proj_dim = added_kv_proj_dim
         self.cross_attention_dim_head = cross_attention_dim_head
         self.kv_inner_dim = self.inner_dim if cross_attention_dim_head is None else cross_attention_dim_head * heads
         self.is_causal = is_causal
@@ -178,16 +179,27 @@ class WanAttention:
             self.qkv = QLinear(dim, self.inner_dim + 2 * self.kv_inner_dim, bias=True, data_type=data_type)
         self.to_out = QLinear(self.inner_dim, dim, bias=True, data_type=data_type)
         self.add_k_proj = self.add_v_proj = None
+        self.norm_added_k_weight = None
+        if added_kv_proj_dim is not None:
+            self.add_k_proj = QLinear(added_kv_proj_dim, self.inner_dim, bias=True, data_type=data_type)
+            self.add_v_proj = QLinear(added_kv_proj_dim, self.inner_dim, bias=True, data_type=data_type)
         self.is_cross_attention = cross_attention_dim_head is not None
 
     # ---- fused path: x is a [B*S, D] matrix (Quantized or bf16); returns the attention result [B*S, inner] (before to_out)
-    def attend(self, xq, batch: int, seq: int, rope=None, enc_q=None, enc_len: int = 0, sparse_attn=None, layer_index: int = 0):
+    def attend(self, xq, batch: int, seq: int, rope=None, enc_q=None, enc_len: int = 0, sparse_attn=None, layer_index: int = 0,
+               img_q=None, img_len: int = 0):
+        """enc_q: GEMM input of the TEXT rows [B*enc_len, D]; img_q: of the image-context rows [B*img_len, added_kv_proj_dim]."""
         D = self.inner_dim
         if self.is_cross_attention:
             q = fused.rms_norm_rows(self.to_q.forward_q(xq), self.norm_q_weight, self.eps)
             kv = self.to_kv.forward_q(enc_q)
             k = fused.rms_norm_rows(kv[:, :D], self.norm_k_weight, self.eps)
             v, sk = kv[:, D:], enc_len
+            if img_q is not None:       # transformer.py:502-507,531-532
+                k_img = fused.rms_norm_rows(self.add_k_proj.forward_q(img_q), self.norm_added_k_weight, self.eps)
+                v_img = self.add_v_proj.forward_q(img_q)
+                return (fused.attention(q, k, v, batch, self.heads, self.head_dim, self.scale)
+                        + fused.attention(q, k_img, v_img, batch, self.heads, self.head_dim, self.scale))
         else:
             qkv = self.qkv.forward_q(xq)
             q = fused.rms_norm_rows(qkv[:, :D], self.norm_q_weight, self.eps)
@@ -222,11 +234,16 @@ class WanAttention:
         if rotary_emb is not None:
             rope = rotary_emb if torch.is_tensor(rotary_emb) else \
                 torch.cat((rotary_emb[0].squeeze()[:, 0::2], rotary_emb[1].squeeze()[:, 1::2]), dim=-1).to(hidden_states.dtype).contiguous()
-        enc_q, enc_len = None, 0
+        enc_q, enc_len, img_q, img_len = None, 0, None, 0
         if self.is_cross_attention:
+            if self.add_k_proj is not None:
+                img_len = encoder_hidden_states.shape[1] - self.TEXT_LEN
+                ei = encoder_hidden_states[:, :img_len].reshape(B * img_len, -1).contiguous()
+                img_q = self.add_k_proj.quantize_input(ei) if self.add_k_proj.quant_type is not None else ei
+                encoder_hidden_states = encoder_hidden_states[:, img_len:]
             enc_len = encoder_hidden_states.shape[1]
             e = encoder_hidden_states.reshape(B * enc_len, -1).contiguous()
             enc_q = self.to_kv.quantize_input(e) if self.to_kv.quant_type is not None else e
-        o = self.attend(xq, B, S, rope, enc_q, enc_len, sparse_attn, kwargs.get("layer_index", 0))
+        o = self.attend(xq, B, S, rope, enc_q, enc_len, sparse_attn, kwargs.get("layer_index", 0), img_q, img_len)
         oq = self.to_out.quantize_input(o) if self.to_out.quant_type is not None else o
         return self.to_out.forward_q(oq).view(B, S, -1)

@@ -77,11 +77,22 @@ class WanTransformerBlock:
             n = pick(self.norm2.forward_bf16(x1, quant=quant))
         else:
             n = a2.to_q.quantize_input(x1) if quant is not None else x1
+        img_q, s_img = None, 0
+        if a2.add_k_proj is not None:     # Wan2.1-I2V: the image-context rows sit in front of the 512 text rows
+            s_img = encoder_hidden_states.shape[1] - a2.TEXT_LEN
+            if isinstance(encoder_q, tuple):
+                encoder_q, img_q = encoder_q
+            else:
+                encoder_q = None
+            if img_q is None:
+                ei = encoder_hidden_states[:, :s_img].reshape(B * s_img, -1).contiguous()
+                img_q = a2.add_k_proj.quantize_input(ei) if a2.add_k_proj.quant_type is not None else ei
+            encoder_hidden_states = encoder_hidden_states[:, s_img:]
         s_txt = encoder_hidden_states.shape[1]
         if encoder_q is None:
             e = encoder_hidden_states.reshape(B * s_txt, -1).contiguous()
             encoder_q = a2.to_kv.quantize_input(e) if a2.to_kv.quant_type is not None else e
-        o = a2.attend(n, B, S, None, encoder_q, s_txt)
+        o = a2.attend(n, B, S, None, encoder_q, s_txt, img_q=img_q, img_len=s_img)
         oq = a2.to_out.quantize_input(o) if a2.to_out.quant_type is not None else o
         if self._ones is None:
             self._ones = torch.ones((1, D), device=x.device, dtype=BF16)
@@ -137,6 +148,14 @@ class WanTransformer3DModelCore(BaseModelCore):
         self.init_weight(["condition_embedder.time_proj"], ce.time_proj)
         self.init_weight(["condition_embedder.text_embedder.linear_1"], ce.text_embedder.linear1)
         self.init_weight(["condition_embedder.text_embedder.linear_2"], ce.text_embedder.linear2)
+        ie = ce.image_embedder
+        if ie is not None:                                                   # wan.py:234-243
+            ie.norm1.weight = self.init_weight(["condition_embedder.image_embedder.norm1.weight"]).to(torch.float32)
+            ie.norm1.bias = self.init_weight(["condition_embedder.image_embedder.norm1.bias"]).to(torch.float32)
+            self.init_weight(["condition_embedder.image_embedder.ff.net.0.proj"], ie.ff.act_fn.proj)
+            self.init_weight(["condition_embedder.image_embedder.ff.net.2"], ie.ff.ff_out_proj)
+            ie.norm2.weight = self.init_weight(["condition_embedder.image_embedder.norm2.weight"]).to(torch.float32)
+            ie.norm2.bias = self.init_weight(["condition_embedder.image_embedder.norm2.bias"]).to(torch.float32)
 
     def _major_parts_loading(self):
         q = self.quant_dtype
@@ -151,6 +170,10 @@ class WanTransformer3DModelCore(BaseModelCore):
             self.init_weight([f"{p}.attn2.to_q"], blk.attn2.to_q, q)
             self.init_weight([f"{p}.attn2.to_k", f"{p}.attn2.to_v"], blk.attn2.to_kv, q)
             self.init_weight([f"{p}.attn2.to_out.0"], blk.attn2.to_out, q)
+            if blk.attn2.added_kv_proj_dim is not None:                      # wan.py:262-265
+                self.init_weight([f"{p}.attn2.add_k_proj"], blk.attn2.add_k_proj, q)
+                self.init_weight([f"{p}.attn2.add_v_proj"], blk.attn2.add_v_proj, q)
+                blk.attn2.norm_added_k_weight = self.init_weight([f"{p}.attn2.norm_added_k.weight"])
             if blk.cross_attn_norm:
                 blk.norm2.weight = self.init_weight([f"{p}.norm2.weight"]).to(torch.float32)
                 blk.norm2.bias = self.init_weight([f"{p}.norm2.bias"]).to(torch.float32)
@@ -174,7 +197,6 @@ class WanTransformer3DModelCore(BaseModelCore):
     def forward(self, hidden_states: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
                 encoder_hidden_states_image: Optional[torch.Tensor] = None, return_dict: bool = True,
                 attention_kwargs: Optional[Dict[str, Any]] = None) -> Union[torch.Tensor, Tuple[torch.Tensor]]:
-        assert encoder_hidden_states_image is None, "I2V conditioning is not built"
         dev = self.proj_out.weight.device
         hidden_states, timestep, encoder_hidden_states = hidden_states.to(dev), timestep.to(dev), encoder_hidden_states.to(dev)
         B, C, Fr, H, W = hidden_states.shape
@@ -187,12 +209,18 @@ class WanTransformer3DModelCore(BaseModelCore):
         # patchify: [B, C, F, H, W] -> [B*S, C*pt*ph*pw] rows in (f, h, w) token order, columns in the conv weight's (c, t, h, w) order
         patches = hidden_states.reshape(B, C, ppf, p_t, pph, p_h, ppw, p_w).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * S, -1).contiguous()
         x = self.patch_embedding.forward_q(patches).view(B, S, self.inner_dim)
-        temb, timestep_proj, enc, _ = self.condition_embedder.forward(timestep, encoder_hidden_states)
+        if encoder_hidden_states_image is not None:
+            encoder_hidden_states_image = encoder_hidden_states_image.to(dev)
+        temb, timestep_proj, enc, enc_img = self.condition_embedder.forward(timestep, encoder_hidden_states, encoder_hidden_states_image)
         timestep_proj = timestep_proj.unflatten(1, (6, -1))
         a2 = self.blocks[0].attn2
         e2 = enc.reshape(B * enc.shape[1], -1).contiguous()
         # every block quantises the same text rows for its to_kv projection: do it once
         enc_q = a2.to_kv.quantize_input(e2) if a2.to_kv.quant_type is not None else e2
+        if enc_img is not None:                                              # wan.py:333-334: image context in front of the text
+            ei = enc_img.reshape(B * enc_img.shape[1], -1).contiguous()
+            enc_q = (enc_q, a2.add_k_proj.quantize_input(ei) if a2.add_k_proj.quant_type is not None else ei)
+            enc = torch.concat([enc_img, enc], dim=1)
         self._enc_q = enc_q
         try:
             if self.enable_caching:       # wan.py:339-349

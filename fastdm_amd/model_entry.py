@@ -186,7 +186,8 @@ class WanTransformer3DWrapper(BaseModelWrapper):
             patch_size=tuple(cfg["patch_size"]), num_attention_heads=cfg["num_attention_heads"], attention_head_dim=cfg["attention_head_dim"],
             in_channels=cfg["in_channels"], out_channels=cfg["out_channels"], text_dim=cfg["text_dim"], freq_dim=cfg["freq_dim"],
             ffn_dim=cfg["ffn_dim"], num_layers=cfg["num_layers"], qk_norm=cfg["qk_norm"], eps=cfg["eps"],
-            rope_max_seq_len=cfg["rope_max_seq_len"], data_type=dtype, quant_dtype=quant_type, cache=cache,
+            rope_max_seq_len=cfg["rope_max_seq_len"], image_dim=cfg.get("image_dim"), added_kv_proj_dim=cfg.get("added_kv_proj_dim"),
+            pos_embed_seq_len=cfg.get("pos_embed_seq_len"), data_type=dtype, quant_dtype=quant_type, cache=cache,
             sparse_attn=kwargs.get("sparse_attn", None))
         self._load_weights(ckpt_path, dtype, quantized_cache)
 

@@ -180,10 +180,11 @@ def qwen_step_inputs(batch, img_h, img_w, n_txt=128, in_channels=64, joint_atten
 
 
 class SyntheticWanStateDict(dict):
-    """Lazily generated diffusers-named Wan (T2V) state_dict, bit-identical to oracle.wan.synth_state_dict."""
+    """Lazily generated diffusers-named Wan state_dict (T2V, or Wan2.1-I2V with image_dim / added_kv_proj_dim), bit-identical
+    to oracle.wan.synth_state_dict."""
 
     def __init__(self, patch_size=(1, 2, 2), num_attention_heads=40, attention_head_dim=128, in_channels=16, out_channels=16, text_dim=4096,
-                 freq_dim=256, ffn_dim=13824, num_layers=40, seed=0, device="cuda", **_):
+                 freq_dim=256, ffn_dim=13824, num_layers=40, image_dim=None, added_kv_proj_dim=None, seed=0, device="cuda", **_):
         super().__init__()
         self.seed, self.device = seed, device
         D = num_attention_heads * attention_head_dim
@@ -201,6 +202,12 @@ class SyntheticWanStateDict(dict):
         lin("condition_embedder.time_proj", D, 6 * D, "w_mod")
         lin("condition_embedder.text_embedder.linear_1", text_dim, D)
         lin("condition_embedder.text_embedder.linear_2", D, D)
+        if image_dim is not None:
+            ie = "condition_embedder.image_embedder"
+            spec[f"{ie}.norm1.weight"], spec[f"{ie}.norm1.bias"] = ((image_dim,), "rms"), ((image_dim,), "b")
+            lin(f"{ie}.ff.net.0.proj", image_dim, image_dim)
+            lin(f"{ie}.ff.net.2", image_dim, D)
+            spec[f"{ie}.norm2.weight"], spec[f"{ie}.norm2.bias"] = ((D,), "rms"), ((D,), "b")
         for i in range(num_layers):
             p = f"blocks.{i}"
             for a in ("attn1", "attn2"):
@@ -208,6 +215,10 @@ class SyntheticWanStateDict(dict):
                     lin(f"{p}.{a}.{n}", D, D)
                 spec[f"{p}.{a}.norm_q.weight"] = ((D,), "rms")
                 spec[f"{p}.{a}.norm_k.weight"] = ((D,), "rms")
+            if added_kv_proj_dim is not None:
+                lin(f"{p}.attn2.add_k_proj", added_kv_proj_dim, D)
+                lin(f"{p}.attn2.add_v_proj", added_kv_proj_dim, D)
+                spec[f"{p}.attn2.norm_added_k.weight"] = ((D,), "rms")
             spec[f"{p}.norm2.weight"] = ((D,), "rms")
             spec[f"{p}.norm2.bias"] = ((D,), "b")
             lin(f"{p}.ffn.net.0.proj", D, ffn_dim)

@@ -427,6 +427,7 @@ def ref_wan_core(cfg, quant, sd, cache=None):
         patch_size=cfg.patch_size, num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim,
         in_channels=cfg.in_channels, out_channels=cfg.out_channels, text_dim=cfg.text_dim, freq_dim=cfg.freq_dim, ffn_dim=cfg.ffn_dim,
         num_layers=cfg.num_layers, cross_attn_norm=True, eps=cfg.eps, rope_max_seq_len=cfg.rope_max_seq_len,
+        image_dim=cfg.image_dim, added_kv_proj_dim=cfg.added_kv_proj_dim,
         data_type=torch.bfloat16, quant_dtype=quant, cache=cache, sparse_attn=None)
     import contextlib
     import io
@@ -472,6 +473,26 @@ def gen_tiny_wan():
         m[f"g{gi}_log_mask"] = lm.to(torch.uint8)
         m[f"g{gi}_kernel_mask"] = sparge_mask_convert(lm, block_size=bs, arch="sm80").to(torch.uint8)
     save("wan_radial_mask.npz", m)
+
+
+def gen_tiny_wan_i2v():
+    """Wan2.1-I2V wiring (image_dim / added_kv_proj_dim: CLIP image tokens through the image embedder, prepended to the 512
+    text tokens, attended through add_k_proj / add_v_proj in every cross-attention) on a tiny core through the reference."""
+    import_reference()
+    from oracle import wan as OW
+    cfg = OW.TINY_I2V
+    sd = OW.synth_state_dict(cfg, seed=27)
+    inp = OW.synth_inputs(cfg, batch=2, frames=3, height=8, width=8, n_txt=OW.TEXT_LEN_I2V, seed=27)
+    d = {"seed": 27, "batch": 2, "frames": 3, "height": 8, "width": 8}
+    for tag, qt in (("bf16", None), ("fp8", torch.float8_e4m3fn), ("int8", torch.int8)):
+        use_backend("cpu_fp8" if qt == torch.float8_e4m3fn else "torch")
+        core = ref_wan_core(cfg, qt, sd)
+        out = core.forward(hidden_states=inp["hidden_states"], timestep=torch.tensor([700.0, 700.0]),
+                           encoder_hidden_states=inp["encoder_hidden_states"], encoder_hidden_states_image=inp["encoder_hidden_states_image"],
+                           return_dict=False)
+        d[f"out_{tag}"] = out[0] if isinstance(out, (tuple, list)) else out
+    use_backend("torch")
+    save("tiny_wan_i2v.npz", d)
 
 
 def gen_fbcache():
@@ -915,7 +936,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_wan_cache", "sdxl", "sdxl_full", "c3"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "wan_i2v", "sd3_wan_cache", "sdxl", "sdxl_full", "c3"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     args = ap.parse_args()
@@ -938,6 +959,8 @@ def main():
         gen_dicache()
     if args.what in ("small", "sd3"):
         gen_tiny_sd3()
+    if args.what in ("small", "wan_i2v"):
+        gen_tiny_wan_i2v()
     if args.what in ("small", "sd3_wan_cache"):
         gen_cache_sd3_wan()
     if args.what in ("small", "sdxl"):

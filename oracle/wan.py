@@ -38,6 +38,8 @@ class WanConfig:
     num_layers: int = 40
     eps: float = 1e-6
     rope_max_seq_len: int = 1024
+    image_dim: Optional[int] = None           # Wan2.1-I2V: CLIP image embeddings (1280) -> image_embedder (wan.py:167,197)
+    added_kv_proj_dim: Optional[int] = None   # ... and their own K/V projections in every cross-attention (wan.py:168,205)
 
     @property
     def inner_dim(self):
@@ -45,6 +47,9 @@ class WanConfig:
 
 
 TINY = WanConfig(num_attention_heads=2, attention_head_dim=64, in_channels=16, out_channels=16, text_dim=96, ffn_dim=256, num_layers=2)
+TINY_I2V = WanConfig(num_attention_heads=2, attention_head_dim=64, in_channels=36, out_channels=16, text_dim=96, ffn_dim=256, num_layers=2,
+                     image_dim=48, added_kv_proj_dim=128)
+TEXT_LEN_I2V = 512     # "512 is the context length of the text encoder, hardcoded for now" (transformer.py:473-474)
 
 
 def param_specs(cfg: WanConfig):
@@ -63,6 +68,14 @@ def param_specs(cfg: WanConfig):
     yield from lin("condition_embedder.time_proj", D, 6 * D, "w_mod")
     yield from lin("condition_embedder.text_embedder.linear_1", cfg.text_dim, D)
     yield from lin("condition_embedder.text_embedder.linear_2", D, D)
+    if cfg.image_dim is not None:                                   # wan.py:234-243
+        ie = "condition_embedder.image_embedder"
+        yield f"{ie}.norm1.weight", (cfg.image_dim,), "rms"
+        yield f"{ie}.norm1.bias", (cfg.image_dim,), "b"
+        yield from lin(f"{ie}.ff.net.0.proj", cfg.image_dim, cfg.image_dim)
+        yield from lin(f"{ie}.ff.net.2", cfg.image_dim, D)
+        yield f"{ie}.norm2.weight", (D,), "rms"
+        yield f"{ie}.norm2.bias", (D,), "b"
     for i in range(cfg.num_layers):
         p = f"blocks.{i}"
         for a in ("attn1", "attn2"):
@@ -70,6 +83,10 @@ def param_specs(cfg: WanConfig):
                 yield from lin(f"{p}.{a}.{n}", D, D)
             yield f"{p}.{a}.norm_q.weight", (D,), "rms"
             yield f"{p}.{a}.norm_k.weight", (D,), "rms"
+        if cfg.added_kv_proj_dim is not None:                       # wan.py:262-265
+            yield from lin(f"{p}.attn2.add_k_proj", cfg.added_kv_proj_dim, D)
+            yield from lin(f"{p}.attn2.add_v_proj", cfg.added_kv_proj_dim, D)
+            yield f"{p}.attn2.norm_added_k.weight", (D,), "rms"
         yield f"{p}.norm2.weight", (D,), "rms"
         yield f"{p}.norm2.bias", (D,), "b"
         yield from lin(f"{p}.ffn.net.0.proj", D, F_)
@@ -100,8 +117,11 @@ def synth_inputs(cfg: WanConfig, batch: int, frames: int, height: int, width: in
         bits = synth.normal_bf16_bits(synth.key_seed(f"wan.input.{tag}", seed), int(np.prod(shape)), 1.0, 0.0)
         return bf16_from_bits(bits, shape)
 
-    return dict(hidden_states=nrm("latents", (batch, cfg.in_channels, frames, height, width)),
-                encoder_hidden_states=nrm("prompt_embeds", (batch, n_txt, cfg.text_dim)))
+    d = dict(hidden_states=nrm("latents", (batch, cfg.in_channels, frames, height, width)),
+             encoder_hidden_states=nrm("prompt_embeds", (batch, n_txt, cfg.text_dim)))
+    if cfg.image_dim is not None:
+        d["encoder_hidden_states_image"] = nrm("image_embeds", (batch, 5, cfg.image_dim))      # 5 image-context tokens (257 for CLIP ViT-H)
+    return d
 
 
 # ------------------------------------------------------------------ embeddings
@@ -146,6 +166,17 @@ class WanConditionEmbedder:
         self.t1 = L.linear_from(sd, [f"{p}.text_embedder.linear_1"])
         self.t2 = L.linear_from(sd, [f"{p}.text_embedder.linear_2"])
         self.freq_dim = cfg.freq_dim
+        self.img = None
+        if cfg.image_dim is not None:           # WanImageEmbedding (embeddings.py:925-947), no pos_embed
+            ie = f"{p}.image_embedder"
+            self.img = dict(n1=(sd[f"{ie}.norm1.weight"].float(), sd[f"{ie}.norm1.bias"].float()), f1=L.linear_from(sd, [f"{ie}.ff.net.0.proj"]),
+                            f2=L.linear_from(sd, [f"{ie}.ff.net.2"]), n2=(sd[f"{ie}.norm2.weight"].float(), sd[f"{ie}.norm2.bias"].float()))
+
+    def image_embed(self, x):
+        m = self.img
+        h = fp32_layer_norm(x, *m["n1"], eps=1e-5).to(x.dtype)               # FP32LayerNorm returns the input dtype (normalization.py:158-160)
+        h = m["f2"](F.gelu(m["f1"](h)))                                       # FeedForward(mult=1, activation_fn="gelu"): erf GELU
+        return fp32_layer_norm(h, *m["n2"], eps=1e-5).to(h.dtype)
 
     def __call__(self, timestep, encoder_hidden_states):
         ts = L.timestep_embedding(timestep, self.freq_dim)                       # fp32 [cos | sin]
@@ -237,7 +268,8 @@ class RadialMask:
 
 # ------------------------------------------------------------------ attention / block / core
 class WanAttention:
-    """transformer.py:393-534 without the I2V image branch."""
+    """transformer.py:393-534; with `added_kv_proj_dim` the cross-attention also attends the image-context tokens (the
+    first S_enc - 512 rows of the encoder states) through their own K/V projections and adds that result."""
 
     def __init__(self, sd, prefix, cfg: WanConfig, quant, cross: bool):
         self.heads, self.head_dim, self.cross, self.eps = cfg.num_attention_heads, cfg.attention_head_dim, cross, cfg.eps
@@ -250,8 +282,17 @@ class WanAttention:
         self.to_out = L.linear_from(sd, [f"{prefix}.to_out.0"], quant)
         self.norm_q, self.norm_k = sd[f"{prefix}.norm_q.weight"], sd[f"{prefix}.norm_k.weight"]
         self.scale = self.head_dim ** -0.5
+        self.add_k = self.add_v = None
+        if cross and cfg.added_kv_proj_dim is not None:
+            self.add_k = L.linear_from(sd, [f"{prefix}.add_k_proj"], quant)
+            self.add_v = L.linear_from(sd, [f"{prefix}.add_v_proj"], quant)
+            self.norm_added_k = sd[f"{prefix}.norm_added_k.weight"]
 
     def __call__(self, hidden, encoder=None, rope=None, block_mask=None):
+        enc_img = None
+        if self.add_k is not None:
+            n_img = encoder.shape[1] - TEXT_LEN_I2V
+            enc_img, encoder = encoder[:, :n_img], encoder[:, n_img:]
         if self.cross:
             q = self.to_q(hidden)
             kv = self.to_kv(encoder)
@@ -265,6 +306,10 @@ class WanAttention:
             ops.rotary_pos_embedding(q, k, self.head_dim, rope, is_neox=False)
         o = ops.scaled_dot_product_attention(q, k, v.contiguous(), self.heads, self.heads, self.head_dim, scale=self.scale,
                                              block_mask=block_mask)
+        if enc_img is not None:
+            k_img = ops.rms_norm(self.add_k(enc_img).contiguous(), self.norm_added_k, self.eps)
+            o = o + ops.scaled_dot_product_attention(q, k_img, self.add_v(enc_img).contiguous(), self.heads, self.heads, self.head_dim,
+                                                     scale=self.scale)
         return self.to_out(o)
 
 
@@ -316,7 +361,7 @@ class WanCore:
             self._mask = km.to(torch.int8)[None, None].expand(batch, self.cfg.num_attention_heads, -1, -1).contiguous()
         return self._mask
 
-    def forward(self, hidden_states, timestep, encoder_hidden_states, **_):
+    def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_image=None, **_):
         cfg = self.cfg
         B, C, Fr, H, W = hidden_states.shape
         pt, ph, pw = cfg.patch_size
@@ -326,6 +371,8 @@ class WanCore:
         x = x.flatten(2).transpose(1, 2)
         temb, tproj, enc = self.cond(timestep, encoder_hidden_states)
         tproj = tproj.unflatten(1, (6, -1))
+        if encoder_hidden_states_image is not None:                  # wan.py:333-334
+            enc = torch.concat([self.cond.image_embed(encoder_hidden_states_image), enc], dim=1)
         if getattr(self, "cache_fn", None) is not None:      # step cache hook (wan.py:339-349): f(core, hidden, encoder, temb6, rope)
             x = self.cache_fn(self, x, enc, tproj, rope)
         else:

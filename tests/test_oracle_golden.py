@@ -250,6 +250,23 @@ def test_wan_tiny_core_matches_reference(tag, qt):
         assert d.max() <= lim[0] and d.mean() <= lim[1], (tag, ti, d.max().item(), d.mean().item())
 
 
+@pytest.mark.parametrize("tag,qt", [("bf16", None), ("fp8", torch.float8_e4m3fn), ("int8", torch.int8)])
+def test_wan_i2v_tiny_core_matches_reference(tag, qt):
+    """Wan2.1-I2V branch (image embedder, image-context K/V in the cross-attentions, 36 input channels) against the reference."""
+    from oracle import wan as OW
+    g = load("tiny_wan_i2v.npz")
+    cfg = OW.TINY_I2V
+    sd = OW.synth_state_dict(cfg, seed=int(g["seed"]))
+    inp = OW.synth_inputs(cfg, int(g["batch"]), int(g["frames"]), int(g["height"]), int(g["width"]), OW.TEXT_LEN_I2V, seed=int(g["seed"]))
+    out = OW.WanCore(sd, cfg, qt).forward(inp["hidden_states"], torch.tensor([700.0, 700.0]), inp["encoder_hidden_states"],
+                                          inp["encoder_hidden_states_image"])[0]
+    ref = g[f"out_{tag}"]
+    assert out.shape == ref.shape == (2, 16, 3, 8, 8)
+    d = (out.float() - ref.float()).abs()
+    lim = {"bf16": (3e-2, 5e-3), "fp8": (1.4e-1, 1.8e-2), "int8": (5e-2, 8e-3)}[tag]
+    assert d.max() <= lim[0] and d.mean() <= lim[1], (tag, d.max().item(), d.mean().item())
+
+
 def test_wan_radial_masks_bit_exact():
     """The radial block-sparse mask generator (fastdm/sparse/xsparse.py:71-183) and the kernel-mask conversion
     (xsparse.py:227-250, non-sm90 branch -> 128 x 64 blocks) against masks produced by the reference on CPU."""

@@ -136,7 +136,8 @@ def tiny_core(quant, seed=21, sparse_attn=None, cfg=OW.TINY, cache=None):
     sd = OW.synth_state_dict(cfg, seed=seed)
     mc = dict(patch_size=cfg.patch_size, num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim,
               in_channels=cfg.in_channels, out_channels=cfg.out_channels, text_dim=cfg.text_dim, freq_dim=cfg.freq_dim, ffn_dim=cfg.ffn_dim,
-              num_layers=cfg.num_layers, eps=cfg.eps, rope_max_seq_len=cfg.rope_max_seq_len)
+              num_layers=cfg.num_layers, eps=cfg.eps, rope_max_seq_len=cfg.rope_max_seq_len, image_dim=cfg.image_dim,
+              added_kv_proj_dim=cfg.added_kv_proj_dim)
     return create_model("wan", ckpt_path=sd, dtype=BF16, quant_type=quant, kernel_backend="hip", model_config=mc, sparse_attn=sparse_attn,
                         cache=cache).eval()
 
@@ -238,3 +239,28 @@ def test_wan_fbcache_matches_reference_trace():
     bad = tiny_core(None, seed=21, cache=di)
     with pytest.raises(NotImplementedError, match="reference's own call is broken"):
         bad(hidden_states=inp["hidden_states"].cuda(), timestep=torch.tensor([500.0]).cuda(), encoder_hidden_states=enc, return_dict=False)
+
+
+@pytest.mark.parametrize("tag,qt", [("bf16", None), ("fp8", torch.float8_e4m3fn), ("int8", torch.int8)])
+def test_tiny_wan_i2v_against_reference_golden(tag, qt):
+    """Wan2.1-I2V wiring (wan.py:167-168,234-243,262-265,333-334; transformer.py:470-507,531-532): CLIP image tokens through the
+    image embedder, prepended to the 512 text tokens and attended through add_k_proj / add_v_proj in every cross-attention;
+    36 input channels.  Against the reference itself (tests/golden/tiny_wan_i2v.npz)."""
+    from oracle.make_golden import load
+    from fastdm_amd.synthetic import SyntheticWanStateDict
+    g = load("tiny_wan_i2v.npz")
+    cfg = OW.TINY_I2V
+    model = tiny_core(qt, seed=int(g["seed"]), cfg=cfg)
+    assert model.config.image_dim == cfg.image_dim and model.core_model.blocks[0].attn2.add_k_proj is not None
+    inp = OW.synth_inputs(cfg, int(g["batch"]), int(g["frames"]), int(g["height"]), int(g["width"]), OW.TEXT_LEN_I2V, seed=int(g["seed"]))
+    out = model(hidden_states=inp["hidden_states"].cuda(), timestep=torch.tensor([700.0, 700.0]).cuda(),
+                encoder_hidden_states=inp["encoder_hidden_states"].cuda(), encoder_hidden_states_image=inp["encoder_hidden_states_image"].cuda(),
+                return_dict=False)[0]
+    assert out.shape == (2, 16, 3, 8, 8)
+    # oracle-vs-reference on this fixture: bf16 0.020 / 0.0037, int8 0.031 / 0.0061, fp8 0.105 / 0.0141 on |out| ~ 0.86
+    lim = {"bf16": (4e-2, 6e-3), "fp8": (1.6e-1, 2.2e-2), "int8": (6e-2, 1e-2)}[tag]
+    close(out, g[f"out_{tag}"], lim[0], lim[1], f"tiny wan i2v {tag}")
+    # the lazily generated GPU state dict has the same inventory as the oracle's
+    sd = SyntheticWanStateDict(num_attention_heads=2, attention_head_dim=64, in_channels=36, text_dim=96, ffn_dim=256, num_layers=2, image_dim=48,
+                               added_kv_proj_dim=128, device="cpu")
+    assert {k: tuple(v[0]) for k, v in sd.spec.items()} == {n: tuple(s) for n, s, _ in OW.param_specs(cfg)}
