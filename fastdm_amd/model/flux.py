@@ -240,18 +240,28 @@ class FluxTransformer2DModelCore(BaseModelCore):
         return self._rope_val
 
     def run_blocks(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb, joint_attention_kwargs=None,
-                   controlnet_block_samples=None, controlnet_single_block_samples=None, start_block: int = 0, **_):
-        """Double blocks [start_block:], then all single blocks (start_block = 1: FBCache already ran block 0)."""
-        assert controlnet_block_samples is None and controlnet_single_block_samples is None, "ControlNet residuals are out of scope"
-        for block in self.transformer_blocks[start_block:]:
-            encoder_hidden_states, hidden_states = block.forward(hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states,
-                                                                 temb=temb, image_rotary_emb=image_rotary_emb,
-                                                                 joint_attention_kwargs=joint_attention_kwargs)
+                   controlnet_block_samples=None, controlnet_single_block_samples=None, start_block: int = 0,
+                   controlnet_blocks_repeat: bool = False, **_):
+        """Double blocks [start_block:], then all single blocks (start_block = 1: FBCache already ran block 0).  ControlNet
+        residuals (tensors produced by a ControlNet the caller ran) are added after each block as flux.py:454-480 does."""
+        import math
+        nd, ns = len(self.transformer_blocks), len(self.single_transformer_blocks)
+        for index_block in range(start_block, nd):
+            encoder_hidden_states, hidden_states = self.transformer_blocks[index_block].forward(
+                hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states, temb=temb, image_rotary_emb=image_rotary_emb,
+                joint_attention_kwargs=joint_attention_kwargs)
+            if controlnet_block_samples is not None:
+                n = len(controlnet_block_samples)
+                pick = index_block % n if controlnet_blocks_repeat else index_block // int(math.ceil(nd / n))
+                hidden_states = hidden_states + controlnet_block_samples[pick]
         n_txt = encoder_hidden_states.shape[1]
         hidden_states = torch.cat([encoder_hidden_states, hidden_states], dim=1)
-        for block in self.single_transformer_blocks:
+        for index_block, block in enumerate(self.single_transformer_blocks):
             hidden_states = block.forward(hidden_states=hidden_states, temb=temb, image_rotary_emb=image_rotary_emb,
                                           joint_attention_kwargs=joint_attention_kwargs)
+            if controlnet_single_block_samples is not None:
+                pick = index_block // int(math.ceil(ns / len(controlnet_single_block_samples)))
+                hidden_states[:, n_txt:, ...] = hidden_states[:, n_txt:, ...] + controlnet_single_block_samples[pick]
         return hidden_states[:, n_txt:, ...]
 
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None, pooled_projections: torch.Tensor = None,
@@ -279,6 +289,8 @@ class FluxTransformer2DModelCore(BaseModelCore):
             self.mod_table.begin_step(temb)
         try:
             if self.enable_caching:
+                if controlnet_block_samples is not None or controlnet_single_block_samples is not None:
+                    raise NotImplementedError("ControlNet residuals together with a step cache are not built")
                 hidden_states = self.cache.apply_cache(model_type="flux", hidden_states=hidden_states,
                                                        encoder_hidden_states=encoder_hidden_states, temb=temb,
                                                        image_rotary_emb=image_rotary_emb, attention_kwargs=joint_attention_kwargs,
@@ -286,7 +298,8 @@ class FluxTransformer2DModelCore(BaseModelCore):
                                                        single_transformer_blocks=self.single_transformer_blocks, core=self)
             else:
                 hidden_states = self.run_blocks(hidden_states, encoder_hidden_states, temb, image_rotary_emb, joint_attention_kwargs,
-                                                controlnet_block_samples, controlnet_single_block_samples)
+                                                controlnet_block_samples, controlnet_single_block_samples,
+                                                controlnet_blocks_repeat=controlnet_blocks_repeat)
             hidden_states = self.norm_out.forward(hidden_states.contiguous(), temb)
         finally:
             if self.mod_table is not None:

@@ -136,18 +136,23 @@ class SD3TransformerModelCore(BaseModelCore):
             layers += [blk.norm1, blk.norm1_context]
         self.mod_table = ModulationTable(layers)
 
-    def run_blocks(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb=None, joint_attention_kwargs=None, start_block: int = 0, **_):
-        """Blocks [start_block:] (the step caches run the first block(s) themselves)."""
-        for block in self.transformer_blocks[start_block:]:
+    def run_blocks(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb=None, joint_attention_kwargs=None, start_block: int = 0,
+                   block_controlnet_hidden_states=None, **_):
+        """Blocks [start_block:] (the step caches run the first block(s) themselves); ControlNet residuals are added after every
+        block but the context_pre_only one (sd35.py:401-404)."""
+        nb = len(self.transformer_blocks)
+        for index_block in range(start_block, nb):
+            block = self.transformer_blocks[index_block]
             encoder_hidden_states, hidden_states = block.forward(hidden_states=hidden_states, encoder_hidden_states=encoder_hidden_states,
                                                                  temb=temb, joint_attention_kwargs=joint_attention_kwargs)
+            if block_controlnet_hidden_states is not None and block.context_pre_only is False:
+                hidden_states = hidden_states + block_controlnet_hidden_states[index_block // (nb // len(block_controlnet_hidden_states))]
         return hidden_states
 
     # ------------------------------------------------------------------ forward (sd35.py:335-422)
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None, pooled_projections: torch.Tensor = None,
                 timestep: torch.Tensor = None, block_controlnet_hidden_states: List = None,
                 joint_attention_kwargs: Optional[Dict[str, Any]] = None, return_dict: bool = True):
-        assert block_controlnet_hidden_states is None, "ControlNet residuals are out of scope"
         dev = self.proj_out.weight.device
         hidden_states, encoder_hidden_states = hidden_states.to(dev), encoder_hidden_states.to(dev)
         pooled_projections, timestep = pooled_projections.to(dev), timestep.to(dev)
@@ -158,10 +163,12 @@ class SD3TransformerModelCore(BaseModelCore):
         self.mod_table.begin_step(temb)
         try:
             if self.enable_caching:       # sd35.py:384-392
+                if block_controlnet_hidden_states is not None:
+                    raise NotImplementedError("ControlNet residuals together with a step cache are not built")
                 x = self.cache.apply_cache(model_type="sd35", hidden_states=x, encoder_hidden_states=enc, temb=temb,
                                            attention_kwargs=joint_attention_kwargs, transformer_blocks=self.transformer_blocks, core=self)
             else:
-                x = self.run_blocks(x, enc, temb, None, joint_attention_kwargs)
+                x = self.run_blocks(x, enc, temb, None, joint_attention_kwargs, block_controlnet_hidden_states=block_controlnet_hidden_states)
         finally:
             self.mod_table.end_step()
         x = self.norm_out.forward(x.contiguous(), temb)

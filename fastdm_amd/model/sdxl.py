@@ -1,4 +1,4 @@
-"""SDXL UNet core (reference fastdm/model/sdxl.py:17-470; IP-adapter and ControlNet residual inputs are not built).
+"""SDXL UNet core (reference fastdm/model/sdxl.py:17-470; the IP-adapter branch is not built).
 
 Same constructor surface, diffusers key names and forward signature as the reference.  The reference hard-codes
 SDXL-base's widths inside the class (sdxl.py:53-113); here they are constructor arguments that default to SDXL-base, so
@@ -127,8 +127,8 @@ class SDXLUNetModelCore(BaseModelCore):
 
     # ------------------------------------------------------------------ forward (sdxl.py:375-470)
     def forward(self, sample, timesteps, encoder_hidden_states, added_cond_kwargs: Dict[str, Any], **kwargs):
-        if kwargs.get("mid_block_additional_residual") is not None or kwargs.get("down_block_additional_residuals") is not None:
-            raise NotImplementedError("ControlNet residual inputs are not built (DESIGN.md §8)")
+        mid_res, down_res = kwargs.get("mid_block_additional_residual"), kwargs.get("down_block_additional_residuals")
+        is_controlnet = mid_res is not None and down_res is not None            # sdxl.py:405
         timesteps = timesteps.expand(sample.shape[0])
         t_emb = self.time_proj.forward(timesteps).to(dtype=sample.dtype)
         emb = self.time_embedding.forward(t_emb)
@@ -145,7 +145,12 @@ class SDXLUNetModelCore(BaseModelCore):
         sample, (s1, s2, s3) = self.down_blocks[0].forward(sample, temb=emb)
         sample, (s4, s5, s6) = self.down_blocks[1].forward(sample, temb=emb, encoder_hidden_states=enc)
         sample, (s7, s8) = self.down_blocks[2].forward(sample, temb=emb, encoder_hidden_states=enc)
+        if is_controlnet:               # residuals of a ControlNet the caller ran, added to the nine skip tensors (sdxl.py:427-432)
+            s0, s1, s2, s3, s4, s5, s6, s7, s8 = (s + r for s, r in zip((s0, s1, s2, s3, s4, s5, s6, s7, s8), down_res))
+            sample = s8     # upstream adds in place and `sample` IS s8 (the last down block has no downsampler): the mid block sees it
         sample = self.mid_block.forward(sample, emb, encoder_hidden_states=enc)
+        if is_controlnet:
+            sample = sample + mid_res
         sample = self.up_blocks[0].forward(hidden_states=sample, temb=emb, res_hidden_states_tuple=[s6, s7, s8], encoder_hidden_states=enc)
         sample = self.up_blocks[1].forward(hidden_states=sample, temb=emb, res_hidden_states_tuple=[s3, s4, s5], encoder_hidden_states=enc)
         sample = self.up_blocks[2].forward(hidden_states=sample, temb=emb, res_hidden_states_tuple=[s0, s1, s2])

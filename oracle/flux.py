@@ -201,23 +201,31 @@ class FluxCore:
         rope = L.flux_rope_cache(txt_ids, img_ids, self.cfg.axes_dims_rope, hidden.dtype)
         return hidden, encoder, temb, rope
 
-    def run_blocks(self, hidden, encoder, temb, rope):
-        """flux.py:445-485."""
-        for blk in self.transformer_blocks:
+    def run_blocks(self, hidden, encoder, temb, rope, cn_double=None, cn_single=None, cn_repeat=False):
+        """flux.py:445-485, with the ControlNet residual inputs (flux.py:454-480)."""
+        import math
+        nd, ns = len(self.transformer_blocks), len(self.single_transformer_blocks)
+        for i, blk in enumerate(self.transformer_blocks):
             encoder, hidden = blk(hidden, encoder, temb, rope)
+            if cn_double is not None:
+                hidden = hidden + cn_double[i % len(cn_double) if cn_repeat else i // int(math.ceil(nd / len(cn_double)))]
         n_txt = encoder.shape[1]
         x = torch.cat([encoder, hidden], dim=1)
-        for blk in self.single_transformer_blocks:
+        for i, blk in enumerate(self.single_transformer_blocks):
             x = blk(x, temb, rope)
+            if cn_single is not None:
+                x[:, n_txt:] = x[:, n_txt:] + cn_single[i // int(math.ceil(ns / len(cn_single)))]
         return x[:, n_txt:]
 
     def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None,
-                img_ids=None, txt_ids=None, guidance=None, **_):
+                img_ids=None, txt_ids=None, guidance=None, controlnet_block_samples=None, controlnet_single_block_samples=None,
+                controlnet_blocks_repeat=False, **_):
         hidden, encoder, temb, rope = self.embed(hidden_states, encoder_hidden_states, pooled_projections,
                                                  timestep, img_ids, txt_ids, guidance)
         if self.cache is not None and self.cache.config.enable_caching:
             hidden = self.cache.apply_cache(self, hidden, encoder, temb, rope)
         else:
-            hidden = self.run_blocks(hidden, encoder, temb, rope)
+            hidden = self.run_blocks(hidden, encoder, temb, rope, controlnet_block_samples, controlnet_single_block_samples,
+                                     controlnet_blocks_repeat)
         hidden = self.norm_out(hidden, temb)
         return (self.proj_out(hidden),)

@@ -495,6 +495,53 @@ def gen_tiny_wan_i2v():
     save("tiny_wan_i2v.npz", d)
 
 
+def controlnet_residuals(tag, shapes, seed=0, scale=0.25):
+    """Stand-ins for the tensors a ControlNet would hand over: N(0, scale^2) from the shared counter-based generator."""
+    from oracle import synth
+    from oracle.flux import bf16_from_bits
+    out = []
+    for i, shp in enumerate(shapes):
+        bits = synth.normal_bf16_bits(synth.key_seed(f"controlnet.{tag}.{i}", seed), int(np.prod(shp)), scale, 0.0)
+        out.append(bf16_from_bits(bits, shp))
+    return out
+
+
+def gen_controlnet_residual_inputs():
+    """The cores' ControlNet residual INPUTS (flux.py:454-480, sd35.py:401-404, sdxl.py:405-440) through the reference: FLUX with
+    one residual per double block and one for both single blocks, in both index modes; SD3.5 with one residual shared by the
+    first two blocks; the SDXL UNet with nine down residuals + the mid residual."""
+    import_reference()
+    use_backend("torch")
+    from oracle import flux as OF, sd35 as OS, sdxl as OX
+    d = {}
+    cfg = OF.TINY
+    core = ref_flux_core(cfg, None, OF.synth_state_dict(cfg, seed=7))
+    inp = OF.synth_inputs(cfg, batch=1, img_h=4, img_w=6, n_txt=8, seed=9)
+    D = cfg.attention_head_dim * cfg.num_attention_heads
+    dbl = controlnet_residuals("flux.double", [(1, 24, D)] * 2)
+    sgl = controlnet_residuals("flux.single", [(1, 24, D)])
+    for tag, rep in (("flux", False), ("flux_repeat", True)):
+        d[tag] = core.forward(hidden_states=inp["hidden_states"], encoder_hidden_states=inp["encoder_hidden_states"],
+                              pooled_projections=inp["pooled_projections"], timestep=torch.tensor([0.5]), img_ids=inp["img_ids"],
+                              txt_ids=inp["txt_ids"], guidance=torch.tensor([3.5]), controlnet_block_samples=[t.clone() for t in dbl[:1 if not rep else 2]],
+                              controlnet_single_block_samples=[t.clone() for t in sgl], controlnet_blocks_repeat=rep)[0]
+    c3 = OS.TINY
+    core3 = ref_sd3_core(c3, None, OS.synth_state_dict(c3, seed=31))
+    i3 = OS.synth_inputs(c3, batch=2, height=8, width=12, n_txt=9, seed=31)
+    d["sd3"] = core3.forward(timestep=torch.tensor([500.0, 500.0]), return_dict=False,
+                             block_controlnet_hidden_states=controlnet_residuals("sd3", [(2, 24, c3.inner_dim)]), **i3)[0]
+    cx = OX.TINY
+    corex = ref_sdxl_core(cx, None, OX.synth_state_dict(cx, seed=41))
+    ix = OX.synth_inputs(cx, batch=2, height=16, width=24, n_txt=11, seed=41)
+    c0, c1, c2 = cx.block_out_channels
+    down_shapes = [(2, c0, 16, 24)] * 3 + [(2, c0, 8, 12)] + [(2, c1, 8, 12)] * 2 + [(2, c1, 4, 6)] + [(2, c2, 4, 6)] * 2
+    down = controlnet_residuals("sdxl.down", down_shapes)
+    mid = controlnet_residuals("sdxl.mid", [(2, c2, 4, 6)])[0]
+    d["sdxl"] = corex.forward(ix["sample"], torch.tensor(500.0), ix["encoder_hidden_states"], ix["added_cond_kwargs"],
+                              down_block_additional_residuals=[t.clone() for t in down], mid_block_additional_residual=mid.clone())[0]
+    save("controlnet_residual_inputs.npz", d)
+
+
 def gen_fbcache():
     """FBCache decisions + final latents on the tiny FLUX core (bf16) and the tiny Qwen-Image core (int8) over 12-step
     trajectories, driven through the reference's AutoCache exactly like gen_teacache."""
@@ -936,7 +983,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "wan_i2v", "sd3_wan_cache", "sdxl", "sdxl_full", "c3"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "wan_i2v", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     args = ap.parse_args()
@@ -959,6 +1006,8 @@ def main():
         gen_dicache()
     if args.what in ("small", "sd3"):
         gen_tiny_sd3()
+    if args.what in ("small", "controlnet"):
+        gen_controlnet_residual_inputs()
     if args.what in ("small", "wan_i2v"):
         gen_tiny_wan_i2v()
     if args.what in ("small", "sd3_wan_cache"):

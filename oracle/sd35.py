@@ -227,7 +227,8 @@ class SD3Core:
         pe = self.pos.reshape(1, m, m, -1)[:, top: top + h, left: left + w, :].reshape(1, h * w, -1)
         return (x + pe).to(x.dtype)
 
-    def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, **_):
+    def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None,
+                block_controlnet_hidden_states=None, **_):
         cfg = self.cfg
         height, width = hidden_states.shape[-2:]
         x = self.patch_embed(hidden_states)
@@ -237,8 +238,11 @@ class SD3Core:
         if self.cache_fn is not None:
             x = self.cache_fn(self, x, enc, temb)
         else:
-            for blk in self.blocks:
+            cn = block_controlnet_hidden_states
+            for i, blk in enumerate(self.blocks):
                 enc, x = blk(x, enc, temb)
+                if cn is not None and not blk.last:                    # sd35.py:401-404
+                    x = x + cn[i // (len(self.blocks) // len(cn))]
         emb = self.norm_out(F.silu(temb).to(x.dtype))
         scale, shift = emb.chunk(2, dim=1)
         x = L.layer_norm_noaffine(x, 1e-6) * (1 + scale)[:, None, :] + shift[:, None, :]

@@ -266,7 +266,8 @@ class SDXLCore:
             dict(res=[R(f"up_blocks.2.resnets.{i}", True) for i in range(3)], attn=None, us=None),
         ]
 
-    def forward(self, sample, timesteps, encoder_hidden_states, added_cond_kwargs):
+    def forward(self, sample, timesteps, encoder_hidden_states, added_cond_kwargs, mid_block_additional_residual=None,
+                down_block_additional_residuals=None):
         sd, cfg = self.sd, self.cfg
         timesteps = timesteps.expand(sample.shape[0])
         t_emb = L.timestep_embedding(timesteps, cfg.time_proj_dim).to(sample.dtype)                      # sdxl.py:382-383
@@ -286,9 +287,14 @@ class SDXLCore:
             if blk["ds"] is not None:
                 x = F.conv2d(x, sd[blk["ds"] + ".weight"], sd[blk["ds"] + ".bias"], 2, 1)
                 skips.append(x)
+        if mid_block_additional_residual is not None and down_block_additional_residuals is not None:    # sdxl.py:405,427-432
+            skips = [sk + r for sk, r in zip(skips, down_block_additional_residuals)]
+            x = skips[-1]           # upstream adds IN PLACE and the running sample is the last skip tensor (no downsampler on level 3)
         x = self.mid_res[0](x, emb)                                                                       # unetblock.py:504-516
         x = self.mid_attn(x, encoder_hidden_states)
         x = self.mid_res[1](x, emb)
+        if mid_block_additional_residual is not None and down_block_additional_residuals is not None:    # sdxl.py:439-440
+            x = x + mid_block_additional_residual
         for blk in self.up:                                                                               # unetblock.py:462-494
             for i, r in enumerate(blk["res"]):
                 x = r(torch.cat([x, skips.pop()], dim=1), emb)

@@ -483,3 +483,44 @@ def test_step_caches_sd3_and_wan_traces():
     assert [int(t[-1]) for t in cache.trace] == g["wan_fbcache_should_calc"].tolist(), cache.trace
     d = (lat.float() - g["wan_fbcache_final"].float()).abs()
     assert d.max() <= 1e-1 and d.mean() <= 1.5e-2, (d.max().item(), d.mean().item())
+
+
+def test_controlnet_residual_inputs_flux_sd3_sdxl(monkeypatch):
+    """The residual INPUTS a ControlNet hands to the cores (flux.py:454-480 incl. the `controlnet_blocks_repeat` index mode,
+    sd35.py:401-404, sdxl.py:405-440 with upstream's in-place add that also feeds the mid block) against the reference."""
+    from oracle import sd35 as OS, sdxl as OX
+    from oracle import ops as OPS
+    from oracle.make_golden import controlnet_residuals as cn
+    g = load("controlnet_residual_inputs.npz")
+    cfg = OF.TINY
+    core = OF.FluxCore(OF.synth_state_dict(cfg, seed=7), cfg, None)
+    inp = OF.synth_inputs(cfg, 1, 4, 6, 8, seed=9)
+    D = cfg.attention_head_dim * cfg.num_attention_heads
+    dbl, sgl = cn("flux.double", [(1, 24, D)] * 2), cn("flux.single", [(1, 24, D)])
+    plain = core.forward(timestep=torch.tensor([0.5]), guidance=torch.tensor([3.5]), **inp)[0]
+    for tag, rep in (("flux", False), ("flux_repeat", True)):
+        out = core.forward(timestep=torch.tensor([0.5]), guidance=torch.tensor([3.5]), controlnet_block_samples=dbl[:2 if rep else 1],
+                           controlnet_single_block_samples=sgl, controlnet_blocks_repeat=rep, **inp)[0]
+        d = (out.float() - g[tag].float()).abs()
+        assert d.max() <= 5e-2 and d.mean() <= 6e-3, (tag, d.max().item(), d.mean().item())
+        assert (out.float() - plain.float()).abs().mean() > 5e-2          # the residuals matter
+    c3 = OS.TINY
+    core3 = OS.SD3Core(OS.synth_state_dict(c3, seed=31), c3, None)
+    i3 = OS.synth_inputs(c3, 2, 8, 12, 9, seed=31)
+    out = core3.forward(timestep=torch.tensor([500.0, 500.0]), block_controlnet_hidden_states=cn("sd3", [(2, 24, c3.inner_dim)]), **i3)[0]
+    d = (out.float() - g["sd3"].float()).abs()
+    assert d.max() <= 5e-2 and d.mean() <= 6e-3, (d.max().item(), d.mean().item())
+
+    def torch_sdpa(query, key, value, hq, hk, hd, is_causal=False, scale=None, **_):
+        b, s, c = query.shape
+        q, k, v = (x.view(b, x.size(1), h, hd).transpose(1, 2) for x, h in ((query, hq), (key, hk), (value, hk)))
+        return F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=is_causal, scale=scale).transpose(1, 2).contiguous().view(b, s, c)
+    monkeypatch.setattr(OPS, "scaled_dot_product_attention", torch_sdpa)       # bit-exact mode (see test_sdxl_tiny_unet_matches_reference)
+    cx = OX.TINY
+    corex = OX.SDXLCore(OX.synth_state_dict(cx, seed=41), cx, None)
+    ix = OX.synth_inputs(cx, 2, 16, 24, 11, seed=41)
+    c0, c1, c2 = cx.block_out_channels
+    shapes = [(2, c0, 16, 24)] * 3 + [(2, c0, 8, 12)] + [(2, c1, 8, 12)] * 2 + [(2, c1, 4, 6)] + [(2, c2, 4, 6)] * 2
+    out = corex.forward(ix["sample"], torch.tensor(500.0), ix["encoder_hidden_states"], ix["added_cond_kwargs"],
+                        down_block_additional_residuals=cn("sdxl.down", shapes), mid_block_additional_residual=cn("sdxl.mid", [(2, c2, 4, 6)])[0])[0]
+    assert torch.equal(out, g["sdxl"])

@@ -84,8 +84,6 @@ def test_sdxl_blocks_keep_reference_signatures_and_errors():
         SDXLUNetModelCore(is_ip_adapter=True)
     model = tiny_model(None, 41)
     core = model.core_model
-    with pytest.raises(NotImplementedError):
-        core.forward(None, None, None, {}, mid_block_additional_residual=torch.zeros(1), down_block_additional_residuals=[torch.zeros(1)])
     # block-level forwards with the reference's argument lists: [B*S, C] tokens in and out
     blk = core.down_blocks[1].attentions[0].transformer_blocks[0]
     assert isinstance(blk, BasicTransformerBlock) and isinstance(blk.ff, FeedForward_SDXL)
@@ -152,3 +150,51 @@ def test_engine_sdxl_and_sd35_synthetic_pipelines(tmp_path):
     assert lat.shape == (1, 16, 8, 12) and torch.isfinite(lat.float()).all()
     calc = [t[3] for t in eng.cache.trace]
     assert len(calc) == 6 and calc[0] and not all(calc), calc        # TeaCache driven by the pipeline's step index skipped something
+
+
+def test_controlnet_residual_inputs_on_the_hip_path():
+    """FLUX (both index modes), SD3.5 and the SDXL UNet accept the residual tensors of a ControlNet the caller ran
+    (flux.py:454-480, sd35.py:401-404, sdxl.py:405-440); outputs against the reference (tests/golden/controlnet_residual_inputs.npz)."""
+    from fastdm_amd.model_entry import create_model
+    from oracle import flux as OF, sd35 as OS
+    from oracle.make_golden import controlnet_residuals as cn
+    g = load("controlnet_residual_inputs.npz")
+    cu = lambda ts: [t.cuda() for t in ts]
+
+    def close(got, ref, mx, mean, what):
+        d = (got.float().cpu() - ref.float()).abs()
+        assert d.max() <= mx and d.mean() <= mean, (what, d.max().item(), d.mean().item())
+
+    cfg = OF.TINY
+    flux = create_model("flux", ckpt_path=OF.synth_state_dict(cfg, seed=7), dtype=BF16, quant_type=None, kernel_backend="hip",
+                        in_channels=cfg.in_channels, out_channels=cfg.out_channels, num_layers=cfg.num_layers,
+                        num_single_layers=cfg.num_single_layers, attention_head_dim=cfg.attention_head_dim,
+                        num_attention_heads=cfg.num_attention_heads, joint_attention_dim=cfg.joint_attention_dim,
+                        pooled_projection_dim=cfg.pooled_projection_dim, axes_dims_rope=cfg.axes_dims_rope).eval()
+    inp = {k: v.cuda() for k, v in OF.synth_inputs(cfg, 1, 4, 6, 8, seed=9).items()}
+    D = cfg.attention_head_dim * cfg.num_attention_heads
+    dbl, sgl = cn("flux.double", [(1, 24, D)] * 2), cn("flux.single", [(1, 24, D)])
+    for tag, rep in (("flux", False), ("flux_repeat", True)):
+        out = flux(timestep=torch.tensor([0.5]).cuda(), guidance=torch.tensor([3.5]).cuda(), return_dict=False,
+                   controlnet_block_samples=cu(dbl[:2 if rep else 1]), controlnet_single_block_samples=cu(sgl), controlnet_blocks_repeat=rep,
+                   **inp)[0]
+        close(out, g[tag], 6e-2, 8e-3, tag)
+    c3 = OS.TINY
+    sd3 = create_model("sd35", ckpt_path=OS.synth_state_dict(c3, seed=31), dtype=BF16, quant_type=None, kernel_backend="hip",
+                       sample_size=c3.sample_size, patch_size=c3.patch_size, in_channels=c3.in_channels, out_channels=c3.out_channels,
+                       num_layers=c3.num_layers, attention_head_dim=c3.attention_head_dim, num_attention_heads=c3.num_attention_heads,
+                       joint_attention_dim=c3.joint_attention_dim, caption_projection_dim=c3.caption_projection_dim,
+                       pooled_projection_dim=c3.pooled_projection_dim, pos_embed_max_size=c3.pos_embed_max_size,
+                       dual_attention_layers=c3.dual_attention_layers).eval()
+    i3 = {k: v.cuda() for k, v in OS.synth_inputs(c3, 2, 8, 12, 9, seed=31).items()}
+    out = sd3(timestep=torch.tensor([500.0, 500.0]).cuda(), return_dict=False,
+              block_controlnet_hidden_states=cu(cn("sd3", [(2, 24, c3.inner_dim)])), **i3)[0]
+    close(out, g["sd3"], 6e-2, 8e-3, "sd3")
+    cx = OX.TINY
+    unet = tiny_model(None, 41)
+    ix = to_cuda(OX.synth_inputs(cx, 2, 16, 24, 11, seed=41))
+    c0, c1, c2 = cx.block_out_channels
+    shapes = [(2, c0, 16, 24)] * 3 + [(2, c0, 8, 12)] + [(2, c1, 8, 12)] * 2 + [(2, c1, 4, 6)] + [(2, c2, 4, 6)] * 2
+    out = unet(ix["sample"], torch.tensor(500.0).cuda(), ix["encoder_hidden_states"], ix["added_cond_kwargs"],
+               down_block_additional_residuals=cu(cn("sdxl.down", shapes)), mid_block_additional_residual=cn("sdxl.mid", [(2, c2, 4, 6)])[0].cuda())[0]
+    close(out, g["sdxl"], 1e-1, 1.6e-2, "sdxl")
