@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--max-seq-len", type=int, default=None, help="text tokens: default 512 (flux) / 128 (qwen)")
     ap.add_argument("--quant", choices=["fp8", "int8", "bf16"], default=None, help="default fp8 (flux) / int8 (qwen)")
     ap.add_argument("--cache-config", default=None, help="TeaCache JSON (changes the metric: reported as a different workload)")
+    ap.add_argument("--batch-cfg", action="store_true", help="qwen: conditional + unconditional prompt as one batch-2 forward per step")
     ap.add_argument("--graph", action="store_true", help="sdxl: replay the UNet forward from a HIP graph (the step is launch-bound: ~2000 small kernels)")
     ap.add_argument("--nhwc", action="store_true", help="sdxl: keep convolution activations channels-last instead of NCHW")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -136,7 +137,7 @@ def main():
     elif args.model == "qwen":
         model = create_model("qwen", ckpt_path=SyntheticQwenStateDict(seed=0), dtype=torch.bfloat16, quant_type=quant,
                              kernel_backend="hip", cache=cache, out_channels=16).eval()
-        pipe = SyntheticQwenPipeline(model, seed=0)
+        pipe = SyntheticQwenPipeline(model, seed=0, batch_cfg=args.batch_cfg)
     elif args.model == "sd35":
         from fastdm_amd.synthetic import SyntheticSD3StateDict, sd3_step_inputs
         arch = dict(num_layers=38, num_attention_heads=38, attention_head_dim=64, caption_projection_dim=2432, pos_embed_max_size=192,
@@ -288,7 +289,7 @@ def main():
     else:
         nfw = 2 * args.steps
         workload = (f"Qwen-Image {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step schedule, true CFG "
-                    f"(2 forwards per step), batch 1 per GPU, 60 double-stream blocks"
+                    f"({'one batch-2 forward' if args.batch_cfg else '2 forwards'} per step), batch 1 per GPU, 60 double-stream blocks"
                     + (f", TeaCache ({skipped}/{nfw} forwards skipped)" if cache else ""))
     out = {
         "metric": {"flux": "denoise it/s (sec/image = 25 / (value / n_gpus)), FLUX 1024x2048 fp8 @25 steps",

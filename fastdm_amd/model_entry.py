@@ -305,12 +305,15 @@ class FastDMEngine:
         elif architecture == "qwen":
             from fastdm_amd.pipeline import SyntheticQwenPipeline
             from fastdm_amd.synthetic import SyntheticQwenStateDict
+            batch_cfg = bool(model_kwargs.pop("batch_cfg", False))      # cond + uncond as one batch-2 forward (pipeline.py)
+            if batch_cfg and self.cache is not None:
+                raise ValueError("batch_cfg runs both prompts in one forward; the step caches key on the cond / uncond alternation")
             keys = ("patch_size", "num_layers", "attention_head_dim", "num_attention_heads", "joint_attention_dim", "in_channels", "out_channels")
             sd = SyntheticQwenStateDict(seed=synthetic_seed, **{k: v for k, v in model_kwargs.items() if k in keys})
             model_kwargs.setdefault("out_channels", 16)      # the checkpoint's value (proj_out = patch^2 * 16 = 64 = in_channels)
             transformer = create_model("qwen", ckpt_path=sd, dtype=self.dtype, quant_type=self.quant_type, kernel_backend=kernel_backend,
                                        cache=self.cache, **model_kwargs).eval()
-            self.pipe = SyntheticQwenPipeline(transformer, seed=synthetic_seed)
+            self.pipe = SyntheticQwenPipeline(transformer, seed=synthetic_seed, batch_cfg=batch_cfg)
             if self.cache:
                 self.cache.config.current_steps_callback = lambda: self.pipe.scheduler_step_index
                 self.cache.config.total_steps_callback = lambda: self.pipe.num_steps

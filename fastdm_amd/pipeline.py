@@ -79,9 +79,13 @@ class SyntheticQwenPipeline:
     to the conditional prediction's per-token norm, then the flow-match Euler update.  Latents are packed
     [B, (H/16)*(W/16), 64]; `timestep = sigma`; prompt / negative-prompt embeddings are synthetic."""
 
-    def __init__(self, transformer, seed: int = 0):
+    def __init__(self, transformer, seed: int = 0, batch_cfg: bool = False):
+        """batch_cfg: run the conditional and the unconditional prompt as ONE batch-2 forward (same bits as two forwards: all
+        quantisation is per token) when both prompts have the same length and no step cache keys on the cond / uncond
+        alternation; the N = 3072 GEMMs then fill 2.6 instead of 1.3 rounds of the chip."""
         self.transformer = transformer
         self.seed = seed
+        self.batch_cfg = batch_cfg
         self.scheduler_step_index = None
         self.num_steps = 0
         self._inputs_key, self._inputs = None, None
@@ -107,9 +111,19 @@ class SyntheticQwenPipeline:
     @torch.no_grad()
     def step(self, latents, inp, sigma, sigma_next, true_cfg_scale):
         t = torch.full((latents.shape[0],), float(sigma), device=latents.device, dtype=latents.dtype)
-        cond = self._forward("cond", latents, t, inp["encoder_hidden_states"], inp)
-        if true_cfg_scale is not None and true_cfg_scale > 1:
-            uncond = self._forward("uncond", latents, t, inp["negative_encoder_hidden_states"], inp)
+        use_cfg = true_cfg_scale is not None and true_cfg_scale > 1
+        if use_cfg and self.batch_cfg:
+            b = latents.shape[0]
+            both = dict(inp, encoder_hidden_states_mask=torch.cat([inp["encoder_hidden_states_mask"]] * 2, dim=0),
+                        img_shapes=list(inp["img_shapes"]) * 2, txt_seq_lens=list(inp["txt_seq_lens"]) * 2)
+            out = self._forward("cond", torch.cat([latents, latents], dim=0), torch.cat([t, t], dim=0),
+                                torch.cat([inp["encoder_hidden_states"], inp["negative_encoder_hidden_states"]], dim=0), both)
+            cond, uncond = out[:b], out[b:]
+        else:
+            cond = self._forward("cond", latents, t, inp["encoder_hidden_states"], inp)
+        if use_cfg:
+            if not self.batch_cfg:
+                uncond = self._forward("uncond", latents, t, inp["negative_encoder_hidden_states"], inp)
             comb = uncond.float() + true_cfg_scale * (cond.float() - uncond.float())
             cond_norm = torch.norm(cond.float(), dim=-1, keepdim=True)
             comb = comb * (cond_norm / torch.norm(comb, dim=-1, keepdim=True))
