@@ -436,6 +436,31 @@ def ref_wan_core(cfg, quant, sd, cache=None):
     return core
 
 
+def gen_wan_full(n_blocks=2, frames=5, height=32, width=48, n_txt=512, seed=0):
+    """Wan2.2-T2V-A14B at FULL WIDTH (D = 5120, 40 x 128 heads, ffn 13824, text 4096 -> 512 tokens) through the reference's own
+    core at reduced depth, fp8 W8A8 (BASELINE.json configs[4]) and bf16, on a small video (5 latent frames of 32 x 48 -> 1920 tokens)."""
+    import_reference()
+    from oracle import wan as OW
+    cfg = OW.WanConfig(num_layers=n_blocks)
+    t0 = time.time()
+    sd = OW.synth_state_dict(cfg, seed=seed)
+    print(f"synthetic weights: {sum(v.numel() for v in sd.values()) / 1e6:.0f} M parameters in {time.time() - t0:.0f}s", flush=True)
+    inp = OW.synth_inputs(cfg, batch=1, frames=frames, height=height, width=width, n_txt=n_txt, seed=seed)
+    d = {"seed": seed, "n_blocks": n_blocks, "frames": frames, "height": height, "width": width, "n_txt": n_txt, "timestep": 700.0}
+    for tag, qt in (("fp8", torch.float8_e4m3fn), ("bf16", None)):
+        use_backend("cpu_fp8" if tag == "fp8" else "torch")
+        core = ref_wan_core(cfg, qt, sd)
+        t0 = time.time()
+        out = core.forward(hidden_states=inp["hidden_states"], timestep=torch.tensor([700.0]), encoder_hidden_states=inp["encoder_hidden_states"],
+                           return_dict=False)
+        out = out[0] if isinstance(out, (tuple, list)) else out
+        print(f"{tag}: forward {time.time() - t0:.0f}s, mean|out| {out.float().abs().mean():.3f}", flush=True)
+        d[f"out_{tag}"] = out
+        del core
+    use_backend("torch")
+    save(f"wan_full_{n_blocks}blocks.npz", d)
+
+
 def gen_tiny_wan():
     """Tiny Wan core (2 blocks, 2 x 64 heads) through the reference in bf16 / fp8 (dense attention: the reference has no
     CPU sparse kernel), plus radial block-sparse masks from the reference's generator on three geometries."""
@@ -983,7 +1008,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "wan_i2v", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     args = ap.parse_args()
@@ -1018,6 +1043,8 @@ def main():
         gen_sdxl_full(args.quant)
     if args.what == "qwen_full":
         gen_qwen_full()
+    if args.what == "wan_full":
+        gen_wan_full()
     if args.what == "c3":
         gen_c3(args.blocks[0], args.blocks[1], args.quant)
 

@@ -264,3 +264,27 @@ def test_tiny_wan_i2v_against_reference_golden(tag, qt):
     sd = SyntheticWanStateDict(num_attention_heads=2, attention_head_dim=64, in_channels=36, text_dim=96, ffn_dim=256, num_layers=2, image_dim=48,
                                added_kv_proj_dim=128, device="cpu")
     assert {k: tuple(v[0]) for k, v in sd.spec.items()} == {n: tuple(s) for n, s, _ in OW.param_specs(cfg)}
+
+
+@pytest.mark.parametrize("tag,qt", [("fp8", torch.float8_e4m3fn), ("bf16", None)])
+def test_full_width_wan_against_reference_core(tag, qt):
+    """Wan2.2-T2V-A14B at full width (D = 5120, 40 x 128 heads, ffn 13824, 512 x 4096 text), two blocks, through the reference's
+    own core (tests/golden/wan_full_2blocks.npz); the 0.94 B synthetic parameters are regenerated bit-identically on the GPU."""
+    from oracle.make_golden import load
+    from fastdm_amd.model_entry import create_model
+    from fastdm_amd.synthetic import SyntheticWanStateDict, wan_step_inputs
+    g = load("wan_full_2blocks.npz")
+    seed, nb = int(g["seed"]), int(g["n_blocks"])
+    model = create_model("wan", ckpt_path=SyntheticWanStateDict(seed=seed, num_layers=nb), dtype=BF16, quant_type=qt, kernel_backend="hip",
+                         model_config={"num_layers": nb}).eval()
+    inp = wan_step_inputs(1, int(g["frames"]), int(g["height"]), int(g["width"]), int(g["n_txt"]), seed=seed)
+    want = OW.synth_inputs(OW.WanConfig(num_layers=nb), 1, int(g["frames"]), int(g["height"]), int(g["width"]), int(g["n_txt"]), seed=seed)
+    assert torch.equal(inp["hidden_states"].cpu(), want["hidden_states"]) and torch.equal(inp["encoder_hidden_states"].cpu(), want["encoder_hidden_states"])
+    out = model(hidden_states=inp["hidden_states"], timestep=torch.tensor([float(g["timestep"])]).cuda(),
+                encoder_hidden_states=inp["encoder_hidden_states"], return_dict=False)[0]
+    ref = g[f"out_{tag}"]
+    assert out.shape == ref.shape
+    d = (out.float().cpu() - ref.float()).abs()
+    print(f"Wan full width {tag}: max|d| {d.max().item():.4f} mean|d| {d.mean().item():.5f} on mean|ref| {ref.float().abs().mean().item():.3f}")
+    lim = {"bf16": (6e-2, 6e-3), "fp8": (2.5e-1, 3e-2)}[tag]
+    assert torch.isfinite(out.float()).all() and d.max() <= lim[0] and d.mean() <= lim[1], (tag, d.max().item(), d.mean().item())
