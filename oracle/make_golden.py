@@ -859,6 +859,28 @@ def gen_sdxl_full(quants=("fp8", "bf16")):
     save("sdxl_full.npz", d)
 
 
+def gen_sd3_full(seed=0):
+    """SD3.5-large WIDTH (38 x 64 heads, D = 2432, text 4096, pooled 2048) at three blocks -- a dual-attention block (as SD3.5-medium
+    has), a plain one and the context_pre_only last one -- through the reference's own core, fp8 and bf16, 512 x 512 (1024 image +
+    154 text tokens), CFG batch 2."""
+    import_reference()
+    from oracle import sd35 as OS
+    cfg = OS.SD3Config(sample_size=128, num_layers=3, attention_head_dim=64, num_attention_heads=38, caption_projection_dim=2432,
+                       pos_embed_max_size=192, dual_attention_layers=(0,))
+    sd = OS.synth_state_dict(cfg, seed=seed)
+    print(f"synthetic weights: {sum(v.numel() for v in sd.values()) / 1e6:.0f} M parameters", flush=True)
+    inp = OS.synth_inputs(cfg, batch=2, height=64, width=64, n_txt=154, seed=seed)
+    d = {"seed": seed, "batch": 2, "height": 64, "width": 64, "n_txt": 154}
+    for tag, qt in (("fp8", torch.float8_e4m3fn), ("bf16", None)):
+        use_backend("cpu_fp8" if tag == "fp8" else "torch")
+        core = ref_sd3_core(cfg, qt, sd)
+        out = core.forward(timestep=torch.tensor([600.0, 600.0]), return_dict=False, **inp)
+        d[f"out_{tag}"] = out[0] if isinstance(out, (tuple, list)) else out
+        print(tag, "mean|out|", d[f"out_{tag}"].float().abs().mean().item(), flush=True)
+    use_backend("torch")
+    save("sd3_full_3blocks.npz", d)
+
+
 def gen_dicache():
     """DiCache (probe depth 1, delta_y) decisions + final latents on the tiny FLUX (bf16) and Qwen-Image (int8) cores over
     12-step trajectories through the reference's AutoCache."""
@@ -1008,7 +1030,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     args = ap.parse_args()
@@ -1045,6 +1067,8 @@ def main():
         gen_qwen_full()
     if args.what == "wan_full":
         gen_wan_full()
+    if args.what == "sd3_full":
+        gen_sd3_full()
     if args.what == "c3":
         gen_c3(args.blocks[0], args.blocks[1], args.quant)
 

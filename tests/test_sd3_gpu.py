@@ -82,3 +82,26 @@ def test_sd3_step_caches_match_reference_traces(name):
     assert [int(t[3]) for t in cache.trace] == g[f"{name}_should_calc"].tolist(), cache.trace
     d = (lat.float().cpu() - g[f"{name}_final"].float()).abs()
     assert d.max() <= 8e-2 and d.mean() <= 1e-2, (name, d.max().item(), d.mean().item())
+
+
+@pytest.mark.parametrize("tag,qt", [("fp8", FP8), ("bf16", None)])
+def test_full_width_sd3_against_reference_core(tag, qt):
+    """SD3.5-large width (38 x 64 heads, D = 2432), three blocks (dual-attention, plain, context_pre_only) through the reference's
+    own core, 512 x 512, CFG batch 2 (tests/golden/sd3_full_3blocks.npz); synthetic weights regenerated bit-identically on the GPU."""
+    from fastdm_amd.model_entry import create_model
+    from fastdm_amd.synthetic import SyntheticSD3StateDict, sd3_step_inputs
+    g = load("sd3_full_3blocks.npz")
+    arch = dict(sample_size=128, num_layers=3, attention_head_dim=64, num_attention_heads=38, caption_projection_dim=2432, pos_embed_max_size=192,
+                dual_attention_layers=(0,))
+    seed = int(g["seed"])
+    model = create_model("sd35", ckpt_path=SyntheticSD3StateDict(seed=seed, **arch), dtype=BF16, quant_type=qt, kernel_backend="hip", **arch).eval()
+    inp = sd3_step_inputs(int(g["batch"]), int(g["height"]), int(g["width"]), int(g["n_txt"]), seed=seed)
+    want = OS.synth_inputs(OS.SD3Config(**arch), int(g["batch"]), int(g["height"]), int(g["width"]), int(g["n_txt"]), seed=seed)
+    assert all(torch.equal(inp[k].cpu(), want[k]) for k in want)
+    out = model(timestep=torch.tensor([600.0, 600.0]).cuda(), return_dict=False, **inp)[0]
+    ref = g[f"out_{tag}"]
+    assert out.shape == ref.shape == (2, 16, 64, 64)
+    d = (out.float().cpu() - ref.float()).abs()
+    print(f"SD3.5 full width {tag}: max|d| {d.max().item():.4f} mean|d| {d.mean().item():.5f} on mean|ref| {ref.float().abs().mean().item():.3f}")
+    lim = {"bf16": (8e-2, 8e-3), "fp8": (3e-1, 4e-2)}[tag]
+    assert torch.isfinite(out.float()).all() and d.max() <= lim[0] and d.mean() <= lim[1], (tag, d.max().item(), d.mean().item())
