@@ -342,6 +342,53 @@ def test_attention_split_kv_tail(K, S):
     torch.testing.assert_close(split.cpu()[:, rows][:, :, hsel], ref, rtol=0.0, atol=1.8e-2)
 
 
+def test_attention_reference_maximum_shape_wan_i2v(K):
+    """The largest shape the reference tests (tests/test_sparge_attention.py:18-19, Wan2.2-I2V-A14B): S = 489 830 video tokens,
+    40 x 128 heads, self-attention and the 512-token cross-attention, through the dense kernel and through the block-mask kernel
+    with an all-ones mask (what the reference's test feeds).  5 GB per tensor: inputs come from the on-device generator, the
+    check is an fp32 softmax on sampled query rows (the oracle's definition, evaluated on the GPU) plus dense-vs-masked agreement."""
+    from fastdm_amd import _native as N
+    from fastdm_amd.kernel import fused
+    S, H, hd = 489830, 40, 128
+    D = H * hd
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs ~35 GB of free HBM")
+    q, k, v = (fused.synth_fill(torch.empty((S, D), dtype=BF16, device="cuda"), seed, 0, 1.0 / 37837.0) for seed in (11, 12, 13))   # ~N(0,1)
+    rows = torch.tensor([0, 1, 127, 128, 255, 256, 70000, 244915, 489829 - 256, 489829 - 255, 489829])
+    heads = [0, 17, 39]
+
+    def fp32_ref(kk, vv):
+        out = torch.empty(len(rows), len(heads), hd, device="cuda")
+        for i, h in enumerate(heads):
+            sl = slice(h * hd, (h + 1) * hd)
+            sc = (q[rows][:, sl].float() @ kk[:, sl].float().t()) * hd ** -0.5
+            out[:, i] = torch.softmax(sc, dim=-1) @ vv[:, sl].float()
+        return out
+
+    def sample(o):
+        return torch.stack([o[rows][:, h * hd:(h + 1) * hd].float() for h in heads], dim=1)
+
+    dense = fused.attention(q, k, v, 1, H, hd, hd ** -0.5)
+    ref = fp32_ref(k, v)
+    assert torch.isfinite(dense[::4096].float()).all()
+    d = (sample(dense) - ref).abs()
+    assert d.max() <= 1.8e-2 and d.mean() <= 1e-3, ("dense", d.max().item(), d.mean().item())       # tests/test_attention.py atol
+    mask = torch.ones((1, H, (S + 127) // 128, (S + 63) // 64), dtype=torch.int8, device="cuda")
+    masked = torch.empty_like(dense)
+    N.check(N.lib().fdm_attn_fwd(N.ptr(masked), N.ptr(q), N.ptr(k), N.ptr(v), 1, S, S, H, H, hd, D, D, D, D, hd ** -0.5, N.ptr(mask), 128, 64,
+                                 None, 0, N.stream()), "masked attention")
+    d = (sample(masked) - ref).abs()
+    assert d.max() <= 1.8e-2 and d.mean() <= 1e-3, ("masked", d.max().item(), d.mean().item())
+    assert (masked[::997].float() - dense[::997].float()).abs().max() <= 2.0 ** -6
+    del mask, masked
+    # cross-attention to 512 text tokens
+    kc, vc = k[:512].contiguous(), v[:512].contiguous()
+    cross = fused.attention(q, kc, vc, 1, H, hd, hd ** -0.5)
+    d = (sample(cross) - fp32_ref(kc, vc)).abs()
+    assert d.max() <= 1.8e-2 and d.mean() <= 2e-3, ("cross", d.max().item(), d.mean().item())
+
+
 def test_attention_rescale_branch_forced(K):
     """A late key that dominates one query row (online-softmax max jumps at a chosen tile)."""
     g = gen(9)
