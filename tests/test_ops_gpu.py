@@ -142,6 +142,15 @@ def test_rms_norm_flux_shape(K):
     ulp_close(K.rms_norm(x.cuda(), w.cuda(), 1e-5), O.rms_norm(x, w, 1e-5), 0.01, "rms wide")
 
 
+@pytest.mark.parametrize("shape", [(1, 14, 3584), (1, 10, 3584), (1, 4096, 24, 128), (1, 512, 24, 128), (1, 4608, 24, 128), (1, 14, 24, 128),
+                                   (2, 4096, 24, 64), (2, 589, 24, 64)])
+def test_rms_norm_reference_shapes(K, shape):
+    """Every shape of /root/reference/tests/test_rmsnorm.py:5-14 (Qwen text norm, FLUX / SD3 per-head q/k norms)."""
+    g = gen(sum(shape))
+    x, w = rbf(g, *shape, scale=2.0), (1 + 0.1 * torch.randn(shape[-1], generator=g)).to(BF16)
+    ulp_close(K.rms_norm(x.cuda(), w.cuda(), 1e-6), O.rms_norm(x, w, 1e-6), 0.01, f"rms {shape}", ulps=2)
+
+
 def test_rope_flux_shape_bit_exact(K):
     g = gen(2)
     q, k = rbf(g, 1, 4608, 3072), rbf(g, 1, 4608, 3072)
@@ -153,7 +162,16 @@ def test_rope_flux_shape_bit_exact(K):
     assert torch.equal(qd.cpu(), q) and torch.equal(kd.cpu(), k)
 
 
-@pytest.mark.parametrize("M,Kd", [(4096, 3072), (512, 12288), (14, 3072), (4608, 15360), (8192, 640), (154, 2048), (3, 20480)])
+QUANT_SHAPES = [  # every shape of /root/reference/tests/test_quant.py:5-50, plus a 3-row 20480-wide one
+    (9216, 3072), (3072, 3072), (12288, 3072), (3072, 12288), (3072, 15360), (4096, 3072), (512, 3072), (4096, 12288), (512, 12288), (4608, 3072),
+    (4608, 15360), (1280, 320), (1280, 1280), (1280, 2816), (640, 640), (1920, 640), (1280, 2048), (5120, 640), (640, 2560), (3840, 1280), (2560,
+    2048), (10240, 1280), (1280, 5120), (2, 320), (2, 1280), (2, 2816), (8192, 640), (154, 2048), (8192, 2560), (2048, 1280), (2048, 5120), (4608,
+    1536), (1536, 1536), (6144, 1536), (1536, 6144), (3072, 1536), (64, 1536), (8192, 1536), (1178, 1536), (8192, 6144), (1178, 6144), (2, 1536), (14,
+    3072), (14, 12288), (3, 20480),
+]
+
+
+@pytest.mark.parametrize("M,Kd", QUANT_SHAPES)
 def test_quant_shapes_bit_exact(K, M, Kd):
     g = gen(M + Kd)
     x = rbf(g, M, Kd, scale=1.5)
