@@ -239,6 +239,7 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             one_step()
+        D.gather_latents(state["lat"], world, rank, world)   # RCCL builds its all-gather channels on the first call: not part of a step
         state["i"] = 0
         torch.cuda.synchronize()
         D.barrier()
