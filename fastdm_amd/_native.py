@@ -41,10 +41,12 @@ SIGNATURES = {
     "fdm_qk_norm_rope": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, I32, F32, P]),
     "fdm_qk_norm_rope_inplace": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, P]),
     "fdm_absdiff_sums": (I32, [P, P, P, I64, P]),
+    "fdm_abi_version": (I32, []),
     "fdm_synth_fill_bf16": (I32, [P, I64, U32, I32, F32, F32, P]),
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
 }
 
+ABI_VERSION = 8          # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL, EPI_GATE_RESIDUAL_F32 = 0, 1, 2, 3, 4
 
 
@@ -127,6 +129,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError -> missing export: let it propagate loudly
             fn.restype, fn.argtypes = res, args
+        if handle.fdm_abi_version() != ABI_VERSION:
+            raise NativeLibraryError(f"fastdm_amd: {LIB_PATH} was built from another revision of include/fastdm_amd.h (ABI "
+                                     f"{handle.fdm_abi_version()}, these bindings expect {ABI_VERSION}); rebuild it with __graft_entry__.build()")
         _lib = handle
     return _lib
 

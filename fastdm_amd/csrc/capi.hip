@@ -30,6 +30,8 @@ const char* fdm_error_string(int code) {
   }
 }
 
+int fdm_abi_version(void) { return FDM_ABI_VERSION; }
+
 const char* fdm_last_hip_error_string(void) { return hipGetErrorString((hipError_t)fdm::g_last_hip_error); }
 
 }  // extern "C"

@@ -41,6 +41,11 @@ const char* fdm_error_string(int code);
 /* HIP runtime message behind the most recent FDM_ERR_LAUNCH returned to this process. */
 const char* fdm_last_hip_error_string(void);
 
+/* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
+ * refuse to run instead of passing arguments at the wrong positions. */
+#define FDM_ABI_VERSION 8
+int fdm_abi_version(void);
+
 /* ---- replaces cuda_ops.rms_norm_ (ops.h:17-20; csrc/elmwise_ops.cu:56-84,433-449) -------------
  * out[r,:] = bf16(bf16(x[r,:] * rsqrt(mean(x^2)+eps)) * w[:]);  rows x hidden, contiguous.   */
 int fdm_rms_norm(void* out, const void* in, const void* weight, float eps,

@@ -27,6 +27,14 @@ def test_library_builds_and_loads():
     assert b"unsupported" in lib.fdm_error_string(-2)
 
 
+def test_abi_version_stamp_agrees_everywhere():
+    """include/fastdm_amd.h, the built library and the ctypes table carry the same FDM_ABI_VERSION: a library built from another
+    revision of the header is refused at load time instead of receiving arguments at the wrong positions."""
+    src = open(os.path.join(ROOT, "include", "fastdm_amd.h")).read()
+    hdr = int(re.search(r"#define\s+FDM_ABI_VERSION\s+(\d+)", src).group(1))
+    assert hdr == N.ABI_VERSION == N.lib().fdm_abi_version()
+
+
 def test_every_header_symbol_is_exported_and_bound():
     protos = header_prototypes()
     assert len(protos) >= 19
