@@ -3,6 +3,7 @@
 tokens), 25-step flow-match schedule, synthetic weights and prompts (BASELINE.json configs[2]).
 
     python bench.py --gpus 1 --steps 25 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          # plain command: spawns one fresh child process per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -80,6 +81,34 @@ def cpu_baseline_leg(height, width, n_txt, quant_tag):
                       f"to one denoise step ({step_s:.0f}s)"}
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes (one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set) BEFORE anything in this process touches the GPU, relay rank 0's JSON line, and return
+    non-zero if any rank failed.  The parent never initialises HIP and never re-execs itself."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 ARCH_NAME = {"flux": "FLUX.1-dev", "qwen": "Qwen-Image", "wan": "Wan2.2-T2V-A14B", "sd35": "SD3.5-large", "sdxl": "SDXL-base-1.0"}
 
 
@@ -104,6 +133,8 @@ def main():
     ap.add_argument("--batch-cfg", action="store_true", help="qwen: conditional + unconditional prompt as one batch-2 forward per step")
     ap.add_argument("--graph", action="store_true", help="sdxl: replay the UNet forward from a HIP graph (the step is launch-bound: ~2000 small kernels)")
     ap.add_argument("--nhwc", action="store_true", help="sdxl: keep convolution activations channels-last instead of NCHW")
+    ap.add_argument("--cfg-pair", action="store_true", help="qwen / wan / sd35 / sdxl with --gpus 2k: ranks (2i, 2i+1) share image i -- one runs the "
+                    "conditional, the other the unconditional forward, one all-gather of the noise predictions per step (strong scaling of a step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event spans")
     args = ap.parse_args()
@@ -115,9 +146,17 @@ def main():
     args.steps = args.steps if args.steps is not None else (3 if args.model == "wan" else 25)
     args.warmup = args.warmup if args.warmup is not None else (1 if args.model == "wan" else 3)
 
+    for var in ("FDM_GEMM_DEBUG", "FDM_FP8_SW_CVT"):
+        if os.environ.get(var):
+            sys.exit(f"bench.py: refusing to run with {var} set (a bring-up switch of debug builds; it must not shape a benchmark number)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))       # nothing above this line has touched the GPU
+    if args.cfg_pair and (args.model == "flux" or args.gpus % 2):
+        sys.exit("--cfg-pair needs a two-forward model (qwen / wan / sd35 / sdxl) and an even --gpus")
+
     from fastdm_amd import distributed as D
     rank, world, local_rank = D.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run or let bench.py spawn the ranks"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -163,26 +202,39 @@ def main():
             sparse.config.current_steps_callback = lambda: pipe.scheduler_step_index
     if cache:
         cache.config.current_steps_callback = lambda: pipe.scheduler_step_index
-    # rank r denoises image r of the global batch (different latents/prompt per image)
+    # rank r denoises image r of the global batch (different latents/prompt per image); under --cfg-pair ranks 2i and 2i+1
+    # share image i (fastdm_amd/distributed.py: CFGPair)
+    pair = D.make_cfg_pairs(rank, world) if args.cfg_pair else None
+    n_images = world // 2 if pair is not None else world
+    img_rank = rank // 2 if pair is not None else rank
+    if pair is not None:
+        if args.model in ("qwen", "wan"):
+            pipe.cfg_pair = pair
+        elif args.model == "sd35":
+            from fastdm_amd.pipeline import SyntheticSD3Pipeline
+            pipe2 = SyntheticSD3Pipeline(model, seed=0, cfg_pair=pair)
+        else:
+            from fastdm_amd.pipeline import SyntheticSDXLPipeline
+            pipe2 = SyntheticSDXLPipeline(model, seed=0, use_graph=args.graph, cfg_pair=pair)
     if args.model == "sd35":
         IMAGE_STEPS = 28
-        inp = sd3_step_inputs(2, args.height // 8, args.width // 8, args.max_seq_len, seed=rank)      # cond + uncond batched (CFG), as diffusers does
+        inp = sd3_step_inputs(2, args.height // 8, args.width // 8, args.max_seq_len, seed=img_rank)      # cond + uncond batched (CFG), as diffusers does
         n_img = (args.height // 16) * (args.width // 16)
         lin = np.linspace(1.0, 1.0 / IMAGE_STEPS, IMAGE_STEPS)
         sig = np.concatenate([3.0 * lin / (1.0 + 2.0 * lin), [0.0]]).astype(np.float32)      # flow-match schedule, shift 3
     elif args.model == "sdxl":
         IMAGE_STEPS = 30
-        inp = sdxl_step_inputs(2, args.height // 8, args.width // 8, args.max_seq_len, seed=rank)     # cond + uncond batched (CFG), as diffusers does
+        inp = sdxl_step_inputs(2, args.height // 8, args.width // 8, args.max_seq_len, seed=img_rank)     # cond + uncond batched (CFG), as diffusers does
         inp["hidden_states"] = inp["sample"]
         n_img = (args.height // 16) * (args.width // 16)
         sig = np.concatenate([np.linspace(1.0, 1.0 / IMAGE_STEPS, IMAGE_STEPS), [0.0]]).astype(np.float32)
     elif args.model == "wan":
         IMAGE_STEPS = 40
-        inp = pipe.prepare(1, args.height, args.width, args.frames, args.max_seq_len, seed=rank)
+        inp = pipe.prepare(1, args.height, args.width, args.frames, args.max_seq_len, seed=img_rank)
         n_img = inp["hidden_states"].shape[2] * (inp["hidden_states"].shape[3] // 2) * (inp["hidden_states"].shape[4] // 2)
         sig = pipe.sigmas(IMAGE_STEPS)
     else:
-        inp = pipe.prepare(1, args.height, args.width, args.max_seq_len, seed=rank)
+        inp = pipe.prepare(1, args.height, args.width, args.max_seq_len, seed=img_rank)
         n_img = inp["hidden_states"].shape[1]
         sig = flow_match_sigmas(IMAGE_STEPS, n_img) if args.model == "flux" else flow_match_sigmas(IMAGE_STEPS, n_img, max_seq_len=8192, max_shift=0.9)
     guidance = torch.full((1,), 3.5, device=dev, dtype=torch.float32)
@@ -204,6 +256,14 @@ def main():
             state["lat"] = inp["hidden_states"].clone()
         if pipe is not None:
             pipe.scheduler_step_index = i
+        if pair is not None and args.model == "sd35":
+            state["lat"] = pipe2.step(state["lat"][0:1], inp, float(sig[i]), float(sig[i + 1]), 4.5)
+            state["i"] += 1
+            return
+        if pair is not None and args.model == "sdxl":
+            state["lat"] = pipe2.step(state["lat"][0:1], inp, float(sig[i]) * 999.0, float(sig[i]), float(sig[i + 1]), 5.0)
+            state["i"] += 1
+            return
         if args.model == "sd35":
             lat = state["lat"]
             t = torch.full((2,), float(sig[i]) * 1000.0, device=dev, dtype=torch.float32)
@@ -239,7 +299,12 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             one_step()
-        D.gather_latents(state["lat"], world, rank, world)   # RCCL builds its all-gather channels on the first call: not part of a step
+        def gather_final():
+            own = state["lat"][0:1]        # sd35 / sdxl keep the CFG batch-2 copy of the ONE latent this rank owns
+            if pair is not None:
+                return D.gather_pair_latents(own, pair, rank, world)
+            return D.gather_latents(own, world, rank, world)
+        gather_final()   # RCCL builds its all-gather channels on the first call: not part of a step
         state["i"] = 0
         torch.cuda.synchronize()
         D.barrier()
@@ -252,7 +317,7 @@ def main():
             one_step()
         if rec:
             rec.__exit__(None, None, None)
-        final = D.gather_latents(state["lat"], world, rank, world)      # the job's single collective (RCCL all-gather)
+        final = gather_final()      # the job's single end-of-job collective (RCCL all-gather)
         torch.cuda.synchronize()
         D.barrier()
         torch.cuda.synchronize()
@@ -298,7 +363,7 @@ def main():
                    "sd35": "denoise it/s (sec/image = 28 / (value / n_gpus)), SD3.5-large 1024x1024 fp8 @28 steps, CFG",
                    "sdxl": "denoise it/s (sec/image = 30 / (value / n_gpus)), SDXL-base UNet 1024x1024 fp8 @30 steps, CFG",
                    "wan": "denoise it/s (sec/video = 40 / (value / n_gpus)), Wan2.2-T2V-A14B 768x1280x81f fp8 @40 steps, CFG"}[args.model],
-        "value": world * args.steps / elapsed,
+        "value": n_images * args.steps / elapsed,
         "unit": "it/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -306,11 +371,15 @@ def main():
         "ms_per_step": ms_per_step,
         "sec_per_image": ms_per_step * IMAGE_STEPS / 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if (pair is not None and world == 2) else "weak",
         "vs_baseline": None,
         "dtype": {"fp8": "fp8_e4m3 W8A8 GEMM (fp32 accumulate) + bf16 attention", "int8": "int8 W8A8 + bf16 attention", "bf16": "bf16"}[args.quant],
         "data": f"synthetic (counter-based random weights of the {ARCH_NAME[args.model]} architecture, synthetic latents/prompt embeddings)",
-        "config": {"workload": workload, "global_batch": world, "height": args.height, "width": args.width, "parallelism": f"dp{world} (image-sharded, one all-gather of final latents)"},
+        "config": {"workload": workload, "global_batch": n_images, "height": args.height, "width": args.width,
+                   "parallelism": (f"dp{n_images} x cfg2 (ranks 2i, 2i+1 run the conditional / unconditional forward of image i; one all-gather of the "
+                                   f"two noise predictions per step inside the pair, one all-gather of final latents)" if pair is not None else
+                                   f"dp{world} (image-sharded, one all-gather of final latents)"),
+                   "ranks_in_process_group": D.group_size()},
     }
     if rec:
         summ = rec.summary()

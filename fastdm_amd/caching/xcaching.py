@@ -29,6 +29,16 @@ class AutoCache:
         self.previous_residual_dict = {"positive": None, "negative": None}
         self.cache_status = {"positive": True, "negative": False}
         self.trace = []   # (step, rel_distance | None, accumulated, should_calc): for tests / logging
+        self.pinned_key = None
+
+    def pin_key(self, key):
+        """CFG-pair sharding (fastdm_amd/distributed.py): this process only ever runs ONE branch of the cond / uncond
+        pair, so the positive / negative entry is fixed instead of alternating call by call -- the rank that runs the
+        unconditional forwards pins 'negative' and then sees exactly the state sequence the single-GPU loop keeps under
+        that key (its coefficients included)."""
+        if key not in (None, "positive", "negative"):
+            raise ValueError(f"unknown cache key {key!r}")
+        self.pinned_key = key
 
     @classmethod
     def register(cls, name: str):
@@ -61,6 +71,8 @@ class AutoCache:
         """xcaching.py:66-76: alternate positive/negative on successive calls when negtive_cache is set."""
         if not self.config.negtive_cache:
             return "positive"
+        if self.pinned_key is not None:
+            return self.pinned_key
         cache_key = None
         for k in self.cache_status:
             if self.cache_status[k] and cache_key is None:

@@ -493,17 +493,14 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
   p.ws_o = nullptr;
   p.ws_ml = nullptr;
   int n_tail = 0;
+  // a workspace that cannot be used is an error, not a silent fall-back to the (20 % slower) unsplit schedule
+  if (workspace != nullptr && ((reinterpret_cast<uintptr_t>(workspace) & 15) || workspace_bytes < 0)) return FDM_ERR_INVALID;
   if (block_mask == nullptr && workspace != nullptr && (bh % 8) == 0) {
-    static int num_cu = 0;
-    if (num_cu == 0) {
-      int dev = 0, cu = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
-      num_cu = cu * (512 / ATT_THREADS);  // concurrent work-item slots on the chip
-    }
+    const int num_cu = device_cu_count() * (512 / ATT_THREADS);  // concurrent work-item slots on the chip (per device)
     const int rem = (int)(grid % num_cu);
     const int kt_dense = head_dim == 128 ? KT_DENSE : KT_MASK;
     const int ntiles = (int)((sk + kt_dense - 1) / kt_dense);
-    if (rem > 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+    if (rem > 0) {
       // time of the last round in units of one whole item: ceil(rem*S / CUs) rounds of 1/S-sized parts, plus a
       // per-part overhead (Q load, prologue, fp32 partial write + merge) priced at 2% of an item
       // (a split must save >= 0.3 item-times: measured at 432 items, a predicted 0.17 saving was a 5% loss -- a

@@ -3,10 +3,28 @@
 #include <cstring>
 #include "common.h"
 
-namespace fdm {
-int g_last_hip_error = 0;
-}
+#include <atomic>
 
+namespace fdm {
+thread_local int g_last_hip_error = 0;
+
+int device_cu_count() {
+  constexpr int MAX_DEV = 64;
+  static std::atomic<int> cache[MAX_DEV];   // zero-initialised; 0 = not queried yet
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev >= 0 && dev < MAX_DEV) {
+    const int c = cache[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+  }
+  int cu = 0;
+  if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+  if (dev >= 0 && dev < MAX_DEV) cache[dev].store(cu, std::memory_order_relaxed);
+  return cu;
+}
+}  // namespace fdm
+
+#ifdef FDM_DEBUG_BUILD
 namespace {
 struct Init {
   Init() {
@@ -15,6 +33,7 @@ struct Init {
   }
 } g_init;
 }  // namespace
+#endif
 
 extern "C" {
 

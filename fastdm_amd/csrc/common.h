@@ -15,7 +15,11 @@
 
 namespace fdm {
 
-extern int g_last_hip_error;  // HIP error code behind the most recent FDM_ERR_LAUNCH (fdm_last_hip_error_string)
+extern thread_local int g_last_hip_error;  // HIP error code behind this thread's most recent FDM_ERR_LAUNCH (fdm_last_hip_error_string)
+
+// Compute units of the CURRENT device, cached per device id (two devices of one process may differ; threads may race
+// here, all writing the same value).
+int device_cu_count();
 
 typedef uint16_t bf16_t;  // raw bf16 bits
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -134,7 +138,13 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   return 0.5f * x * (1.0f + tanhf(inner));
 }
 
-extern bool g_fp8_sw_cvt;  // set from env FDM_FP8_SW_CVT at load time
+// Bring-up switches exist only in builds made with -DFDM_DEBUG_BUILD (tools/micro); the product library has none: no
+// environment variable can change what a kernel computes or stores.
+#ifdef FDM_DEBUG_BUILD
+extern bool g_fp8_sw_cvt;  // env FDM_FP8_SW_CVT: software e4m3 converter instead of v_cvt_pk_fp8_f32
+#else
+constexpr bool g_fp8_sw_cvt = false;
+#endif
 
 inline hipStream_t to_stream(fdm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

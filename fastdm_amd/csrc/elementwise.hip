@@ -6,7 +6,9 @@
 
 namespace fdm {
 
+#ifdef FDM_DEBUG_BUILD
 bool g_fp8_sw_cvt = false;
+#endif
 
 constexpr int MAXV = 8;  // 16-byte vectors held per thread
 
@@ -611,7 +613,7 @@ template <int MODE>
 static int launch_quant(void* q, float* scale, int32_t* azp, const bf16_t* s0, int w0, int64_t st0, const bf16_t* s1, int w1,
                         int64_t st1, int64_t rows, hipStream_t s) {
   const int hidden = w0 + w1;
-  const bool sw = g_fp8_sw_cvt;
+  const bool sw = g_fp8_sw_cvt;   // constexpr false in the product build
   auto qq = (uint8_t*)q;
   if (hidden <= 4096) {
     if (sw) quant_rowwise_kernel<64, MODE, true><<<(unsigned)rows, 64, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1);
@@ -632,7 +634,7 @@ template <int THREADS>
 static int launch_ln(void* out_bf16, void* out_q, float* out_scale, int32_t* out_azp, int qm, const void* x, const void* scale,
                      const void* shift, int64_t mbs, const void* res, const void* gate, void* x_out, int64_t rows, int hidden,
                      int64_t rpb, float eps, hipStream_t s) {
-  const bool sw = g_fp8_sw_cvt;
+  const bool sw = g_fp8_sw_cvt;   // constexpr false in the product build
 #define FDM_LN(QM, SWV)                                                                                                  \
   ln_modulate_kernel<THREADS, QM, SWV><<<(unsigned)rows, THREADS, 0, s>>>(                                               \
       (bf16_t*)out_bf16, (uint8_t*)out_q, out_scale, out_azp, (const bf16_t*)x, (const bf16_t*)scale, (const bf16_t*)shift, \
@@ -649,7 +651,7 @@ static int launch_ln(void* out_bf16, void* out_q, float* out_scale, int32_t* out
 template <int THREADS>
 static int launch_ln_f32(void* out_bf16, void* out_q, float* out_scale, int32_t* out_azp, int qm, const void* x, const float* scale,
                          const float* shift, int64_t mbs, int64_t rows, int hidden, int64_t rpb, float eps, hipStream_t s) {
-  const bool sw = g_fp8_sw_cvt;
+  const bool sw = g_fp8_sw_cvt;   // constexpr false in the product build
 #define FDM_LNF(QM, SWV)                                                                                        \
   ln_modulate_f32_kernel<THREADS, QM, SWV><<<(unsigned)rows, THREADS, 0, s>>>(                                   \
       (bf16_t*)out_bf16, (uint8_t*)out_q, out_scale, out_azp, (const bf16_t*)x, scale, shift, mbs, hidden, rpb, eps)

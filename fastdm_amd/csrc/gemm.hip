@@ -74,7 +74,9 @@ struct GemmGroup {
   GemmProblem p[2];
   int n;            // 1 or 2 problems
   int total_tiles;
-  int debug;        // bring-up ablation (env FDM_GEMM_DEBUG): 4 = no stores
+#ifdef FDM_DEBUG_BUILD
+  int debug;        // bring-up ablation (env FDM_GEMM_DEBUG, debug builds only): 4 = no stores
+#endif
 #ifdef FDM_GEMM_STAMPS
   unsigned long long* stamps;  // [block][4] shader-clock stamps: start / prologue landed / main loop done / epilogue done
 #endif
@@ -470,7 +472,10 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
     };
     auto store_row = [&](int it, const i32x4& v) {
       const int m = m0 + wm * 128 + it * 8 + rsub;
-      if (n_ok && (full || m < p.M) && !(grp.debug & 4)) *reinterpret_cast<i32x4*>(p.C + (int64_t)m * p.ldc + ccol) = v;
+#ifdef FDM_DEBUG_BUILD
+      if (grp.debug & 4) return;
+#endif
+      if (n_ok && (full || m < p.M)) *reinterpret_cast<i32x4*>(p.C + (int64_t)m * p.ldc + ccol) = v;
     };
     // out = res + gate * y.  bf16 gates (FLUX / Qwen-Image): the product is rounded to bf16 before the add, as the
     // reference's two bf16 ops do; fp32 gates (Wan: `(x.float() + y * gate).type_as(x)`, wan.py:102,113): one rounding.
@@ -581,12 +586,14 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s) {
   const_cast<GemmGroup&>(grp).stamps = g_gemm_stamps;
 #endif
   const int grid = grp.total_tiles;
+#ifdef FDM_DEBUG_BUILD
   static int debug = -1;
   if (debug < 0) {
     const char* e = getenv("FDM_GEMM_DEBUG");
     debug = e ? atoi(e) : 0;
   }
   const_cast<GemmGroup&>(grp).debug = debug;
+#endif
   const bool res = grp.p[0].epi == FDM_EPI_GATE_RESIDUAL || (grp.n > 1 && grp.p[1].epi == FDM_EPI_GATE_RESIDUAL);
   if (res) gemm_kernel<DT, true><<<grid, GEMM_THREADS, 0, s>>>(grp);
   else gemm_kernel<DT, false><<<grid, GEMM_THREADS, 0, s>>>(grp);

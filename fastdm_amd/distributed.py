@@ -31,6 +31,18 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local_rank
 
 
+def _all_gather(out: List[torch.Tensor], t: torch.Tensor, group=None):
+    """dist.all_gather; the gloo backend (CPU tests, one-device protocol tests) has no GPU all-gather, so device tensors
+    are staged through host memory there.  RCCL gathers device to device."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = [torch.empty(o.shape, dtype=o.dtype) for o in out]
+        dist.all_gather(host, t.cpu(), group=group)
+        for o, h in zip(out, host):
+            o.copy_(h)
+    else:
+        dist.all_gather(out, t, group=group)
+
+
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     """Round-robin image ownership: rank r takes images r, r+world, ...."""
     return list(range(rank, n_items, world))
@@ -44,10 +56,13 @@ def gather_latents(local: torch.Tensor, n_items: int, rank: int, world: int) -> 
     if world == 1 and not dist.is_initialized():
         return local
     per = -(-n_items // world)
+    if local.shape[0] > per:
+        raise ValueError(f"gather_latents: this rank holds {local.shape[0]} items but ceil({n_items}/{world}) = {per}; pass only the "
+                         "items this rank owns (one latent per image, not the CFG batch)")
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad)
+    _all_gather(out, pad)
     full = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     for r in range(world):
         idx = shard_indices(n_items, r, world)
@@ -63,6 +78,11 @@ def barrier():
             dist.barrier()
 
 
+def group_size() -> int:
+    """Ranks the collective backend (RCCL / gloo) actually sees: 1 without a process group."""
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
 def shutdown():
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -74,3 +94,66 @@ def max_over_ranks(x: float, device) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------- CFG-pair split
+# Models that run a conditional AND an unconditional forward per step (the reference flags them in
+# caching/config.py:16 and loops over both in model_entry.py:782-789) leave GPUs idle when there are fewer images
+# than GPUs.  A CFG pair is a 2-rank group that owns ONE image: role 0 runs the conditional forward, role 1 the
+# unconditional one, each step ends with ONE all-gather of the two noise predictions (1 MiB per 1024x2048 image) inside
+# the pair, and both ranks then apply the same guidance combine + Euler update, so their latents stay bit-identical
+# without any further exchange.  Step caches need no coordination: each rank only ever sees its own branch, i.e.
+# exactly the sequence of forwards the single-GPU loop feeds to that branch's cache context.
+
+class CFGPair:
+    """role 0 = conditional forward, role 1 = unconditional forward; `group` = the pair's process group (None: both on
+    this rank, no exchange)."""
+
+    def __init__(self, role: int, group=None, ranks=None):
+        if role not in (0, 1):
+            raise ValueError("CFGPair role must be 0 (cond) or 1 (uncond)")
+        self.role, self.group, self.ranks = role, group, ranks
+
+    @property
+    def image_index(self) -> int:
+        return 0 if self.ranks is None else self.ranks[0] // 2
+
+    def pin_cache(self, transformer):
+        """Step caches alternate positive / negative entries call by call (caching/xcaching.py get_cache_key); a pair
+        member only ever makes one kind of call, so its entry is pinned."""
+        cache = getattr(getattr(transformer, "core_model", None), "cache", None)
+        if cache is not None and hasattr(cache, "pin_key"):
+            cache.pin_key("positive" if self.role == 0 else "negative")
+
+    def exchange(self, mine: torch.Tensor):
+        """all-gather this rank's noise prediction inside the pair -> (cond, uncond), identical on both ranks."""
+        mine = mine.contiguous()
+        out = [torch.empty_like(mine), torch.empty_like(mine)]
+        _all_gather(out, mine, group=self.group)
+        return out[0], out[1]
+
+
+def make_cfg_pairs(rank: int, world: int) -> Optional[CFGPair]:
+    """Ranks (2i, 2i+1) form pair i.  Every rank must call this (new_group is collective over the default group).
+    Returns None for world == 1 (both forwards run locally)."""
+    if world == 1:
+        return None
+    if world % 2:
+        raise ValueError(f"CFG-pair sharding needs an even number of ranks, got {world}")
+    mine = None
+    for i in range(world // 2):
+        ranks = [2 * i, 2 * i + 1]
+        g = dist.new_group(ranks=ranks)
+        if rank in ranks:
+            mine = CFGPair(rank - 2 * i, g, ranks)
+    return mine
+
+
+def gather_pair_latents(local: torch.Tensor, pair: Optional[CFGPair], rank: int, world: int) -> torch.Tensor:
+    """The job's final collective under CFG-pair sharding: image i lives (identically) on ranks 2i and 2i+1; returns
+    [world // 2, ...] in image order on every rank."""
+    if pair is None or world == 1:
+        return local
+    out = [torch.empty_like(local) for _ in range(world)]
+    _all_gather(out, local.contiguous())
+    return torch.cat([out[2 * i] for i in range(world // 2)], dim=0)

@@ -146,6 +146,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
 def absdiff_sums(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """[sum|a-b|, sum|b|] in fp32 on the device (TeaCache metric, caching/xcaching.py:214)."""
     assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    assert a.dtype == BF16 and b.dtype == BF16, "fdm_absdiff_sums reads its inputs as bf16"
     out = torch.zeros(2, device=a.device, dtype=torch.float32)
     N.check(N.lib().fdm_absdiff_sums(N.ptr(out), N.ptr(a), N.ptr(b), a.numel(), N.stream()), "absdiff_sums")
     return out

@@ -9,11 +9,57 @@ every start-up; with a cache path the first load writes one safetensors file hol
 consume it (fp8 / int8 weights, scales, int8 column sums, biases, the norm / conv tensors) and later loads read that file
 only -- half the bytes of the bf16 checkpoint, no quantisation pass, and the original checkpoint is not needed any more.
 """
+import hashlib
 import os
 
 import torch
 
 from fastdm_amd.layer.qlinear import QLinear
+
+
+def checkpoint_fingerprint(model_path) -> str:
+    """Identity of a checkpoint WITHOUT reading its tensor bytes: sorted tensor names, shapes and dtypes, plus
+    * files / shard directories: every file's relative name, size and mtime (ns);
+    * in-memory state_dicts: the dict's own `fingerprint` attribute when it has one (the lazily generated synthetic
+      checkpoints expose their seed that way), otherwise a hash of the first 64 KiB of every tensor.
+    Stored in a pre-quantised cache file and compared on every later load that still names a checkpoint, so a cache written
+    from other weights (or other arch kwargs of the same class) cannot silently supply them."""
+    h = hashlib.sha256()
+
+    def add(*parts):
+        for x in parts:
+            h.update(str(x).encode())
+            h.update(b"\0")
+
+    if isinstance(model_path, dict):
+        spec = getattr(model_path, "spec", None)
+        if spec is not None:                                  # lazily generated: shapes are known without making tensors
+            for k in sorted(spec):
+                add(k, tuple(spec[k][0]), spec[k][1])
+            add("synthetic", type(model_path).__name__, getattr(model_path, "seed", None))
+        else:
+            for k in sorted(model_path):
+                t = model_path[k]
+                add(k, tuple(t.shape), t.dtype)
+                flat = t.detach().reshape(-1)[:32768].contiguous().cpu()
+                h.update(flat.view(torch.uint8).numpy().tobytes())
+        return h.hexdigest()
+    from safetensors import safe_open
+    files = []
+    if os.path.isdir(model_path):
+        for root, _, names in os.walk(model_path):
+            files += [os.path.join(root, n) for n in names if ".safetensors" in n]
+    else:
+        files = [model_path]
+    for f in sorted(files):
+        st = os.stat(f)
+        add(os.path.relpath(f, os.path.dirname(model_path) or "."), st.st_size, st.st_mtime_ns)
+        if ".safetensors" in f:
+            with safe_open(f, framework="pt") as sf:
+                for k in sorted(sf.keys()):
+                    sl = sf.get_slice(k)
+                    add(k, tuple(sl.get_shape()), sl.get_dtype())
+    return h.hexdigest()
 
 
 class BaseModelCore:
@@ -28,7 +74,10 @@ class BaseModelCore:
             name = weights_name[0]
             if self._qc_in is not None and f"t:{name}" in self._qc_keys:
                 self.unmatched_tensors.discard(name)
-                return self._qc_in.get_tensor(f"t:{name}").to(device=self.device)
+                t = self._qc_in.get_tensor(f"t:{name}")
+                if t.dtype != self.dtype:
+                    raise ValueError(f"quantized cache holds {t.dtype} for {name}, the model runs in {self.dtype}: delete the cache")
+                return t.to(device=self.device)
             if name not in self.origin_tensor_dict:
                 raise ValueError(f"The {name} is not in origin_tensor_dict!!!")
             t = self.origin_tensor_dict[name].to(device=self.device, dtype=self.dtype).contiguous()
@@ -45,7 +94,16 @@ class BaseModelCore:
             if stored != want:
                 raise ValueError(f"quantized cache holds {stored} for {key}, the model asks for {want}: delete the cache or change quant_type")
             dst_module.device = self.device
-            dst_module.import_state({k: self._qc_in.get_tensor(f"{key}.{k}") for k in ("w", "s", "c", "b") if f"{key}.{k}" in self._qc_keys})
+            state = {k: self._qc_in.get_tensor(f"{key}.{k}") for k in ("w", "s", "c", "b") if f"{key}.{k}" in self._qc_keys}
+            want_shape = (dst_module.out_features, dst_module.in_features)
+            if tuple(state["w"].shape) != want_shape:
+                raise ValueError(f"quantized cache holds a {tuple(state['w'].shape)} weight for {key}, the layer is {want_shape} "
+                                 "(out_features, in_features): the cache was written for other arch kwargs -- delete it")
+            if stored in (torch.float8_e4m3fn, torch.int8) and ("s" not in state or state["s"].numel() != want_shape[0]):
+                raise ValueError(f"quantized cache entry {key} lacks its {want_shape[0]} per-channel scales")
+            if "b" in state and (state["b"].numel() != want_shape[0] or state["b"].dtype != dst_module.dtype):
+                raise ValueError(f"quantized cache entry {key}: bias {tuple(state['b'].shape)} {state['b'].dtype} does not fit the layer")
+            dst_module.import_state(state)
             for weight_name in weights_name:
                 self.unmatched_tensors.discard(f"{weight_name}.weight")
                 self.unmatched_tensors.discard(f"{weight_name}.bias")
@@ -82,11 +140,12 @@ class BaseModelCore:
     _qc_in = None
     _qc_out = None
     _qc_keys = frozenset()
-    QC_FORMAT = "fastdm_amd-quantized-v1"
+    QC_FORMAT = "fastdm_amd-quantized-v2"      # v2: + checkpoint fingerprint and activation dtype in the metadata
 
-    def weight_loading(self, model_path, data_type=torch.bfloat16, device_type="cuda", quantized_cache=None):
+    def weight_loading(self, model_path, data_type=torch.bfloat16, device_type="cuda", quantized_cache=None, verify_against=None):
         """basemodel.py:88-143, plus the pre-quantised cache described in the module docstring.  With an existing cache file
-        `model_path` may be None."""
+        `model_path` may be None; `verify_against` (the checkpoint the caller would otherwise have loaded) is then only
+        fingerprinted and compared with the fingerprint stored in the cache."""
         self.origin_tensor_dict = {}
         self.dtype = data_type
         self.device = device_type
@@ -97,6 +156,14 @@ class BaseModelCore:
             meta = self._qc_in.metadata() or {}
             if meta.get("format") != self.QC_FORMAT or meta.get("model") != type(self).__name__:
                 raise ValueError(f"{quantized_cache}: not a {self.QC_FORMAT} file for {type(self).__name__} ({meta})")
+            if meta.get("dtype") != str(data_type):
+                raise ValueError(f"{quantized_cache} was written for {meta.get('dtype')} activations, the model runs in {data_type}")
+            src = verify_against if verify_against is not None else model_path
+            if src is not None and (isinstance(src, dict) or os.path.exists(src)):
+                fp = checkpoint_fingerprint(src)
+                if meta.get("checkpoint") != fp:
+                    raise ValueError(f"{quantized_cache} was written from another checkpoint (fingerprint {str(meta.get('checkpoint'))[:12]}..., "
+                                     f"this one is {fp[:12]}...): delete the cache file or point quantized_cache elsewhere")
             self._qc_keys = frozenset(self._qc_in.keys())
         elif quantized_cache is not None:
             self._qc_out = {}
@@ -131,7 +198,8 @@ class BaseModelCore:
             from safetensors.torch import save_file
             tmp = f"{quantized_cache}.tmp{os.getpid()}"
             save_file({k: v.detach().contiguous().cpu() for k, v in self._qc_out.items()}, tmp,
-                      metadata={"format": self.QC_FORMAT, "model": type(self).__name__})
+                      metadata={"format": self.QC_FORMAT, "model": type(self).__name__, "dtype": str(data_type),
+                                "checkpoint": checkpoint_fingerprint(model_path)})
             os.replace(tmp, quantized_cache)          # readers never see a half-written file
         self._qc_in, self._qc_out, self._qc_keys = None, None, frozenset()
         self._finalize_loading()

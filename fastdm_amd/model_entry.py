@@ -56,8 +56,9 @@ class BaseModelWrapper(nn.Module, ConfigMixin):
         the kernels consume them -- written on the first load, read INSTEAD of the checkpoint afterwards (basemodel.py)."""
         have_ckpt = isinstance(ckpt_path, dict) or bool(ckpt_path and os.path.exists(ckpt_path))
         have_cache = bool(quantized_cache and os.path.isfile(quantized_cache))
-        if have_cache:
-            self.core_model.weight_loading(None, data_type=dtype, device_type="cuda", quantized_cache=quantized_cache)
+        if have_cache:      # the checkpoint, when also given, is only fingerprinted and compared with the cache's record
+            self.core_model.weight_loading(None, data_type=dtype, device_type="cuda", quantized_cache=quantized_cache,
+                                           verify_against=ckpt_path if have_ckpt else None)
         elif have_ckpt:
             self.core_model.weight_loading(ckpt_path, data_type=dtype, device_type="cuda", quantized_cache=quantized_cache)
         elif ckpt_path:

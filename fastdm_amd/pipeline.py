@@ -79,13 +79,18 @@ class SyntheticQwenPipeline:
     to the conditional prediction's per-token norm, then the flow-match Euler update.  Latents are packed
     [B, (H/16)*(W/16), 64]; `timestep = sigma`; prompt / negative-prompt embeddings are synthetic."""
 
-    def __init__(self, transformer, seed: int = 0, batch_cfg: bool = False):
-        """batch_cfg: run the conditional and the unconditional prompt as ONE batch-2 forward (same bits as two forwards: all
+    def __init__(self, transformer, seed: int = 0, batch_cfg: bool = False, cfg_pair=None):
+        """cfg_pair: a `distributed.CFGPair` -- this rank runs only its branch of the CFG forward pair and the two noise
+        predictions meet in one all-gather per step (the combine + Euler update then run identically on both ranks).
+        batch_cfg: run the conditional and the unconditional prompt as ONE batch-2 forward (same bits as two forwards: all
         quantisation is per token) when both prompts have the same length and no step cache keys on the cond / uncond
         alternation; the N = 3072 GEMMs then fill 2.6 instead of 1.3 rounds of the chip."""
         self.transformer = transformer
         self.seed = seed
         self.batch_cfg = batch_cfg
+        self.cfg_pair = cfg_pair
+        if cfg_pair is not None and batch_cfg:
+            raise ValueError("cfg_pair splits the two forwards over two GPUs; batch_cfg fuses them on one")
         self.scheduler_step_index = None
         self.num_steps = 0
         self._inputs_key, self._inputs = None, None
@@ -119,10 +124,17 @@ class SyntheticQwenPipeline:
             out = self._forward("cond", torch.cat([latents, latents], dim=0), torch.cat([t, t], dim=0),
                                 torch.cat([inp["encoder_hidden_states"], inp["negative_encoder_hidden_states"]], dim=0), both)
             cond, uncond = out[:b], out[b:]
+        elif use_cfg and self.cfg_pair is not None:
+            self.cfg_pair.pin_cache(self.transformer)
+            if self.cfg_pair.role == 0:
+                mine = self._forward("cond", latents, t, inp["encoder_hidden_states"], inp)
+            else:
+                mine = self._forward("uncond", latents, t, inp["negative_encoder_hidden_states"], inp)
+            cond, uncond = self.cfg_pair.exchange(mine)
         else:
             cond = self._forward("cond", latents, t, inp["encoder_hidden_states"], inp)
         if use_cfg:
-            if not self.batch_cfg:
+            if not self.batch_cfg and self.cfg_pair is None:
                 uncond = self._forward("uncond", latents, t, inp["negative_encoder_hidden_states"], inp)
             comb = uncond.float() + true_cfg_scale * (cond.float() - uncond.float())
             cond_norm = torch.norm(cond.float(), dim=-1, keepdim=True)
@@ -151,9 +163,10 @@ class SyntheticWanPipeline:
     [B, 16, (frames-1)/4+1, H/8, W/8], `timestep = sigma * 1000`, a conditional and an unconditional forward per step,
     `noise = uncond + guidance * (cond - uncond)`, flow-match Euler update (shift 5 for 720p-class outputs)."""
 
-    def __init__(self, transformer, seed: int = 0):
+    def __init__(self, transformer, seed: int = 0, cfg_pair=None):
         self.transformer = transformer
         self.seed = seed
+        self.cfg_pair = cfg_pair        # distributed.CFGPair: cond / uncond forward on two GPUs, one all-gather per step
         self.scheduler_step_index = None
         self.num_steps = 0
         self._inputs_key, self._inputs = None, None
@@ -179,6 +192,14 @@ class SyntheticWanPipeline:
     @torch.no_grad()
     def step(self, latents, inp, sigma, sigma_next, guidance_scale):
         t = torch.full((latents.shape[0],), float(sigma) * 1000.0, device=latents.device, dtype=torch.float32)
+        if self.cfg_pair is not None and guidance_scale is not None and guidance_scale > 1:
+            name, key = ("cond", "encoder_hidden_states") if self.cfg_pair.role == 0 else ("uncond", "negative_encoder_hidden_states")
+            self.cfg_pair.pin_cache(self.transformer)
+            with self.transformer.cache_context(name):
+                mine = self.transformer(latents, timestep=t, encoder_hidden_states=inp[key], return_dict=False)[0]
+            cond, uncond = self.cfg_pair.exchange(mine)
+            noise = uncond.float() + guidance_scale * (cond.float() - uncond.float())
+            return (latents.float() + float(sigma_next - sigma) * noise).to(latents.dtype)
         with self.transformer.cache_context("cond"):
             cond = self.transformer(latents, timestep=t, encoder_hidden_states=inp["encoder_hidden_states"], return_dict=False)[0]
         if guidance_scale is not None and guidance_scale > 1:
@@ -209,9 +230,10 @@ class SyntheticSD3Pipeline:
     guidance as ONE batch-2 forward ([uncond ; cond] concatenated along the batch), `timestep = sigma * 1000`, flow-match Euler
     update with shift 3."""
 
-    def __init__(self, transformer, seed: int = 0):
+    def __init__(self, transformer, seed: int = 0, cfg_pair=None):
         self.transformer = transformer
         self.seed = seed
+        self.cfg_pair = cfg_pair        # distributed.CFGPair: role 0 runs the cond row, role 1 the uncond row, as batch-1 forwards
         self.scheduler_step_index = None
         self.num_steps = 0
 
@@ -229,9 +251,20 @@ class SyntheticSD3Pipeline:
     @torch.no_grad()
     def step(self, latents, inp, sigma, sigma_next, guidance_scale):
         """latents [1, C, h, w] -> next latents; rows 0 / 1 of the prompt tensors are the unconditional / conditional prompt."""
-        t = torch.full((2,), float(sigma) * 1000.0, device=latents.device, dtype=torch.float32)
-        v = self.transformer(hidden_states=latents.expand(2, -1, -1, -1).contiguous(), encoder_hidden_states=inp["encoder_hidden_states"],
-                             pooled_projections=inp["pooled_projections"], timestep=t, return_dict=False)[0].float()
+        if self.cfg_pair is not None:
+            if getattr(self.transformer.core_model, "cache", None) is not None:
+                # the single-GPU loop feeds the step cache ONE batch-2 tensor; a pair member would decide on its own row only
+                raise ValueError("cfg_pair with a step cache is not defined for the batch-2 CFG families (sd35 / sdxl)")
+            r = 1 - self.cfg_pair.role                                   # prompt row: 1 = conditional, 0 = unconditional
+            t = torch.full((1,), float(sigma) * 1000.0, device=latents.device, dtype=torch.float32)
+            mine = self.transformer(hidden_states=latents.contiguous(), encoder_hidden_states=inp["encoder_hidden_states"][r:r + 1],
+                                    pooled_projections=inp["pooled_projections"][r:r + 1], timestep=t, return_dict=False)[0]
+            cond, uncond = self.cfg_pair.exchange(mine)
+            v = torch.cat([uncond, cond], dim=0).float()
+        else:
+            t = torch.full((2,), float(sigma) * 1000.0, device=latents.device, dtype=torch.float32)
+            v = self.transformer(hidden_states=latents.expand(2, -1, -1, -1).contiguous(), encoder_hidden_states=inp["encoder_hidden_states"],
+                                 pooled_projections=inp["pooled_projections"], timestep=t, return_dict=False)[0].float()
         noise = v[0:1] + guidance_scale * (v[1:2] - v[0:1])
         return (latents.float() + float(sigma_next - sigma) * noise).to(latents.dtype)
 
@@ -255,10 +288,11 @@ class SyntheticSDXLPipeline:
     space (sigma_t from the scaled-linear beta schedule, as EulerDiscreteScheduler does).  `use_graph=True` replays the UNet
     from a HIP graph (fastdm_amd/graph.py): the step is launch-bound."""
 
-    def __init__(self, unet, seed: int = 0, use_graph: bool = False):
+    def __init__(self, unet, seed: int = 0, use_graph: bool = False, cfg_pair=None):
         self.unet = unet
         self.seed = seed
         self.use_graph = use_graph
+        self.cfg_pair = cfg_pair        # distributed.CFGPair: each rank runs its prompt row as a batch-1 UNet forward
         self.scheduler_step_index = None
         self.num_steps = 0
         self._graph_key, self._graphed = None, None
@@ -287,6 +321,16 @@ class SyntheticSDXLPipeline:
     @torch.no_grad()
     def step(self, latents, inp, timestep, sigma, sigma_next, guidance_scale):
         x = (latents.float() / ((sigma ** 2 + 1.0) ** 0.5)).to(latents.dtype)              # scale_model_input
+        if self.cfg_pair is not None:
+            r = 1 - self.cfg_pair.role                                   # prompt row: 1 = conditional, 0 = unconditional
+            if getattr(self, "_row_inp", None) is None or self._row_inp[0] is not inp:
+                self._row_inp = (inp, {"encoder_hidden_states": inp["encoder_hidden_states"][r:r + 1].contiguous(),
+                                       "added_cond_kwargs": {k: v[r:r + 1].contiguous() for k, v in inp["added_cond_kwargs"].items()}})
+            mine = self._forward(x.contiguous(), torch.tensor(float(timestep), device=latents.device), self._row_inp[1])
+            cond, uncond = self.cfg_pair.exchange(mine)
+            eps = torch.cat([uncond, cond], dim=0).float()
+            noise = eps[0:1] + guidance_scale * (eps[1:2] - eps[0:1])
+            return (latents.float() + float(sigma_next - sigma) * noise).to(latents.dtype)
         eps = self._forward(x.expand(2, -1, -1, -1).contiguous(), torch.tensor(float(timestep), device=latents.device), inp).float()
         noise = eps[0:1] + guidance_scale * (eps[1:2] - eps[0:1])
         return (latents.float() + float(sigma_next - sigma) * noise).to(latents.dtype)

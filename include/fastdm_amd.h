@@ -38,7 +38,8 @@ enum {
 
 int fdm_version(void);
 const char* fdm_error_string(int code);
-/* HIP runtime message behind the most recent FDM_ERR_LAUNCH returned to this process. */
+/* HIP runtime message behind the most recent FDM_ERR_LAUNCH returned to the CALLING THREAD (the library keeps no other
+ * mutable state: per-device constants are cached per device id, and no environment variable changes what a kernel does). */
 const char* fdm_last_hip_error_string(void);
 
 /* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
@@ -83,7 +84,7 @@ int fdm_gelu_and_mul(void* out, const void* in, int64_t rows, int d, fdm_stream_
 
 /* ---- replaces cuda_ops.fp8_scaled_mm_ (torch_bindings.cpp:24-84; csrc/gemm/hopper_w8a8_fp8.cu) -
  * out[M,N] (bf16, row stride ldc) = epi( acc_f32(A[M,K] fp8 row-major lda  x  B[K,N] fp8 column-
- * major ldb) * sa[M] * sb[N] + bias[N] ).  K % 16 == 0, N % 16 == 0.  bias may be NULL.
+ * major ldb) * sa[M] * sb[N] + bias[N] ).  K % 16 == 0, N % 8 == 0 (the check in fill_problem; 16-byte output rows).  bias may be NULL.
  * epi_gate / epi_res [M,N] (row stride ldc; may alias out) are only read for
  * FDM_EPI_GATE_RESIDUAL; gate is indexed as gate[(m / epi_rows_per_batch) * epi_gate_stride + n]. */
 int fdm_gemm_w8a8_fp8(void* out, const void* a, const void* b, const float* scale_a,
@@ -168,7 +169,8 @@ int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v,
                  int64_t o_tok_stride, float scale,
                  const int8_t* block_mask, int block_q, int block_k,
                  void* workspace, int64_t workspace_bytes, fdm_stream_t stream);
-/* Optional scratch for fdm_attn_fwd (NULL / 0 = never split): when the last round of equal-sized q-block work
+/* Optional scratch for fdm_attn_fwd (NULL = never split; a non-NULL workspace that is not 16-byte aligned is
+ * FDM_ERR_INVALID, never a silent fall-back): when the last round of equal-sized q-block work
  * items would fill less than half the chip, those items are split along KV and merged (split-KV tail
  * balancing).  Returns the number of bytes that is always sufficient for the given head_dim.                 */
 int64_t fdm_attn_fwd_workspace_bytes(int head_dim);

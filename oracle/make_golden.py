@@ -1027,12 +1027,118 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
     use_backend("torch")
     return results
 
+def gen_c3_traj(n_double, n_single, tag, n_steps=4, attention="ref", img_h=64, img_w=128, n_txt=512, seed=0, sub=8):
+    """A multi-step TRAJECTORY of the full-width, full-depth C3 denoise loop through the reference's own block classes
+    (north_star: tolerance on FINAL latents): the first `n_steps` steps of the 25-step flow-match schedule with the Euler
+    update of pipeline.py / bench.py, `timestep = sigma` in bf16, guidance 3.5.  Unlike gen_c3 the (quantised) blocks stay
+    resident across the steps (12 GB fp8 / 24 GB bf16).
+
+    attention='ref'  : the reference torch backend as is (torch SDPA, bf16, CPU flash kernel)
+    attention='fp32' : the SAME reference model with its attention operator replaced by the oracle's fp32-score /
+                       fp32-softmax restatement (oracle/ops.py) -- the A/B control: two legitimate implementations of the
+                       reference's attention contract; their distance after n_steps bounds what a third (the HIP kernel)
+                       may differ by."""
+    reg = import_reference()
+    from oracle import flux as OF
+    from oracle import ops as OO
+    from fastdm.model.flux import FluxTransformer2DModelCore, FluxTransformerBlock, FluxSingleTransformerBlock
+    import contextlib
+    import io
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from fastdm_amd.pipeline import flow_match_sigmas
+    cfg = OF.FluxConfig(num_layers=n_double, num_single_layers=n_single)
+    inp = OF.synth_inputs(cfg, 1, img_h, img_w, n_txt, seed)
+    sig = flow_match_sigmas(25, img_h * img_w)
+    t0 = time.time()
+    qt = {"bf16": None, "fp8": torch.float8_e4m3fn, "int8": torch.int8}[tag]
+    use_backend("cpu_fp8" if tag == "fp8" else "torch")
+    attn_key, saved_attn = "sdpa", None          # fastdm/kernel/torch/attention.py:7 registers the op as 'sdpa'
+    if attention == "fp32":
+        saved_attn = dict(reg._registry[attn_key])
+
+        def attn_fp32(query, key, value, num_q_heads, num_kv_heads, head_dim, is_causal=False, scale=None):
+            return OO.scaled_dot_product_attention(query, key, value, num_q_heads, num_kv_heads, head_dim, is_causal=is_causal, scale=scale)
+        for b in list(reg._registry[attn_key]):
+            reg._registry[attn_key][b] = attn_fp32
+
+    def specs_with_prefix(prefix):
+        return [(n, s_, k) for n, s_, k in OF.param_specs(OF.FluxConfig()) if n.startswith(prefix)]
+
+    def load_part(core, names_map, loader):
+        sd = {}
+        for name, shape, kind in names_map:
+            sd[name[1]] = OF.synth_tensor(name[0], shape, kind, seed)
+        core.origin_tensor_dict = sd
+        core.unmatched_tensors = list(sd.keys())
+        core.device, core.dtype = "cpu", torch.bfloat16
+        with contextlib.redirect_stdout(io.StringIO()):
+            loader()
+        assert len(core.unmatched_tensors) == 0, core.unmatched_tensors
+        core.origin_tensor_dict = {}
+
+    core = FluxTransformer2DModelCore(num_layers=1, num_single_layers=1, quant_dtype=qt)
+    pre = [((n, n), s_, k) for n, s_, k in OF.param_specs(OF.FluxConfig()) if n.startswith(("time_text_embed", "context_embedder", "x_embedder"))]
+    post = [((n, n), s_, k) for n, s_, k in OF.param_specs(OF.FluxConfig()) if n.startswith(("norm_out", "proj_out"))]
+    load_part(core, pre, core._pre_part_loading)
+    load_part(core, post, core._post_part_loading)
+    doubles, singles = [], []
+    for i in range(n_double):
+        names = [((n, n.replace(f"transformer_blocks.{i}.", "transformer_blocks.0.")), s_, k) for n, s_, k in specs_with_prefix(f"transformer_blocks.{i}.")]
+        core.transformer_blocks = [FluxTransformerBlock(dim=cfg.inner_dim, num_attention_heads=cfg.num_attention_heads,
+                                                        attention_head_dim=cfg.attention_head_dim, data_type=torch.bfloat16)]
+        load_part(core, names, core._FluxTransformer2DModelCore__transformer_block_loading)
+        doubles.append(core.transformer_blocks[0])
+    for i in range(n_single):
+        names = [((n, n.replace(f"single_transformer_blocks.{i}.", "single_transformer_blocks.0.")), s_, k)
+                 for n, s_, k in specs_with_prefix(f"single_transformer_blocks.{i}.")]
+        core.single_transformer_blocks = [FluxSingleTransformerBlock(dim=cfg.inner_dim, num_attention_heads=cfg.num_attention_heads,
+                                                                     attention_head_dim=cfg.attention_head_dim, data_type=torch.bfloat16)]
+        load_part(core, names, core._FluxTransformer2DModelCore__single_trans_block_loading)
+        singles.append(core.single_transformer_blocks[0])
+    print(f"[{tag}/{attention}] {n_double}+{n_single} blocks resident  t={time.time() - t0:.0f}s", flush=True)
+
+    d = {}
+    lat = inp["hidden_states"].clone()
+    with torch.no_grad():
+        ids = torch.cat((inp["txt_ids"], inp["img_ids"]), dim=0)
+        rc, rs = core.pos_embed.forward(ids)
+        rope = torch.cat((rc[:, 0::2], rs[:, 1::2]), dim=-1).to(torch.bfloat16)
+        for step in range(n_steps):
+            hidden = core.x_embedder.forward(lat)
+            ts = torch.tensor([float(sig[step])]).to(hidden.dtype) * 1000
+            gd = torch.tensor([3.5]).to(hidden.dtype) * 1000
+            temb = core.time_text_embed.forward(ts, gd, inp["pooled_projections"])
+            encoder = core.context_embedder.forward(inp["encoder_hidden_states"])
+            for blk in doubles:
+                encoder, hidden = blk.forward(hidden_states=hidden, encoder_hidden_states=encoder, temb=temb, image_rotary_emb=rope)
+            x = torch.cat([encoder, hidden], dim=1)
+            for blk in singles:
+                x = blk.forward(hidden_states=x, temb=temb, image_rotary_emb=rope)
+            out = core.proj_out.forward(core.norm_out.forward(x[:, n_txt:], temb))
+            lat = (lat.float() + float(sig[step + 1] - sig[step]) * out.float()).to(torch.bfloat16)
+            last = step == n_steps - 1
+            d[f"out_s{step}"] = out if last else out[:, ::sub].clone()
+            d[f"lat_s{step}"] = lat if last else lat[:, ::sub].clone()
+            print(f"[{tag}/{attention}] step {step} sigma {sig[step]:.4f} done  t={time.time() - t0:.0f}s  |out|={out.float().abs().mean():.4f} "
+                  f"|lat|={lat.float().abs().mean():.4f}", flush=True)
+    meta = {"seed": seed, "img_h": img_h, "img_w": img_w, "n_txt": n_txt, "sub": sub, "n_double": n_double, "n_single": n_single,
+            "n_steps": n_steps, "guidance": 3.5, "schedule_steps": 25}
+    d.update({f"meta_{k}": v for k, v in meta.items()})
+    d["sigmas"] = torch.from_numpy(sig[: n_steps + 1].copy())
+    save(f"flux_c3_traj_{tag}_{attention}_{n_double}x{n_single}_{n_steps}steps.npz", d)
+    if saved_attn is not None:
+        reg._registry[attn_key].update(saved_attn)
+    use_backend("torch")
+    return d
+
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3", "c3_traj", "radial_full"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
+    ap.add_argument("--steps", type=int, default=4, help="c3_traj: denoise steps of the 25-step schedule")
+    ap.add_argument("--attention", nargs="+", default=["ref"], help="c3_traj: 'ref' (reference torch backend) and / or 'fp32' (A/B control)")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     if args.what in ("small", "ops"):
@@ -1071,6 +1177,12 @@ def main():
         gen_sd3_full()
     if args.what == "c3":
         gen_c3(args.blocks[0], args.blocks[1], args.quant)
+    if args.what == "c3_traj":
+        for tag in args.quant:
+            for att in args.attention:
+                gen_c3_traj(args.blocks[0], args.blocks[1], tag, n_steps=args.steps, attention=att)
+    if args.what == "radial_full":
+        gen_radial_full()
 
 
 if __name__ == "__main__":

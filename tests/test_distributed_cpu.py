@@ -58,3 +58,116 @@ def test_single_process_is_identity():
     from fastdm_amd import distributed as D
     x = torch.randn(2, 5, 3)
     assert D.gather_latents(x, 2, 0, 1) is x and D.shard_indices(5, 1, 2) == [1, 3] and D.max_over_ranks(3.0, "cpu") == 3.0
+
+
+# ---------------------------------------------------------------------------------------------- CFG-pair protocol (gloo)
+class _StubTransformer:
+    """A deterministic stand-in for the wrapper surface the pipelines touch (the product path has no CPU kernels): the
+    'noise prediction' is a fixed nonlinear function of (latents, prompt, t), so the pair protocol -- who runs which
+    forward, what is gathered, in which order it is combined -- is checked bit for bit without a GPU."""
+
+    class core_model:          # noqa: N801 -- attribute lookups only
+        cache = None
+
+    def __init__(self):
+        self.calls = []
+
+    from contextlib import contextmanager
+
+    @contextmanager
+    def cache_context(self, name):
+        self.calls.append(name)
+        yield
+
+    def __call__(self, hidden_states=None, timestep=None, encoder_hidden_states=None, **_):
+        if hidden_states is None:
+            raise AssertionError("stub: hidden_states missing")
+        e = encoder_hidden_states.float().mean(dim=1, keepdim=True)[..., : hidden_states.shape[-1]]
+        out = torch.tanh(hidden_states.float() * 1.7 + e) * (0.5 + timestep.float().reshape(-1, 1, 1))
+        return (out.to(hidden_states.dtype),)
+
+
+def _qwen_like_inputs(image):
+    g = torch.Generator().manual_seed(1000 + image)
+    return {"hidden_states": torch.randn(1, 12, 8, generator=g).to(torch.bfloat16),
+            "encoder_hidden_states": torch.rand(1, 5, 8, generator=g).to(torch.bfloat16),
+            "negative_encoder_hidden_states": torch.rand(1, 5, 8, generator=g).to(torch.bfloat16),
+            "encoder_hidden_states_mask": torch.ones(1, 5, dtype=torch.int64), "img_shapes": [[(1, 3, 4)]], "txt_seq_lens": [5]}
+
+
+def _qwen_denoise(pipe, image, steps=3):
+    import numpy as np
+    inp = _qwen_like_inputs(image)
+    lat = inp["hidden_states"].clone()
+    sig = np.linspace(1.0, 0.0, steps + 1).astype(np.float32)
+    for i in range(steps):
+        lat = pipe.step(lat, inp, sig[i], sig[i + 1], 4.0)
+    return lat
+
+
+def _pair_worker(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from fastdm_amd import distributed as D
+    from fastdm_amd.pipeline import SyntheticQwenPipeline
+    r, w, _ = D.init_from_env(backend="gloo")
+    pair = D.make_cfg_pairs(r, w)
+    assert pair.role == r % 2 and pair.image_index == r // 2
+    stub = _StubTransformer()
+    lat = _qwen_denoise(SyntheticQwenPipeline(stub, cfg_pair=pair), pair.image_index)
+    full = D.gather_pair_latents(lat, pair, r, w)
+    q.put((rank, full.float().tolist(), sorted(set(stub.calls))))
+    torch.distributed.destroy_process_group()
+
+
+def _run_pairs(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pair_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from fastdm_amd.pipeline import SyntheticQwenPipeline
+    want = torch.cat([_qwen_denoise(SyntheticQwenPipeline(_StubTransformer()), i) for i in range(world // 2)], dim=0).float().tolist()
+    for rank, full, calls in res:
+        assert full == want, f"rank {rank}: CFG-pair latents differ from the single-process two-forward loop"
+        assert calls == (["cond"] if rank % 2 == 0 else ["uncond"]), (rank, calls)     # each member runs ONE branch only
+
+
+def test_cfg_pair_matches_two_forward_loop_world2():
+    _run_pairs(2)
+
+
+def test_two_cfg_pairs_world4():
+    _run_pairs(4)
+
+
+def test_cfg_pair_guards():
+    import pytest
+    from fastdm_amd import distributed as D
+    from fastdm_amd.pipeline import SyntheticQwenPipeline
+    assert D.make_cfg_pairs(0, 1) is None
+    with pytest.raises(ValueError, match="even number"):
+        D.make_cfg_pairs(0, 3)
+    with pytest.raises(ValueError, match="role"):
+        D.CFGPair(2)
+    with pytest.raises(ValueError, match="batch_cfg"):
+        SyntheticQwenPipeline(_StubTransformer(), batch_cfg=True, cfg_pair=D.CFGPair(0))
+    from fastdm_amd.caching import AutoCache
+    c = AutoCache.from_dict({"cache_algorithm": "teacache", "enable_caching": True, "threshold": 0.1, "negtive_cache": True,
+                             "coefficients": [1.0, 0.0], "negtive_coefficients": [1.0, 0.0]})
+    assert [c.get_cache_key() for _ in range(4)] == ["positive", "negative", "positive", "negative"]
+    c.pin_key("negative")
+    assert [c.get_cache_key() for _ in range(3)] == ["negative"] * 3
+    with pytest.raises(ValueError, match="ceil"):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+            dist.init_process_group("gloo", rank=0, world_size=1)
+        try:
+            D.gather_latents(torch.zeros(2, 3), 1, 0, 1)
+        finally:
+            dist.destroy_process_group()

@@ -1,0 +1,54 @@
+"""Multi-process runs of the denoise paths on real devices, each checked bit for bit against the
+single-process loop inside tests/multigpu_worker.py:
+
+* image sharding (ragged: 3 images on 2 ranks) + the single all-gather of final latents;
+* the CFG-pair split (one rank runs the conditional, the other the unconditional forward; one all-gather of the two noise
+  predictions per step) for Qwen-Image, with and without TeaCache (per-branch decisions equal the single-GPU trace), and
+  for SD3.5 (each rank one row of the batch-2 forward).
+
+`*_one_device` variants put both ranks on cuda:0 over gloo, so the protocol is exercised on a 1-GPU box; the `*_rccl`
+variants need two GPUs and run over RCCL / xGMI.  The worker is a separate process tree started before anything touches
+the GPU there (the reference forks a process per GPU the same way, examples/evaluation/clip_score.py:346-365)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "multigpu_worker.py")
+MODES = ["flux_shard", "qwen_pair", "qwen_pair_teacache", "sd3_pair"]
+
+
+def _run(mode, *extra):
+    res = subprocess.run([sys.executable, WORKER, "--mode", mode, *extra], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "MULTIGPU_OK" in res.stdout, f"{mode} {extra}:\n{res.stdout[-2000:]}\n{res.stderr[-4000:]}"
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_two_ranks_one_device_gloo(mode):
+    _run(mode, "--world", "2", "--backend", "gloo", "--same-device")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL)")
+@pytest.mark.parametrize("mode", MODES)
+def test_two_ranks_rccl(mode):
+    _run(mode, "--world", "2", "--backend", "nccl")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 4, reason="needs 4 GPUs (two CFG pairs)")
+def test_two_cfg_pairs_rccl():
+    _run("qwen_pair", "--world", "4", "--backend", "nccl")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` as a plain command: one JSON line from rank 0, n_gpus = ranks seen by RCCL."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=1800)
+    assert res.returncode == 0, res.stderr[-4000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_in_process_group"] == 2 and line["value"] > 0

@@ -5,7 +5,7 @@
 #include ATTN_SRC
 #include <cstdio>
 #include <vector>
-namespace fdm { bool g_fp8_sw_cvt = false; int g_last_hip_error = 0; }
+namespace fdm { thread_local int g_last_hip_error = 0; int device_cu_count() { return 256; } }
 
 int main(int argc, char** argv) {
   struct Shape { int64_t B, S, H, D; };
