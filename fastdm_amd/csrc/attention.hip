@@ -35,6 +35,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #ifndef FDM_ATT_PRIO_PV
 #define FDM_ATT_PRIO_PV 0
 #endif
+// 1: the dense head_dim-128 path runs attn_fwd64_kernel (64 query rows per wave, one wave per SIMD); 0: attn_fwd_kernel
+#ifndef FDM_ATT_V2
+#define FDM_ATT_V2 1
+#endif
 #ifndef FDM_ATT_THREADS
 #define FDM_ATT_THREADS 512
 #endif
@@ -394,6 +398,445 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
   }
 }
 
+
+// ================================================================================================================
+// Dense path, head_dim 128: 64 query rows per wave, ONE wave per SIMD.
+//
+//   block     256 threads = 4 waves, one 256-row Q block of one (batch, head); wave w owns rows [64w, 64w+64) as two
+//             32-row q-blocks.  __launch_bounds__(256, 1): the wave has the whole 512-entry register file:
+//             accumulation registers  O (128) + pre-scaled Q fragments (64) + K / V^T fragments in flight,
+//             vector registers        two S tiles (128) + row-reference tiles (32) + packed P (32) + addresses.
+//   why       with 32 rows per wave every MFMA needs its own 1 KB LDS fragment and two waves share a SIMD, whose VALU
+//             (softmax) and MFMA streams do not overlap (measured: 743 cycles for what one interleaved wave does in
+//             551).  Here each K / V^T fragment feeds TWO MFMAs and one wave carries three strands -- QK^T of tile t+1,
+//             exp2 / row sums of tile t, P.V of tile t -- interleaved MFMA gap by MFMA gap.
+//   schedule  hipcc left alone moves whole tiles between the two register classes (2300 v_accvgpr moves), so the MFMAs
+//             are inline asm with fixed classes and the issue order is pinned with sched_barrier(0) per MFMA gap:
+//             gap = 1 MFMA + <= 1 v_exp_f32 + a few plain VALU + <= 2 LDS reads (or one LDS-DMA).
+//   softmax   Q is pre-scaled by scale*log2(e) once per block and the S^T accumulators START at -m_ref[q] (the C operand
+//             of the first MFMA of a tile is a register tile holding the row reference), so P = exp2(S') needs no
+//             per-element FMA.  m_ref = (row max at the last fix-up) + 7: P <= 2 between fix-ups.  The row max of tile
+//             t+1 is taken under the P.V MFMAs of tile t; only if some row's S' reaches 1 (its scores grew by 2^8 since
+//             the last fix-up), on the first tile and on a masked tail tile does the wave take the fix-up path
+//             (integer shift delta: S' -= delta, O and l scaled by 2^-delta -- exact -- and the reference tile rewritten).
+//   K/V       64-key tiles in a 4-stage LDS ring (128 KiB), LDS-DMA three tiles ahead (wave-uniform base + 32-bit lane
+//             offset: no VALU address math), ONE barrier per tile behind a counted vmcnt(8).
+//   hazards   (the assembler pads nothing inside asm)  VALU-written P -> MFMA operand: s_nop 1 in the first MFMA of a
+//             P.V group; MFMA result -> VALU: S tiles are read one phase after they were written and pass through an
+//             ordering asm behind the P.V MFMAs; O is read by VALU only in the fix-up path / epilogue, behind >= 16
+//             other instructions.
+template <int I>
+using ic = std::integral_constant<int, I>;
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(ic<I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+#define FDM_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int D>
+__global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) {
+  static_assert(D == 128, "64-row kernel: head_dim 128");
+  constexpr int KT = 64, NST = 4, CPR = D / 8;
+  constexpr uint32_t ROWB = D * 2;
+  constexpr int TILE_BYTES = KT * D * 2;   // 16 KiB: one K or V tile
+  constexpr int V_RING = NST * TILE_BYTES; // smem = [K ring: 4 tiles][V ring: 4 tiles]
+  constexpr int KSTEPS = D / 16, DT = D / 32;
+  constexpr int QBT = 256;
+  __shared__ __attribute__((aligned(1024))) uint8_t smem[2 * NST * TILE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 31, h = lane >> 5;
+
+  const int BH = p.batch * p.heads;
+  int item = blockIdx.x, part = 0;
+  const bool is_part = item >= p.n_full;
+  if (is_part) {
+    part = (item - p.n_full) % p.split;
+    item = p.n_full + (item - p.n_full) / p.split;
+  }
+  const int xcd = item & 7, j = item >> 3;
+  const int bh = xcd + 8 * (j / p.n_qblocks);
+  if (bh >= BH) return;
+  const int qb_idx = j % p.n_qblocks;
+  const int b = bh / p.heads, head = bh % p.heads;
+  const int kvh = head / (p.heads / p.kv_heads);
+  const int64_t q0 = (int64_t)qb_idx * QBT;
+
+  const bf16_t* qbase = p.q + ((int64_t)b * p.sq) * p.q_ts + (int64_t)head * D;
+  const uint8_t* kbase = reinterpret_cast<const uint8_t*>(p.k + ((int64_t)b * p.sk) * p.k_ts + (int64_t)kvh * D);
+  const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v + ((int64_t)b * p.sk) * p.v_ts + (int64_t)kvh * D);
+
+  const int ntiles = (int)((p.sk + KT - 1) / KT);
+  const int t_begin = is_part ? (int)((int64_t)part * ntiles / p.split) : 0;
+  const int t_end = is_part ? (int)((int64_t)(part + 1) * ntiles / p.split) : ntiles;
+
+  // ---- K/V staging by LDS-DMA: lane-linear destination, swizzle on the source side (as in attn_fwd_kernel).  The source
+  //      is a wave-uniform tile base (SALU) plus a 32-bit per-lane offset that never changes; the rows of a partial last
+  //      tile are clamped through a second offset set (rows past the end re-read the last key: masked later).
+  //      Ring slot of tile t = (t - t_begin) % 4: a compile-time constant in the 4x unrolled loop.
+  uint32_t kofs[4], vofs[4], kofs_t[4], vofs_t[4];
+  {
+    const int last_rows = (int)(p.sk - (int64_t)(ntiles - 1) * KT);   // 1..64 valid rows in the last tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pslot = tid + i * 256;
+      const int r = pslot / CPR, pos = pslot % CPR;
+      const int rc = r < last_rows ? r : last_rows - 1;
+      kofs[i] = (uint32_t)(r * p.k_ts * 2 + Swz<D>::k(r, pos) * 16);
+      vofs[i] = (uint32_t)(r * p.v_ts * 2 + Swz<D>::v(r, pos) * 16);
+      kofs_t[i] = (uint32_t)(rc * p.k_ts * 2 + Swz<D>::k(r, pos) * 16);
+      vofs_t[i] = (uint32_t)(rc * p.v_ts * 2 + Swz<D>::v(r, pos) * 16);
+    }
+  }
+  // DMA piece i (0..3) of the K (V) tile t into ring slot `slot`
+  auto dma_k = [&](int t, int slot, auto idx) {
+    constexpr int I = decltype(idx)::value;
+    const int tc = t < ntiles - 1 ? t : ntiles - 1;
+    const uint8_t* src = kbase + (int64_t)tc * KT * p.k_ts * 2;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (tc == ntiles - 1 ? kofs_t[I] : kofs[I])),
+                                     (__attribute__((address_space(3))) void*)(smem + slot * TILE_BYTES + wave * 1024 + I * 4096), 16, 0, 0);
+  };
+  auto dma_v = [&](int t, int slot, auto idx) {
+    constexpr int I = decltype(idx)::value;
+    const int tc = t < ntiles - 1 ? t : ntiles - 1;
+    const uint8_t* src = vbase + (int64_t)tc * KT * p.v_ts * 2;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (tc == ntiles - 1 ? vofs_t[I] : vofs[I])),
+                                     (__attribute__((address_space(3))) void*)(smem + V_RING + slot * TILE_BYTES + wave * 1024 + I * 4096), 16, 0, 0);
+  };
+  static_for<4>([&](auto s_) { static_for<4>([&](auto i) { dma_k(t_begin + decltype(s_)::value, decltype(s_)::value, i); }); });
+  static_for<3>([&](auto s_) { static_for<4>([&](auto i) { dma_v(t_begin + decltype(s_)::value, decltype(s_)::value, i); }); });
+
+  // ---- Q fragments, pre-scaled by scale * log2(e) (one extra bf16 rounding of q), parked in accumulation registers
+  i32x4 qa[2][KSTEPS];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    int64_t qrow = q0 + wave * 64 + qb * 32 + lq;
+    if (qrow > p.sq - 1) qrow = p.sq - 1;
+    const bf16_t* qp = qbase + qrow * p.q_ts + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      i32x4 v = *reinterpret_cast<const i32x4*>(qp + 16 * ks);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t u = (uint32_t)v[w];
+        v[w] = (int)pack2bf(__builtin_bit_cast(float, u << 16) * p.scale_log2e, __builtin_bit_cast(float, u & 0xffff0000u) * p.scale_log2e);
+      }
+      asm volatile("" : "=a"(qa[qb][ks]) : "0"(v));
+    }
+  }
+
+  // ---- state
+  f32x16 oacc[2][DT];   // accumulation registers
+  {
+    f32x16 z;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int d = 0; d < DT; ++d) asm volatile("" : "=a"(oacc[qb][d]) : "0"(z));
+  }
+  f32x16 mneg[2];       // -m_ref of this lane's query row, replicated over 16 vector registers (C operand of a tile's first MFMA)
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mneg[qb][e] = 0.f;
+    asm volatile("" : "+v"(mneg[qb]));
+  }
+  float mref[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+
+  // ---- LDS read addresses: per-lane bases (8 for the K k-steps, 4 for the V^T d-blocks); ring slot, key block and key
+  //      group are compile-time immediates of the DS instructions (no address VALU in the loop)
+  const int gi = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+  uint32_t kaddr[KSTEPS], vaddr[DT];
+  {
+    const uint32_t kld0 = lq * ROWB + (uint32_t)Swz<D>::k(lq, h) * 16;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) kaddr[ks] = smem_base + (kld0 ^ (uint32_t)(ks << 5));
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+      vaddr[d] = smem_base + V_RING + (4 * h + tq) * ROWB + (uint32_t)Swz<D>::v(4 * h + tq, d * 4 + 2 * (gi & 1) + (tp >> 1)) * 16 + 8 * (tp & 1);
+  }
+  // Fragment reads are inline asm: their lgkmcnt waits are COUNTED by hand below (the compiler's own waits drain to
+  // lgkmcnt(0) in front of every MFMA), so every LDS read of the loop must be one of these two.
+  i32x4 kf[4];   // K fragment f lives in kf[f % 4]: three fragments in flight
+#define FDM_READ_K(SLOT, F)                                                                                       \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(kf[(F) & 3]) : "v"(kaddr[(F) & 7]),                          \
+               "i"((SLOT) * TILE_BYTES + ((F) >> 3) * 32 * (int)ROWB) : FDM_VREGS)
+#define FDM_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory", FDM_VREGS)
+#define FDM_MFMA_S_FIRST(S, KF, QA, C) \
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(S) : "a"(KF), "a"(QA), "v"(C) : FDM_VREGS)
+#define FDM_MFMA_S_ACC(S, KF, QA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(S) : "a"(KF), "a"(QA) : FDM_VREGS)
+#define FDM_MFMA_O(O, FSET, PF) \
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c2:%c3], %1, %0" : "+a"(O) : "v"(PF), "i"(240 + 4 * (FSET)), "i"(243 + 4 * (FSET)) : FDM_VREGS)
+#define FDM_MFMA_O_PAD(O, FSET, PF) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c2:%c3], %1, %0" : "+a"(O) : "v"(PF), "i"(240 + 4 * (FSET)), "i"(243 + 4 * (FSET)) : FDM_VREGS)
+
+  // V^T fragments: a 128-bit MFMA operand filled by TWO 64-bit transposed reads.  Inline asm cannot name the halves of a
+  // tuple operand (and two 64-bit outputs are glued together with 8 v_accvgpr moves per fragment), so the four fragment
+  // sets live in accumulation registers a[240:255] that are owned by the asm statements of this kernel: every asm
+  // statement of the loop lists them as clobbers, which keeps the register allocator from parking anything there (audit:
+  // no instruction outside ASMSTART/ASMEND may touch a240..a255 -- tools/micro/audit_attn_asm.sh).
+#undef FDM_READ_V
+#define FDM_VREGS "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+#define FDM_READ_V(SLOT, F)                                                                                              \
+  asm volatile("ds_read_b64_tr_b16 a[%c1:%c2], %0 offset:%5\n\tds_read_b64_tr_b16 a[%c3:%c4], %0 offset:%6"              \
+               :: "v"(vaddr[(F) & 3]), "i"(240 + 4 * ((F) & 3)), "i"(241 + 4 * ((F) & 3)), "i"(242 + 4 * ((F) & 3)),       \
+                  "i"(243 + 4 * ((F) & 3)),                                                                               \
+                  "i"((SLOT) * TILE_BYTES + (((F) >> 3) * 32 + 16 * (((F) >> 2) & 1)) * (int)ROWB),                      \
+                  "i"((SLOT) * TILE_BYTES + (((F) >> 3) * 32 + 16 * (((F) >> 2) & 1) + 8) * (int)ROWB)                   \
+               : FDM_VREGS)
+
+  // softmax pieces of a decided S tile, element n = 0..63 in the order the P.V groups consume them:
+  // n -> group g = n>>4 (kb = g>>1, sx = g&1), qb = (n>>3)&1, r = n&7 -> register e = 8*sx + r of S[kb][qb]
+  auto sm_exp = [&](f32x16 (&S)[2][2], auto nidx) {
+    constexpr int N = decltype(nidx)::value, g = N >> 4, kb = g >> 1, sx = g & 1, qb = (N >> 3) & 1, r = N & 7, e = 8 * sx + r;
+    S[kb][qb][e] = __builtin_amdgcn_exp2f(S[kb][qb][e]);
+  };
+  auto sm_add = [&](f32x16 (&S)[2][2], auto nidx) {   // one gap after sm_exp(n): the transcendental's latency is not exposed
+    constexpr int N = decltype(nidx)::value, g = N >> 4, kb = g >> 1, sx = g & 1, qb = (N >> 3) & 1, r = N & 7, e = 8 * sx + r;
+    l_run[qb] += S[kb][qb][e];
+    asm volatile("" : "+v"(l_run[qb]));   // pins the add inside this gap (the optimiser otherwise sinks the whole sum chain below the tile)
+  };
+  auto sm_pack = [&](f32x16 (&S)[2][2], i32x4 (&pf)[2][2][2], auto nidx) {   // n odd: elements n-1, n
+    constexpr int N = decltype(nidx)::value, g = N >> 4, kb = g >> 1, sx = g & 1, qb = (N >> 3) & 1, r = N & 7, e = 8 * sx + r;
+    pf[kb][qb][sx][r >> 1] = (int)pack2bf(S[kb][qb][e - 1], S[kb][qb][e]);
+    asm volatile("" : "+v"(pf[kb][qb][sx][r >> 1]));
+  };
+  // softmax slot q of a step (q = 0..63): exp of element q, add of element q-1, pack of the pair ending at q-2
+  auto sm_slot = [&](f32x16 (&S)[2][2], i32x4 (&pf)[2][2][2], auto qidx) {
+    constexpr int Q = decltype(qidx)::value;
+    if constexpr (Q < 64) sm_exp(S, ic<(Q < 64 ? Q : 0)>{});
+    if constexpr (Q >= 1 && Q <= 64) sm_add(S, ic<(Q >= 1 && Q <= 64 ? Q - 1 : 0)>{});
+    if constexpr (Q >= 3 && Q <= 65 && ((Q - 2) & 1)) sm_pack(S, pf, ic<(Q >= 3 && Q <= 65 ? Q - 2 : 1)>{});
+  };
+
+  // Fix-up path (rare): move the row references.  first: the references are not set yet (O = l = 0).
+  auto fixup = [&](f32x16 (&S)[2][2], const float (&mx)[2], bool first) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float delta = __builtin_ceilf(mx[qb] + 7.0f);              // integer: every rescale below is a power of two (exact)
+      if (!first) delta = fmaxf(delta, 0.f);
+      if (!(mx[qb] > -3.0e38f)) delta = 0.f;                     // a fully masked row keeps its reference
+      const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+      mref[qb] += delta;
+      l_run[qb] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[kb][qb][e] -= delta;
+      if (!first) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          f32x16 v;
+          asm volatile("s_nop 7\n\ts_nop 7" : "=v"(v) : "0"(oacc[qb][d]));   // MFMA result -> VALU read: pad (nothing inside asm is padded)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] *= alpha;
+          asm volatile("" : "=a"(oacc[qb][d]) : "0"(v));
+        }
+      }
+      f32x16 mn;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mn[e] = -mref[qb];
+      asm volatile("" : "=v"(mneg[qb]) : "0"(mn));               // keep 16 live registers: an MFMA's C operand cannot broadcast one
+    }
+  };
+  // decision for tile t: tail masking and the wave-wide vote on the row maxima mx (of S' = scores - reference)
+  auto decide = [&](f32x16 (&S)[2][2], float (&mx)[2], int t, bool first, bool have_mx) {
+    const bool tail = (t == ntiles - 1) && (p.sk % KT != 0);
+    if (tail) {
+      const int rem = (int)(p.sk - (int64_t)t * KT) - 4 * h;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (kb * 32 + (e & 3) + 8 * (e >> 2) >= rem) S[kb][qb][e] = -INFINITY;
+    }
+    if (tail || !have_mx) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        float m = fmaxf(S[0][qb][0], S[1][qb][0]);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int e = 1; e < 16; ++e) m = __builtin_amdgcn_fmed3f(m, S[kb][qb][e], __builtin_inff());
+        mx[qb] = m;
+      }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {   // the other half of the query row
+      const int mi = __builtin_bit_cast(int, mx[qb]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mi, mi, false, false);
+      mx[qb] = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    }
+    if (first || tail || __any(fmaxf(mx[0], mx[1]) >= 1.0f)) fixup(S, mx, first);
+  };
+
+  // One pipeline step for tile t (relative index I = (t - t_begin) % 4 fixes every ring slot at compile time):
+  //   phase A   32 QK^T MFMAs of tile t+1 (-> Sn)  | exp2 / sums / packs 0..41 of tile t (Sc) | K DMAs of tile t+4
+  //   barrier   (one per tile) behind a counted vmcnt: K(t+2), V(t+1) and older have landed; newer DMAs stay in flight
+  //   phase B   32 P.V MFMAs of tile t             | softmax 42..63 | row maxima of Sn | V DMAs of tile t+3
+  // Fragment reads run three fragments ahead and cross the phase boundaries (V^T 0..2 are read under the last QK^T
+  // MFMAs, the next tile's K 0..2 under the last P.V MFMAs), so no phase starts on an exposed LDS latency.
+  auto step = [&](f32x16 (&Sc)[2][2], f32x16 (&Sn)[2][2], int t, auto iidx) {
+    constexpr int I = decltype(iidx)::value;
+    constexpr int KS1 = (I + 1) & 3, KS2 = (I + 2) & 3, VS0 = I & 3;   // ring slots: K(t+1), K(t+2), V(t)
+    i32x4 pf[2][2][2];   // [kb][qb][sx]
+    // ---- phase A
+    static_for<32>([&](auto g_) {
+      constexpr int G = decltype(g_)::value, F = G >> 1, kb = G >> 4, ks = (G >> 1) & 7, qb = G & 1;
+      auto& qa_ = qa;
+      auto& mneg_ = mneg;
+      if constexpr ((G & 1) == 0) {
+        if constexpr (F + 3 < 16) FDM_READ_K(KS1, (F + 3 < 16 ? F + 3 : 0));
+        else FDM_READ_V(VS0, (F + 3 - 16 >= 0 ? F + 3 - 16 : 0));
+        // reads issued after fragment F's: K fragments count 1, V^T fragments 2
+        constexpr int newer = F <= 12 ? 3 : (F == 13 ? 4 : (F == 14 ? 5 : 6));
+        FDM_LGKM(newer);
+      }
+      if constexpr (ks == 0) FDM_MFMA_S_FIRST(Sn[kb][qb], kf[F & 3], qa_[qb][ks], mneg_[qb]);
+      else FDM_MFMA_S_ACC(Sn[kb][qb], kf[F & 3], qa_[qb][ks]);
+      // softmax slots 0..41 over the 32 gaps (21 per 16 gaps)
+      constexpr int q0_ = (G * 21) / 16, q1_ = ((G + 1) * 21) / 16;
+      sm_slot(Sc, pf, ic<q0_>{});
+      if constexpr (q1_ - q0_ == 2) sm_slot(Sc, pf, ic<q0_ + 1>{});
+      if constexpr ((G & 7) == 4) dma_k(t + 4, I & 3, ic<(G >> 3)>{});
+      FDM_FENCE();
+    });
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // K(t+2), V(t+1) and older have landed; K(t+3), V(t+2), K(t+4) stay in flight
+    __builtin_amdgcn_s_barrier();
+    FDM_FENCE();
+    // ---- phase B
+    float mxa[2][2];
+    static_for<32>([&](auto g_) {
+      constexpr int G = decltype(g_)::value, F = G >> 1, grp = G >> 3, kb = grp >> 1, sx = grp & 1, d = (G >> 1) & 3, qb = G & 1;
+      auto& oacc_ = oacc;
+      if constexpr ((G & 1) == 0) {
+        if constexpr (F + 3 < 16) FDM_READ_V(VS0, (F + 3 < 16 ? F + 3 : 0));
+        else FDM_READ_K(KS2, (F + 3 - 16 >= 0 ? F + 3 - 16 : 0));
+        constexpr int newer = F <= 12 ? 6 : (F == 13 ? 5 : (F == 14 ? 4 : 3));
+        FDM_LGKM(newer);
+      }
+      if constexpr ((G & 7) == 0) FDM_MFMA_O_PAD(oacc_[qb][d], F & 3, pf[kb][qb][sx]);
+      else FDM_MFMA_O(oacc_[qb][d], F & 3, pf[kb][qb][sx]);
+      if constexpr (G < 24) sm_slot(Sc, pf, ic<(G < 24 ? 42 + G : 0)>{});   // slots 42..65 (the last two only add / pack): group 3's last pack is
+                                                                             // out at gap 23, its first P.V MFMA issues at gap 24
+      if constexpr (G < 16) {
+        // row maxima of Sn (written in phase A): one chain per (q block qq, key block c), 4 gaps of 4 elements each;
+        // med3(a, b, +inf) = max(a, b) pairs fold into v_max3_f32
+        constexpr int qq = (G >> 3) & 1, c = (G >> 2) & 1, q4 = G & 3;
+        float m = q4 == 0 ? Sn[c][qq][0] : mxa[qq][c];
+#pragma unroll
+        for (int e = (q4 == 0 ? 1 : 4 * q4); e < 4 * q4 + 4; ++e) m = __builtin_amdgcn_fmed3f(m, Sn[c][qq][e], __builtin_inff());
+        mxa[qq][c] = m;
+        asm volatile("" : "+v"(mxa[qq][c]));   // pins the max chain inside this gap
+      }
+      if constexpr (G >= 24 && (G & 1) == 0) dma_v(t + 3, (I + 3) & 3, ic<((G - 24) >> 1 < 4 && G >= 24 ? (G - 24) >> 1 : 0)>{});
+      FDM_FENCE();
+    });
+    // MFMA result -> VALU read of Sn: the ordering asm keeps every reader of Sn below the P.V MFMAs above
+    asm volatile("" : "+v"(Sn[0][0]), "+v"(Sn[0][1]), "+v"(Sn[1][0]), "+v"(Sn[1][1]));
+    float mx[2] = {fmaxf(mxa[0][0], mxa[0][1]), fmaxf(mxa[1][0], mxa[1][1])};
+    if (t + 1 < t_end) decide(Sn, mx, t + 1, false, true);
+  };
+
+  f32x16 Sa[2][2], Sb[2][2];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q and the prologue tiles have landed
+  __builtin_amdgcn_s_barrier();
+  FDM_FENCE();
+  if (t_begin < t_end) {
+    // S tile of the first KV tile (ring slot 0), plain fragment reads, then the next tile's first three K fragments
+    static_for<16>([&](auto f_) {
+      constexpr int F = decltype(f_)::value, kb = F >> 3, ks = F & 7;
+      auto& qa_ = qa;
+      auto& mneg_ = mneg;
+      FDM_READ_K(0, F);
+      FDM_LGKM(0);
+      if constexpr (ks == 0) {
+        FDM_MFMA_S_FIRST(Sa[kb][0], kf[F & 3], qa_[0][ks], mneg_[0]);
+        FDM_MFMA_S_FIRST(Sa[kb][1], kf[F & 3], qa_[1][ks], mneg_[1]);
+      } else {
+        FDM_MFMA_S_ACC(Sa[kb][0], kf[F & 3], qa_[0][ks]);
+        FDM_MFMA_S_ACC(Sa[kb][1], kf[F & 3], qa_[1][ks]);
+      }
+      FDM_FENCE();
+    });
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(Sa[0][0]), "+v"(Sa[0][1]), "+v"(Sa[1][0]), "+v"(Sa[1][1]));
+    float mx[2];
+    decide(Sa, mx, t_begin, true, false);
+    FDM_FENCE();
+    FDM_READ_K(1, 0);
+    FDM_READ_K(1, 1);
+    FDM_READ_K(1, 2);
+    FDM_FENCE();
+  }
+  __builtin_amdgcn_s_barrier();   // every wave has read the first K tile: step 0 refills its ring slot
+  FDM_FENCE();
+  for (int t = t_begin; t < t_end; t += 4) {
+    step(Sa, Sb, t, ic<0>{});
+    if (t + 1 < t_end) step(Sb, Sa, t + 1, ic<1>{});
+    if (t + 2 < t_end) step(Sa, Sb, t + 2, ic<2>{});
+    if (t + 3 < t_end) step(Sb, Sa, t + 3, ic<3>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // run-ahead DMAs / fragment reads must not outlive the block
+
+  // ---- finalize
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    const int row = wave * 64 + qb * 32 + lq;
+    f32x16 o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) asm volatile("s_nop 7\n\ts_nop 7" : "=v"(o[d]) : "0"(oacc[qb][d]));
+    if (is_part) {
+      const int64_t slot = (int64_t)(blockIdx.x - p.n_full);
+      float* wo = p.ws_o + (slot * QBT + row) * D;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4 w;
+          w[0] = o[d][4 * g4]; w[1] = o[d][4 * g4 + 1]; w[2] = o[d][4 * g4 + 2]; w[3] = o[d][4 * g4 + 3];
+          *reinterpret_cast<f32x4*>(wo + 32 * d + 8 * g4 + 4 * h) = w;
+        }
+      if (h == 0) {
+        p.ws_ml[(slot * QBT + row) * 2] = t_begin < t_end ? mref[qb] : -1.0e30f;
+        p.ws_ml[(slot * QBT + row) * 2 + 1] = l_tot;
+      }
+      continue;
+    }
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const int64_t qrow = q0 + row;
+    if (qrow < p.sq) {
+      bf16_t* op = p.o + ((int64_t)b * p.sq + qrow) * p.o_ts + (int64_t)head * D;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          i32x2 w;
+          w[0] = (int)pack2bf(o[d][4 * g4] * inv, o[d][4 * g4 + 1] * inv);
+          w[1] = (int)pack2bf(o[d][4 * g4 + 2] * inv, o[d][4 * g4 + 3] * inv);
+          *reinterpret_cast<i32x2*>(op + 32 * d + 8 * g4 + 4 * h) = w;
+        }
+    }
+  }
+#undef FDM_READ_K
+#undef FDM_READ_V
+#undef FDM_LGKM
+#undef FDM_MFMA_S_FIRST
+#undef FDM_MFMA_S_ACC
+#undef FDM_MFMA_O
+#undef FDM_MFMA_O_PAD
+#undef FDM_VREGS
+}
+
 // Merge the split-KV parts of the tail q-blocks: O = sum_p 2^(m_p - M) O_p / sum_p 2^(m_p - M) l_p, M = max_p m_p.
 // One thread per (row, 8 consecutive d).
 template <int D>
@@ -530,7 +973,11 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
     if (head_dim == 128) attn_fwd_kernel<128, 256, KT_MASK><<<(unsigned)grid, 256, 0, s>>>(p);
     else attn_fwd_kernel<64, 256, KT_MASK><<<(unsigned)grid, 256, 0, s>>>(p);
   } else {
+#if FDM_ATT_V2
+    if (head_dim == 128) attn_fwd64_kernel<128><<<(unsigned)grid, 256, 0, s>>>(p);
+#else
     if (head_dim == 128) attn_fwd_kernel<128, 512, KT_DENSE><<<(unsigned)grid, 512, 0, s>>>(p);
+#endif
     else attn_fwd_kernel<64, 512, KT_MASK><<<(unsigned)grid, 512, 0, s>>>(p);    // head_dim 64: 64-key tiles measured faster
   }
   FDM_CHECK_LAUNCH();

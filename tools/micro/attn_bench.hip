@@ -1,54 +1,93 @@
-// Standalone attention micro-benchmark (compiles attention.hip directly; variants via -D macros / other source paths).
+// Standalone attention micro-benchmark + accuracy check (compiles attention.hip directly; variants via -D macros).
+//   attn_bench [check]   : timing at the FLUX / SD3.5 shapes; with `check`, sampled rows of several shapes (ragged tails,
+//                          cross-attention, a spiked key that forces the running-max fix-up mid-sequence) against an fp64 softmax.
 #ifndef ATTN_SRC
 #define ATTN_SRC "../../fastdm_amd/csrc/attention.hip"
 #endif
 #include ATTN_SRC
+#include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 namespace fdm { thread_local int g_last_hip_error = 0; int device_cu_count() { return 256; } }
 
+static uint16_t f2b(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+static float b2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint64_t rng_state = 88172645463325252ull;
+static double urand() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return ((rng_state >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+static float nrand() { return (float)(sqrt(-2.0 * log(urand())) * cos(6.283185307179586 * urand())); }
+
 int main(int argc, char** argv) {
-  struct Shape { int64_t B, S, H, D; };
-  std::vector<Shape> shapes = {{1, 8704, 24, 128}, {1, 4608, 24, 128}, {2, 4096, 24, 64}};
+  const bool check = argc > 1 && !strcmp(argv[1], "check");
+  struct Shape { int64_t B, Sq, Sk, H, D; int spike; };
+  std::vector<Shape> shapes = {{1, 8704, 8704, 24, 128, 0}, {1, 4608, 4608, 24, 128, 0}, {2, 4096, 4096, 24, 64, 0}};
+  if (check) shapes = {{1, 8704, 8704, 24, 128, 0}, {1, 8704, 8704, 24, 128, 1}, {1, 1000, 1000, 8, 128, 0}, {2, 300, 300, 3, 128, 1}, {1, 50, 50, 2, 128, 0},
+                       {1, 777, 2100, 5, 128, 1}, {1, 4608, 512, 24, 128, 0}, {1, 64, 64, 1, 128, 0}, {1, 257, 129, 2, 128, 1}, {2, 1111, 1111, 8, 64, 0}};
   const int64_t maxe = 8704 * 24 * 128 * 2;
   uint16_t *q, *k, *v, *o; void* ws;
   hipMalloc(&q, maxe * 2); hipMalloc(&k, maxe * 2); hipMalloc(&v, maxe * 2); hipMalloc(&o, maxe * 2);
   const int64_t wsb = fdm_attn_fwd_workspace_bytes(128);
   hipMalloc(&ws, wsb);
-  {
-    std::vector<uint16_t> h(maxe);
-    uint64_t x = 88172645463325252ull;
-    for (uint16_t** dst : {&q, &k, &v}) {
-      for (auto& e : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; e = (uint16_t)(0x3c00 + ((x >> 40) & 0x3ff)) ^ (uint16_t)((x >> 20) & 0x8000) ; }   // +-[0.0078, 0.0156)*... small gaussian-ish magnitudes
-      // spread exponents a little: values in +-[2^-7, 2^-6) scaled by random power 2^0..2^6
-      for (auto& e : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; e = (uint16_t)(e + (((x >> 33) % 7) << 7)); }
-      hipMemcpy(*dst, h.data(), maxe * 2, hipMemcpyHostToDevice);
-    }
-  }
+  std::vector<uint16_t> hq(maxe), hk(maxe), hv(maxe), ho(maxe);
+  for (auto* hbuf : {&hq, &hk, &hv}) for (auto& e : *hbuf) e = f2b(nrand());
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int rep = 0; rep < 2; ++rep)
+  int bad = 0;
+  for (int rep = 0; rep < (check ? 1 : 2); ++rep)
   for (auto& s : shapes) {
-    auto run = [&]() {
-      return fdm_attn_fwd(o, q, k, v, s.B, s.S, s.S, (int)s.H, (int)s.H, (int)s.D, s.H * s.D, s.H * s.D, s.H * s.D, s.H * s.D,
-                          1.0f / sqrtf((float)s.D), nullptr, 0, 0, ws, wsb, nullptr);
-    };
-    for (int i = 0; i < 3; ++i) if (run() != 0) { printf("launch failed\n"); return 1; }
-    hipDeviceSynchronize();
-    const int iters = 20;
-    hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) run();
-    hipEventRecord(e1, 0);
-    hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    ms /= iters;
-    uint64_t hsh = 1469598103934665603ull;
-    if (rep == 1) {
-      std::vector<uint16_t> hc((size_t)s.B * s.S * s.H * s.D);
-      hipMemcpy(hc.data(), o, hc.size() * 2, hipMemcpyDeviceToHost);
-      for (size_t i = 0; i < hc.size(); i += 5) hsh = (hsh ^ hc[i]) * 1099511628211ull;
+    const int64_t C = s.H * s.D;
+    std::vector<uint16_t> kq(hk.begin(), hk.begin() + s.B * s.Sk * C);
+    int spike_key = -1, spike_row = -1;
+    if (s.spike) {   // key spike_key of every head is 3 x the query row spike_row: that row's score jumps by ~3*|q|^2/sqrt(D) ~ 34 sigma mid-sequence
+      spike_key = (int)(s.Sk * 2 / 3); spike_row = (int)(s.Sq / 2);
+      for (int64_t b = 0; b < s.B; ++b) for (int64_t c = 0; c < C; ++c) kq[(b * s.Sk + spike_key) * C + c] = f2b(3.0f * b2f(hq[(b * s.Sq + spike_row) * C + c]));
     }
-    printf("attn B=%ld S=%ld H=%ld hd=%ld: %8.1f us %8.1f TF/s  hash %016llx\n", (long)s.B, (long)s.S, (long)s.H, (long)s.D, ms * 1e3,
-           4.0 * s.B * s.S * s.S * s.H * s.D / (ms * 1e-3) / 1e12, (unsigned long long)hsh);
+    hipMemcpy(q, hq.data(), s.B * s.Sq * C * 2, hipMemcpyHostToDevice);
+    hipMemcpy(k, kq.data(), s.B * s.Sk * C * 2, hipMemcpyHostToDevice);
+    hipMemcpy(v, hv.data(), s.B * s.Sk * C * 2, hipMemcpyHostToDevice);
+    hipMemset(o, 0xff, s.B * s.Sq * C * 2);
+    auto run = [&]() {
+      return fdm_attn_fwd(o, q, k, v, s.B, s.Sq, s.Sk, (int)s.H, (int)s.H, (int)s.D, C, C, C, C, 1.0f / sqrtf((float)s.D), nullptr, 0, 0, ws, wsb, nullptr);
+    };
+    for (int i = 0; i < (check ? 1 : 3); ++i) if (run() != 0) { printf("launch failed\n"); return 1; }
+    if (hipDeviceSynchronize() != hipSuccess) { printf("kernel fault\n"); return 1; }
+    float ms = 0.f;
+    if (!check) {
+      const int iters = 20;
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < iters; ++i) run();
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+      ms /= iters;
+    }
+    double maxerr = 0, sumerr = 0; int64_t nchk = 0, nan = 0;
+    if (check || rep == 1) {
+      hipMemcpy(ho.data(), o, s.B * s.Sq * C * 2, hipMemcpyDeviceToHost);
+      std::vector<int64_t> rows = {0, 1, 31, 32, 63, 64, 255, 256, s.Sq / 2, s.Sq - 1, s.Sq - 2, s.Sq - 33, s.Sq - 65, s.Sq - 257, s.Sq / 3, 5 * s.Sq / 7};
+      std::vector<double> sc(s.Sk);
+      for (int64_t b = 0; b < s.B; ++b) for (int64_t hh = 0; hh < s.H; hh += (s.H > 4 ? 5 : 1)) for (int64_t r : rows) {
+        if (r < 0 || r >= s.Sq) continue;
+        const uint16_t* qr = &hq[(b * s.Sq + r) * C + hh * s.D];
+        double mx = -1e300;
+        for (int64_t j = 0; j < s.Sk; ++j) {
+          const uint16_t* kr = &kq[(b * s.Sk + j) * C + hh * s.D];
+          double a = 0; for (int d = 0; d < s.D; ++d) a += (double)b2f(qr[d]) * b2f(kr[d]);
+          sc[j] = a / sqrt((double)s.D); mx = fmax(mx, sc[j]);
+        }
+        double l = 0; for (int64_t j = 0; j < s.Sk; ++j) { sc[j] = exp(sc[j] - mx); l += sc[j]; }
+        for (int d = 0; d < s.D; ++d) {
+          double a = 0; for (int64_t j = 0; j < s.Sk; ++j) a += sc[j] * b2f(hv[(b * s.Sk + j) * C + hh * s.D + d]);
+          const float got = b2f(ho[(b * s.Sq + r) * C + hh * s.D + d]);
+          if (!(got == got)) { ++nan; continue; }
+          const double err = fabs(a / l - got); maxerr = fmax(maxerr, err); sumerr += err; ++nchk;
+        }
+      }
+      if (nan || maxerr > 1.8e-2) ++bad;
+    }
+    printf("attn B=%ld Sq=%ld Sk=%ld H=%ld hd=%ld spike=%d: %8.1f us %8.1f TF/s  max|err| %.3e mean %.3e nan %ld (%ld values)%s\n", (long)s.B, (long)s.Sq,
+           (long)s.Sk, (long)s.H, (long)s.D, s.spike, ms * 1e3, ms > 0 ? 4.0 * s.B * s.Sq * s.Sk * s.H * s.D / (ms * 1e-3) / 1e12 : 0.0, maxerr,
+           nchk ? sumerr / nchk : 0.0, (long)nan, (long)nchk, (nan || maxerr > 1.8e-2) ? "  <-- FAIL" : "");
   }
-  return 0;
+  printf(bad ? "CHECK FAILED\n" : "CHECK OK\n");
+  return bad ? 2 : 0;
 }

@@ -1,0 +1,39 @@
+#!/bin/bash
+# Audit of attn_fwd64_kernel's asm-owned registers (fastdm_amd/csrc/attention.hip): compiles attention.hip with -save-temps and
+# fails if (1) the kernel spills or uses scratch, (2) any instruction OUTSIDE the inline-asm statements touches a240..a255
+# (the V^T fragment registers owned by the asm), (3) an s_load / compiler LDS instruction sits inside the tile loop (it would
+# break the hand-counted lgkmcnt waits).
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+TMP=$(mktemp -d)
+cd "$TMP"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wno-unused-result -save-temps \
+    -c "$HERE/../../fastdm_amd/csrc/attention.hip" -o a.o 2> err.txt || { tail -20 err.txt; exit 1; }
+S=attention-hip-amdgcn-amd-amdhsa-gfx950.s
+awk '/^_ZN3fdm17attn_fwd64_kernelILi128EEEvNS_10AttnParamsE:/,/^\.Lfunc_end/' $S > k.s
+grep -A40 "amdhsa_kernel _ZN3fdm17attn_fwd64" $S | grep -E "next_free_vgpr|accum_offset|private_segment_fixed_size"
+python3 - <<'PY'
+import re, sys
+lines = open("k.s").read().split("\n")
+inasm = False
+bad = []
+loop_start = None
+for i, l in enumerate(lines):
+    if "Loop Header" in l and loop_start is None:
+        loop_start = i
+    if "#ASMSTART" in l: inasm = True; continue
+    if "#ASMEND" in l: inasm = False; continue
+    code = l.split(";")[0]
+    if not inasm and re.search(r"\ba(24[0-9]|25[0-5])\b|a\[(2[0-9][0-9]):(24[0-9]|25[0-5])\]", code):
+        bad.append((i, l.strip()))
+    if not inasm and loop_start is not None and re.search(r"^\s*(s_load|s_buffer_load|ds_)", code) and "s_endpgm" not in code:
+        # compiler-generated scalar loads / LDS ops inside the loop region (the epilogue's ds_bpermute comes after the loop: allow ds_bpermute)
+        if "ds_bpermute" not in code:
+            bad.append((i, "in-loop: " + l.strip()))
+scratch = [l for l in lines if re.search(r"^\s*scratch_", l)]
+n_ins = sum(1 for l in lines if re.match(r"^\s+[a-z]", l))
+print("instructions: %d, mfma %d, scratch ops %d" % (n_ins, sum("v_mfma" in l for l in lines), len(scratch)))
+for b in bad[:20]: print("VIOLATION line %d: %s" % b)
+sys.exit(1 if bad or scratch else 0)
+PY
+echo "audit ok"
