@@ -436,6 +436,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 #define FDM_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+#ifdef FDM_ATT_STAMPS
+// diagnostic build only (tools/micro/attn_bench.hip): per-block cycle sums of the step's segments
+__device__ unsigned long long g_att_stamps[4096 * 8];
+#define FDM_STAMP(VAR)                                                                       \
+  FDM_FENCE();                                                                               \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(VAR)::"memory");                \
+  FDM_FENCE()
+#else
+#define FDM_STAMP(VAR)
+#endif
+
 template <int D>
 __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) {
   static_assert(D == 128, "64-row kernel: head_dim 128");
@@ -473,6 +484,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
   const int ntiles = (int)((p.sk + KT - 1) / KT);
   const int t_begin = is_part ? (int)((int64_t)part * ntiles / p.split) : 0;
   const int t_end = is_part ? (int)((int64_t)(part + 1) * ntiles / p.split) : ntiles;
+  const int t_tail = (p.sk % KT != 0) ? ntiles - 1 : -1;   // the one tile whose keys need masking
 
   // ---- K/V staging by LDS-DMA: lane-linear destination, swizzle on the source side (as in attn_fwd_kernel).  The source
   //      is a wave-uniform tile base (SALU) plus a 32-bit per-lane offset that never changes; the rows of a partial last
@@ -492,23 +504,33 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
       vofs_t[i] = (uint32_t)(rc * p.v_ts * 2 + Swz<D>::v(r, pos) * 16);
     }
   }
-  // DMA piece i (0..3) of the K (V) tile t into ring slot `slot`
-  auto dma_k = [&](int t, int slot, auto idx) {
-    constexpr int I = decltype(idx)::value;
+  // DMA piece i (0..3) of a K (V) tile into ring slot `slot`; src = the tile's base (tile_src, once per phase), last = it is
+  // the sequence's last tile (clamped row offsets)
+  auto tile_src = [&](const uint8_t* base, int64_t ts, int t, bool& last) -> const uint8_t* {
     const int tc = t < ntiles - 1 ? t : ntiles - 1;
-    const uint8_t* src = kbase + (int64_t)tc * KT * p.k_ts * 2;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (tc == ntiles - 1 ? kofs_t[I] : kofs[I])),
+    last = tc == ntiles - 1;
+    return base + (int64_t)tc * KT * ts * 2;
+  };
+  auto dma_k = [&](const uint8_t* src, bool last, int slot, auto idx) {
+    constexpr int I = decltype(idx)::value;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (last ? kofs_t[I] : kofs[I])),
                                      (__attribute__((address_space(3))) void*)(smem + slot * TILE_BYTES + wave * 1024 + I * 4096), 16, 0, 0);
   };
-  auto dma_v = [&](int t, int slot, auto idx) {
+  auto dma_v = [&](const uint8_t* src, bool last, int slot, auto idx) {
     constexpr int I = decltype(idx)::value;
-    const int tc = t < ntiles - 1 ? t : ntiles - 1;
-    const uint8_t* src = vbase + (int64_t)tc * KT * p.v_ts * 2;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (tc == ntiles - 1 ? vofs_t[I] : vofs[I])),
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (last ? vofs_t[I] : vofs[I])),
                                      (__attribute__((address_space(3))) void*)(smem + V_RING + slot * TILE_BYTES + wave * 1024 + I * 4096), 16, 0, 0);
   };
-  static_for<4>([&](auto s_) { static_for<4>([&](auto i) { dma_k(t_begin + decltype(s_)::value, decltype(s_)::value, i); }); });
-  static_for<3>([&](auto s_) { static_for<4>([&](auto i) { dma_v(t_begin + decltype(s_)::value, decltype(s_)::value, i); }); });
+  static_for<4>([&](auto s_) {
+    bool last;
+    const uint8_t* src = tile_src(kbase, p.k_ts, t_begin + decltype(s_)::value, last);
+    static_for<4>([&](auto i) { dma_k(src, last, decltype(s_)::value, i); });
+  });
+  static_for<3>([&](auto s_) {
+    bool last;
+    const uint8_t* src = tile_src(vbase, p.v_ts, t_begin + decltype(s_)::value, last);
+    static_for<4>([&](auto i) { dma_v(src, last, decltype(s_)::value, i); });
+  });
 
   // ---- Q fragments, pre-scaled by scale * log2(e) (one extra bf16 rounding of q), parked in accumulation registers
   i32x4 qa[2][KSTEPS];
@@ -548,6 +570,9 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
     asm volatile("" : "+v"(mneg[qb]));
   }
   float mref[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+#ifdef FDM_ATT_STAMPS
+  unsigned long long st_a = 0, st_w = 0, st_b = 0, st_d = 0, st_n = 0, st_t0;
+#endif
 
   // ---- LDS read addresses: per-lane bases (8 for the K k-steps, 4 for the V^T d-blocks); ring slot, key block and key
   //      group are compile-time immediates of the DS instructions (no address VALU in the loop)
@@ -667,14 +692,10 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int e = 1; e < 16; ++e) m = __builtin_amdgcn_fmed3f(m, S[kb][qb][e], __builtin_inff());
-        mx[qb] = m;
+        const int mi = __builtin_bit_cast(int, m);   // the other half of the query row
+        const auto sw = __builtin_amdgcn_permlane32_swap(mi, mi, false, false);
+        mx[qb] = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
       }
-    }
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {   // the other half of the query row
-      const int mi = __builtin_bit_cast(int, mx[qb]);
-      const auto sw = __builtin_amdgcn_permlane32_swap(mi, mi, false, false);
-      mx[qb] = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
     }
     if (first || tail || __any(fmaxf(mx[0], mx[1]) >= 1.0f)) fixup(S, mx, first);
   };
@@ -689,6 +710,14 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
     constexpr int I = decltype(iidx)::value;
     constexpr int KS1 = (I + 1) & 3, KS2 = (I + 2) & 3, VS0 = I & 3;   // ring slots: K(t+1), K(t+2), V(t)
     i32x4 pf[2][2][2];   // [kb][qb][sx]
+#ifdef FDM_ATT_STAMPS
+    unsigned long long ts0, ts1, ts2, ts3, ts4;
+#endif
+    FDM_STAMP(ts0);
+    bool klast, vlast;
+    const uint8_t* ksrc = tile_src(kbase, p.k_ts, t + 4, klast);
+    const uint8_t* vsrc = tile_src(vbase, p.v_ts, t + 3, vlast);
+    FDM_FENCE();
     // ---- phase A
     static_for<32>([&](auto g_) {
       constexpr int G = decltype(g_)::value, F = G >> 1, kb = G >> 4, ks = (G >> 1) & 7, qb = G & 1;
@@ -707,14 +736,17 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
       constexpr int q0_ = (G * 21) / 16, q1_ = ((G + 1) * 21) / 16;
       sm_slot(Sc, pf, ic<q0_>{});
       if constexpr (q1_ - q0_ == 2) sm_slot(Sc, pf, ic<q0_ + 1>{});
-      if constexpr ((G & 7) == 4) dma_k(t + 4, I & 3, ic<(G >> 3)>{});
+      if constexpr ((G & 7) == 4) dma_k(ksrc, klast, I & 3, ic<(G >> 3)>{});
       FDM_FENCE();
     });
+    FDM_STAMP(ts1);
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // K(t+2), V(t+1) and older have landed; K(t+3), V(t+2), K(t+4) stay in flight
     __builtin_amdgcn_s_barrier();
     FDM_FENCE();
+    FDM_STAMP(ts2);
     // ---- phase B
-    float mxa[2][2];
+    float mxa[2][2], mx[2];
+    unsigned long long vote = 0;
     static_for<32>([&](auto g_) {
       constexpr int G = decltype(g_)::value, F = G >> 1, grp = G >> 3, kb = grp >> 1, sx = grp & 1, d = (G >> 1) & 3, qb = G & 1;
       auto& oacc_ = oacc;
@@ -738,15 +770,39 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
         mxa[qq][c] = m;
         asm volatile("" : "+v"(mxa[qq][c]));   // pins the max chain inside this gap
       }
-      if constexpr (G >= 24 && (G & 1) == 0) dma_v(t + 3, (I + 3) & 3, ic<((G - 24) >> 1 < 4 && G >= 24 ? (G - 24) >> 1 : 0)>{});
+      if constexpr (G == 16) {
+        mx[0] = fmaxf(mxa[0][0], mxa[0][1]);
+        mx[1] = fmaxf(mxa[1][0], mxa[1][1]);
+        asm volatile("" : "+v"(mx[0]), "+v"(mx[1]));
+      }
+      if constexpr (G == 17 || G == 18) {   // the other half of the query row
+        constexpr int qq = G - 17;
+        const int mi = __builtin_bit_cast(int, mx[qq]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(mi, mi, false, false);
+        mx[qq] = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        asm volatile("" : "+v"(mx[qq]));
+      }
+      if constexpr (G == 20) {
+        vote = __builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[1]) >= 1.0f);
+        asm volatile("" : "+s"(vote));
+      }
+      if constexpr (G >= 24 && (G & 1) == 0) dma_v(vsrc, vlast, (I + 3) & 3, ic<((G - 24) >> 1 < 4 && G >= 24 ? (G - 24) >> 1 : 0)>{});
       FDM_FENCE();
     });
+    FDM_STAMP(ts3);
     // MFMA result -> VALU read of Sn: the ordering asm keeps every reader of Sn below the P.V MFMAs above
     asm volatile("" : "+v"(Sn[0][0]), "+v"(Sn[0][1]), "+v"(Sn[1][0]), "+v"(Sn[1][1]));
-    float mx[2] = {fmaxf(mxa[0][0], mxa[0][1]), fmaxf(mxa[1][0], mxa[1][1])};
-    if (t + 1 < t_end) decide(Sn, mx, t + 1, false, true);
+    // fix-up path only if some row's S' reached 1 (vote), or tile t+1 is the sequence's masked last tile
+    if (t + 1 < t_end && (vote != 0 || t + 1 == t_tail)) decide(Sn, mx, t + 1, false, true);
+    FDM_STAMP(ts4);
+#ifdef FDM_ATT_STAMPS
+    st_a += ts1 - ts0; st_w += ts2 - ts1; st_b += ts3 - ts2; st_d += ts4 - ts3; st_n += 1;
+#endif
   };
 
+#ifdef FDM_ATT_STAMPS
+  FDM_STAMP(st_t0);
+#endif
   f32x16 Sa[2][2], Sb[2][2];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q and the prologue tiles have landed
   __builtin_amdgcn_s_barrier();
@@ -786,6 +842,16 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
     if (t + 3 < t_end) step(Sb, Sa, t + 3, ic<3>{});
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // run-ahead DMAs / fragment reads must not outlive the block
+#ifdef FDM_ATT_STAMPS
+  {
+    unsigned long long st_t1;
+    FDM_STAMP(st_t1);
+    if (tid == 0 && blockIdx.x < 4096) {
+      unsigned long long* o_ = g_att_stamps + (size_t)blockIdx.x * 8;
+      o_[0] = st_a; o_[1] = st_w; o_[2] = st_b; o_[3] = st_d; o_[4] = st_n; o_[5] = st_t1 - st_t0;
+    }
+  }
+#endif
 
   // ---- finalize
 #pragma unroll

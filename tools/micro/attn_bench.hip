@@ -21,6 +21,7 @@ int main(int argc, char** argv) {
   const bool check = argc > 1 && !strcmp(argv[1], "check");
   struct Shape { int64_t B, Sq, Sk, H, D; int spike; };
   std::vector<Shape> shapes = {{1, 8704, 8704, 24, 128, 0}, {1, 4608, 4608, 24, 128, 0}, {2, 4096, 4096, 24, 64, 0}};
+  if (argc > 1 && !strcmp(argv[1], "one")) shapes = {{1, 8704, 8704, 24, 128, 0}};
   if (check) shapes = {{1, 8704, 8704, 24, 128, 0}, {1, 8704, 8704, 24, 128, 1}, {1, 1000, 1000, 8, 128, 0}, {2, 300, 300, 3, 128, 1}, {1, 50, 50, 2, 128, 0},
                        {1, 777, 2100, 5, 128, 1}, {1, 4608, 512, 24, 128, 0}, {1, 64, 64, 1, 128, 0}, {1, 257, 129, 2, 128, 1}, {2, 1111, 1111, 8, 64, 0}};
   const int64_t maxe = 8704 * 24 * 128 * 2;
@@ -88,6 +89,16 @@ int main(int argc, char** argv) {
            (long)s.Sk, (long)s.H, (long)s.D, s.spike, ms * 1e3, ms > 0 ? 4.0 * s.B * s.Sq * s.Sk * s.H * s.D / (ms * 1e-3) / 1e12 : 0.0, maxerr,
            nchk ? sumerr / nchk : 0.0, (long)nan, (long)nchk, (nan || maxerr > 1.8e-2) ? "  <-- FAIL" : "");
   }
+#ifdef FDM_ATT_STAMPS
+  {   // cycle shares of the LAST launch (S = 4096 hd 64 does not run the stamped kernel: run with a single hd-128 shape last)
+    std::vector<unsigned long long> st(4096 * 8);
+    hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(fdm::g_att_stamps), st.size() * 8);
+    double a = 0, w = 0, bb = 0, d = 0, n = 0, tot = 0; int blocks = 0;
+    for (int i = 0; i < 4096; ++i) if (st[i * 8 + 4] > 0) { a += st[i*8]; w += st[i*8+1]; bb += st[i*8+2]; d += st[i*8+3]; n += st[i*8+4]; tot += st[i*8+5]; ++blocks; }
+    printf("stamps over %d blocks: per step: phaseA %.0f  wait+barrier %.0f  phaseB %.0f  decide %.0f cycles (sum %.0f); steps/block %.1f; block total %.0f cycles (loop share %.2f)\n",
+           blocks, a / n, w / n, bb / n, d / n, (a + w + bb + d) / n, n / blocks, tot / blocks, (a + w + bb + d) / tot);
+  }
+#endif
   printf(bad ? "CHECK FAILED\n" : "CHECK OK\n");
   return bad ? 2 : 0;
 }
