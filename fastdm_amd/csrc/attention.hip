@@ -436,6 +436,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 #define FDM_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// 1: the softmax row sums are taken by 8 extra MFMAs per tile (ones x P^T, same B fragments as P.V) instead of 64 v_add_f32
+#ifndef FDM_A64_LSUM_MFMA
+#define FDM_A64_LSUM_MFMA 0
+#endif
+// 1: the VALU work sits in the odd MFMA gaps (no fragment read + wait there); 0: spread evenly
+#ifndef FDM_A64_BAL
+#define FDM_A64_BAL 0      // measured in one process (tools/micro/attn_ab): 762 vs 756 us, kept for the record
+#endif
+// timing-only ablations (tools/micro; wrong results): 1 no DMA in the loop, 2 no fragment reads, 4 no exp2, 8 no row sums,
+// 16 no row maxima, 32 no barrier, 64 no packs
+#ifndef FDM_A64_ABL
+#define FDM_A64_ABL 0
+#endif
 #ifdef FDM_ATT_STAMPS
 // diagnostic build only (tools/micro/attn_bench.hip): per-block cycle sums of the step's segments
 __device__ unsigned long long g_att_stamps[4096 * 8];
@@ -570,6 +583,18 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
     asm volatile("" : "+v"(mneg[qb]));
   }
   float mref[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+#if FDM_A64_LSUM_MFMA
+  f32x16 lacc[2];       // accumulation registers: every row of ones[32 x 16] . P^T[16 x 32] is the row-sum vector
+  {
+    f32x16 z;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+    asm volatile("" : "=a"(lacc[0]) : "0"(z));
+    asm volatile("" : "=a"(lacc[1]) : "0"(z));
+  }
+  i32x4 ones = {0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};   // bf16 1.0 x 8
+  asm volatile("" : "+v"(ones));
+#endif
 #ifdef FDM_ATT_STAMPS
   unsigned long long st_a = 0, st_w = 0, st_b = 0, st_d = 0, st_n = 0, st_t0;
 #endif
@@ -621,16 +646,22 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
   // n -> group g = n>>4 (kb = g>>1, sx = g&1), qb = (n>>3)&1, r = n&7 -> register e = 8*sx + r of S[kb][qb]
   auto sm_exp = [&](f32x16 (&S)[2][2], auto nidx) {
     constexpr int N = decltype(nidx)::value, g = N >> 4, kb = g >> 1, sx = g & 1, qb = (N >> 3) & 1, r = N & 7, e = 8 * sx + r;
-    S[kb][qb][e] = __builtin_amdgcn_exp2f(S[kb][qb][e]);
+    if constexpr (FDM_A64_ABL & 4) asm volatile("" : "+v"(S[kb][qb][e]));
+    else S[kb][qb][e] = __builtin_amdgcn_exp2f(S[kb][qb][e]);
   };
   auto sm_add = [&](f32x16 (&S)[2][2], auto nidx) {   // one gap after sm_exp(n): the transcendental's latency is not exposed
     constexpr int N = decltype(nidx)::value, g = N >> 4, kb = g >> 1, sx = g & 1, qb = (N >> 3) & 1, r = N & 7, e = 8 * sx + r;
+#if FDM_A64_LSUM_MFMA || (FDM_A64_ABL & 8)
+    (void)S; (void)e;
+#else
     l_run[qb] += S[kb][qb][e];
     asm volatile("" : "+v"(l_run[qb]));   // pins the add inside this gap (the optimiser otherwise sinks the whole sum chain below the tile)
+#endif
   };
   auto sm_pack = [&](f32x16 (&S)[2][2], i32x4 (&pf)[2][2][2], auto nidx) {   // n odd: elements n-1, n
     constexpr int N = decltype(nidx)::value, g = N >> 4, kb = g >> 1, sx = g & 1, qb = (N >> 3) & 1, r = N & 7, e = 8 * sx + r;
-    pf[kb][qb][sx][r >> 1] = (int)pack2bf(S[kb][qb][e - 1], S[kb][qb][e]);
+    if constexpr (FDM_A64_ABL & 64) pf[kb][qb][sx][r >> 1] = __builtin_bit_cast(int, S[kb][qb][e]);
+    else pf[kb][qb][sx][r >> 1] = (int)pack2bf(S[kb][qb][e - 1], S[kb][qb][e]);
     asm volatile("" : "+v"(pf[kb][qb][sx][r >> 1]));
   };
   // softmax slot q of a step (q = 0..63): exp of element q, add of element q-1, pack of the pair ending at q-2
@@ -651,6 +682,15 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
       const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
       mref[qb] += delta;
       l_run[qb] *= alpha;
+#if FDM_A64_LSUM_MFMA
+      if (!first) {
+        f32x16 v;
+        asm volatile("s_nop 7\n\ts_nop 7" : "=v"(v) : "0"(lacc[qb]));
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] *= alpha;
+        asm volatile("" : "=a"(lacc[qb]) : "0"(v));
+      }
+#endif
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -724,24 +764,38 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
       auto& qa_ = qa;
       auto& mneg_ = mneg;
       if constexpr ((G & 1) == 0) {
-        if constexpr (F + 3 < 16) FDM_READ_K(KS1, (F + 3 < 16 ? F + 3 : 0));
+        if constexpr (FDM_A64_ABL & 2) {
+        } else if constexpr (F + 3 < 16) FDM_READ_K(KS1, (F + 3 < 16 ? F + 3 : 0));
         else FDM_READ_V(VS0, (F + 3 - 16 >= 0 ? F + 3 - 16 : 0));
         // reads issued after fragment F's: K fragments count 1, V^T fragments 2
         constexpr int newer = F <= 12 ? 3 : (F == 13 ? 4 : (F == 14 ? 5 : 6));
-        FDM_LGKM(newer);
+        if constexpr (!(FDM_A64_ABL & (2 | 128))) FDM_LGKM(newer);
       }
       if constexpr (ks == 0) FDM_MFMA_S_FIRST(Sn[kb][qb], kf[F & 3], qa_[qb][ks], mneg_[qb]);
       else FDM_MFMA_S_ACC(Sn[kb][qb], kf[F & 3], qa_[qb][ks]);
+#if FDM_A64_BAL
+      // softmax slots 0..41: one in every even gap (which also carries a fragment read + wait), 26 in the 16 odd gaps
+      constexpr int PR = G >> 1;                               // gap pair
+      constexpr int o0 = (PR * 26) / 16, o1 = ((PR + 1) * 26) / 16;   // odd-gap slots of this pair: 1 or 2
+      constexpr int base_ = PR + o0;                           // slots before this pair
+      if constexpr ((G & 1) == 0) sm_slot(Sc, pf, ic<base_>{});
+      else {
+        sm_slot(Sc, pf, ic<base_ + 1>{});
+        if constexpr (o1 - o0 == 2) sm_slot(Sc, pf, ic<base_ + 2>{});
+      }
+      if constexpr ((G & 7) == 5 && !(FDM_A64_ABL & 1)) dma_k(ksrc, klast, I & 3, ic<(G >> 3)>{});
+#else
       // softmax slots 0..41 over the 32 gaps (21 per 16 gaps)
       constexpr int q0_ = (G * 21) / 16, q1_ = ((G + 1) * 21) / 16;
       sm_slot(Sc, pf, ic<q0_>{});
       if constexpr (q1_ - q0_ == 2) sm_slot(Sc, pf, ic<q0_ + 1>{});
-      if constexpr ((G & 7) == 4) dma_k(ksrc, klast, I & 3, ic<(G >> 3)>{});
+      if constexpr ((G & 7) == 4 && !(FDM_A64_ABL & 1)) dma_k(ksrc, klast, I & 3, ic<(G >> 3)>{});
+#endif
       FDM_FENCE();
     });
     FDM_STAMP(ts1);
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // K(t+2), V(t+1) and older have landed; K(t+3), V(t+2), K(t+4) stay in flight
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(FDM_A64_ABL & 32)) __builtin_amdgcn_s_barrier();
     FDM_FENCE();
     FDM_STAMP(ts2);
     // ---- phase B
@@ -751,16 +805,38 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
       constexpr int G = decltype(g_)::value, F = G >> 1, grp = G >> 3, kb = grp >> 1, sx = grp & 1, d = (G >> 1) & 3, qb = G & 1;
       auto& oacc_ = oacc;
       if constexpr ((G & 1) == 0) {
-        if constexpr (F + 3 < 16) FDM_READ_V(VS0, (F + 3 < 16 ? F + 3 : 0));
+        if constexpr (FDM_A64_ABL & 2) {
+        } else if constexpr (F + 3 < 16) FDM_READ_V(VS0, (F + 3 < 16 ? F + 3 : 0));
         else FDM_READ_K(KS2, (F + 3 - 16 >= 0 ? F + 3 - 16 : 0));
         constexpr int newer = F <= 12 ? 6 : (F == 13 ? 5 : (F == 14 ? 4 : 3));
-        FDM_LGKM(newer);
+        if constexpr (!(FDM_A64_ABL & (2 | 128))) FDM_LGKM(newer);
       }
       if constexpr ((G & 7) == 0) FDM_MFMA_O_PAD(oacc_[qb][d], F & 3, pf[kb][qb][sx]);
       else FDM_MFMA_O(oacc_[qb][d], F & 3, pf[kb][qb][sx]);
+#if FDM_A64_LSUM_MFMA
+      if constexpr ((G & 7) == 7) {   // the group's P fragments once more: row sums
+        auto& lacc_ = lacc;
+        FDM_FENCE();
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(lacc_[0]) : "v"(ones), "v"(pf[kb][0][sx]) : FDM_VREGS);
+        FDM_FENCE();
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(lacc_[1]) : "v"(ones), "v"(pf[kb][1][sx]) : FDM_VREGS);
+      }
+#endif
       if constexpr (G < 24) sm_slot(Sc, pf, ic<(G < 24 ? 42 + G : 0)>{});   // slots 42..65 (the last two only add / pack): group 3's last pack is
                                                                              // out at gap 23, its first P.V MFMA issues at gap 24
-      if constexpr (G < 16) {
+#if FDM_A64_BAL
+      if constexpr (G < 16 && (G & 1) && !(FDM_A64_ABL & 16)) {
+        // row maxima of Sn (written in phase A) in the odd gaps: one chain per (q block qq, key block c), 2 gaps of 8
+        // elements each; med3(a, b, +inf) = max(a, b) pairs fold into v_max3_f32
+        constexpr int qq = (G >> 3) & 1, c = (G >> 2) & 1, q2 = (G >> 1) & 1;
+        float m = q2 == 0 ? Sn[c][qq][0] : mxa[qq][c];
+#pragma unroll
+        for (int e = (q2 == 0 ? 1 : 8); e < 8 * q2 + 8; ++e) m = __builtin_amdgcn_fmed3f(m, Sn[c][qq][e], __builtin_inff());
+        mxa[qq][c] = m;
+        asm volatile("" : "+v"(mxa[qq][c]));   // pins the max chain inside this gap
+      }
+#else
+      if constexpr (G < 16 && !(FDM_A64_ABL & 16)) {
         // row maxima of Sn (written in phase A): one chain per (q block qq, key block c), 4 gaps of 4 elements each;
         // med3(a, b, +inf) = max(a, b) pairs fold into v_max3_f32
         constexpr int qq = (G >> 3) & 1, c = (G >> 2) & 1, q4 = G & 3;
@@ -770,7 +846,9 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
         mxa[qq][c] = m;
         asm volatile("" : "+v"(mxa[qq][c]));   // pins the max chain inside this gap
       }
-      if constexpr (G == 16) {
+#endif
+      if constexpr (G == 16 && (FDM_A64_ABL & 16)) mx[0] = mx[1] = 0.f;
+      if constexpr (G == 16 && !(FDM_A64_ABL & 16)) {
         mx[0] = fmaxf(mxa[0][0], mxa[0][1]);
         mx[1] = fmaxf(mxa[1][0], mxa[1][1]);
         asm volatile("" : "+v"(mx[0]), "+v"(mx[1]));
@@ -786,7 +864,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
         vote = __builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[1]) >= 1.0f);
         asm volatile("" : "+s"(vote));
       }
-      if constexpr (G >= 24 && (G & 1) == 0) dma_v(vsrc, vlast, (I + 3) & 3, ic<((G - 24) >> 1 < 4 && G >= 24 ? (G - 24) >> 1 : 0)>{});
+      if constexpr (G >= 24 && (G & 1) == FDM_A64_BAL && !(FDM_A64_ABL & 1)) dma_v(vsrc, vlast, (I + 3) & 3, ic<((G - 24) >> 1 < 4 && G >= 24 ? (G - 24) >> 1 : 0)>{});
       FDM_FENCE();
     });
     FDM_STAMP(ts3);
@@ -802,6 +880,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
 
 #ifdef FDM_ATT_STAMPS
   FDM_STAMP(st_t0);
+  const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   f32x16 Sa[2][2], Sb[2][2];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q and the prologue tiles have landed
@@ -849,6 +928,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
     if (tid == 0 && blockIdx.x < 4096) {
       unsigned long long* o_ = g_att_stamps + (size_t)blockIdx.x * 8;
       o_[0] = st_a; o_[1] = st_w; o_[2] = st_b; o_[3] = st_d; o_[4] = st_n; o_[5] = st_t1 - st_t0;
+      o_[6] = __builtin_amdgcn_s_memrealtime() - st_r0;   // 100 MHz ticks
     }
   }
 #endif
@@ -856,7 +936,16 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
   // ---- finalize
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
+#if FDM_A64_LSUM_MFMA
+    float l_tot;
+    {
+      f32x16 lv;
+      asm volatile("s_nop 7\n\ts_nop 7" : "=v"(lv) : "0"(lacc[qb]));
+      l_tot = lv[0];   // every row of the tile is the row-sum vector: this lane's column = its query row, both halves included
+    }
+#else
     const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+#endif
     const int row = wave * 64 + qb * 32 + lq;
     f32x16 o[DT];
 #pragma unroll

@@ -7,8 +7,12 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result $*"
 pids=()
+# attention.hip: the hand-placed MFMA gaps of attn_fwd64_kernel must not be re-packed by the SLP vectoriser (it merges the
+# two q-blocks' row-sum chains into v_pk_add_f32 and sinks them below the tile)
 for f in elementwise gemm attention capi; do
-  "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OUT/$f.o" &
+  extra=""
+  [ "$f" = attention ] && extra="-fno-slp-vectorize"
+  "$HIPCC" $FLAGS $extra -c "$HERE/$f.hip" -o "$OUT/$f.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done

@@ -1131,10 +1131,58 @@ def gen_c3_traj(n_double, n_single, tag, n_steps=4, attention="ref", img_h=64, i
     use_backend("torch")
     return d
 
+def gen_c3_equal_inputs(rows=128, seed=0):
+    """is the fp8 path's extra noise after ONE block implementation noise of the quantised chain, or
+    something else?  Feed EQUAL inputs to the chain: `rows` full-width rows of the C3 block-0 image stream (x_embedder output of
+    the synthetic latents) and temb go through the reference's own block-0 pieces -- AdaLayerNormZero, per-token fp8 quantisation,
+    the q columns of the fused qkv QLinear, and the feed-forward (GELU-tanh GEMM, re-quantisation, down GEMM) -- and every intermediate is stored, so the
+    HIP chain can be held to: identical fp8 codes and scales, GEMM outputs within one bf16 ulp."""
+    reg = import_reference()
+    from oracle import flux as OF
+    from fastdm.model.flux import FluxTransformer2DModelCore, FluxTransformerBlock
+    from fastdm.kernel.operators_set import quantize_to_fp8
+    import contextlib
+    import io
+    cfg = OF.FluxConfig(num_layers=1, num_single_layers=1)
+    inp = OF.synth_inputs(cfg, 1, 64, 128, 512, seed)
+    use_backend("cpu_fp8")
+    core = FluxTransformer2DModelCore(num_layers=1, num_single_layers=1, quant_dtype=torch.float8_e4m3fn)
+
+    def load_part(names_map, loader):
+        sd = {}
+        for name, shape, kind in names_map:
+            sd[name[1]] = OF.synth_tensor(name[0], shape, kind, seed)
+        core.origin_tensor_dict = sd
+        core.unmatched_tensors = list(sd.keys())
+        core.device, core.dtype = "cpu", torch.bfloat16
+        with contextlib.redirect_stdout(io.StringIO()):
+            loader()
+        core.origin_tensor_dict = {}
+    full = list(OF.param_specs(OF.FluxConfig()))
+    load_part([((n, n), s_, k) for n, s_, k in full if n.startswith(("time_text_embed", "context_embedder", "x_embedder"))], core._pre_part_loading)
+    core.transformer_blocks = [FluxTransformerBlock(dim=cfg.inner_dim, num_attention_heads=cfg.num_attention_heads,
+                                                    attention_head_dim=cfg.attention_head_dim, data_type=torch.bfloat16)]
+    load_part([((n, n), s_, k) for n, s_, k in full if n.startswith("transformer_blocks.0.")], core._FluxTransformer2DModelCore__transformer_block_loading)
+    blk = core.transformer_blocks[0]
+    with torch.no_grad():
+        hidden = core.x_embedder.forward(inp["hidden_states"][:, :rows])
+        ts = torch.tensor([1.0]).to(hidden.dtype) * 1000
+        gd = torch.tensor([3.5]).to(hidden.dtype) * 1000
+        temb = core.time_text_embed.forward(ts, gd, inp["pooled_projections"])
+        norm_hidden, gate_msa, shift_mlp, scale_mlp, gate_mlp = blk.norm1.forward(hidden, emb=temb)
+        codes, scales = quantize_to_fp8(norm_hidden.reshape(-1, norm_hidden.shape[-1]))
+        q_out = blk.attn.qkv.forward(norm_hidden)[:, :, : cfg.inner_dim].contiguous()      # the q third of the fused qkv projection
+        ff_out = blk.ff.forward(norm_hidden)
+    d = {"hidden": hidden, "temb": temb, "norm_hidden": norm_hidden, "codes": codes, "scales": scales.reshape(-1).float(), "q_out": q_out,
+         "ff_out": ff_out, "gate_msa": gate_msa, "meta_rows": rows, "meta_seed": seed}
+    save("flux_c3_equal_inputs.npz", d)
+    use_backend("torch")
+    return d
+
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3", "c3_traj", "radial_full"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3", "c3_traj", "radial_full", "c3_equal"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     ap.add_argument("--steps", type=int, default=4, help="c3_traj: denoise steps of the 25-step schedule")
@@ -1183,6 +1231,8 @@ def main():
                 gen_c3_traj(args.blocks[0], args.blocks[1], tag, n_steps=args.steps, attention=att)
     if args.what == "radial_full":
         gen_radial_full()
+    if args.what == "c3_equal":
+        gen_c3_equal_inputs()
 
 
 if __name__ == "__main__":

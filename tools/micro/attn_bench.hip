@@ -93,8 +93,9 @@ int main(int argc, char** argv) {
   {   // cycle shares of the LAST launch (S = 4096 hd 64 does not run the stamped kernel: run with a single hd-128 shape last)
     std::vector<unsigned long long> st(4096 * 8);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(fdm::g_att_stamps), st.size() * 8);
-    double a = 0, w = 0, bb = 0, d = 0, n = 0, tot = 0; int blocks = 0;
-    for (int i = 0; i < 4096; ++i) if (st[i * 8 + 4] > 0) { a += st[i*8]; w += st[i*8+1]; bb += st[i*8+2]; d += st[i*8+3]; n += st[i*8+4]; tot += st[i*8+5]; ++blocks; }
+    double a = 0, w = 0, bb = 0, d = 0, n = 0, tot = 0, rt = 0; int blocks = 0;
+    for (int i = 0; i < 4096; ++i) if (st[i * 8 + 4] > 0) { a += st[i*8]; w += st[i*8+1]; bb += st[i*8+2]; d += st[i*8+3]; n += st[i*8+4]; tot += st[i*8+5]; rt += st[i*8+6]; ++blocks; }
+    printf("in-kernel clock: %.3f GHz (shader cycles / 100 MHz realtime ticks)\n", tot / rt * 0.1);
     printf("stamps over %d blocks: per step: phaseA %.0f  wait+barrier %.0f  phaseB %.0f  decide %.0f cycles (sum %.0f); steps/block %.1f; block total %.0f cycles (loop share %.2f)\n",
            blocks, a / n, w / n, bb / n, d / n, (a + w + bb + d) / n, n / blocks, tot / blocks, (a + w + bb + d) / tot);
   }
