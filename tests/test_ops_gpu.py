@@ -186,6 +186,30 @@ def test_quant_shapes_bit_exact(K, M, Kd):
     assert torch.equal(s.cpu(), rs) and torch.equal(zp.cpu(), rzp) and torch.equal(q.cpu(), rq)
 
 
+def test_quant_fp8_adversarial_rows_on_rounding_boundaries(K):
+    """Rows built to sit ON the fp8 rounding boundaries -- lattice values whose quotients x / scale are exact ties, saturating
+    and subnormal-range values, zeros, the scale clamp -- must be bit-identical to the reference arithmetic (a quantiser that
+    replaces the division by a reciprocal multiplication fails exactly here; r2 tried a bracketed division-free variant, which
+    passed this test but was not faster: the row quantisers are bound by their load -> reduce -> convert phase structure, not
+    by VALU throughput)."""
+    g = gen(4242)
+    rows, width = 24, 12288
+    x = rbf(g, rows, width, scale=1.0)
+    x[1] = (torch.randint(-32768, 32768, (width,), generator=g).float() / 8192.0).to(BF16)      # lattice: many exact ties
+    x[2] = x[1] * 3.5
+    x[2, 0] = 448.0                                   # amax = 448 -> scale exactly 1: every fp8 midpoint in the row is a tie
+    x[3] = 0.0                                        # scale clamp (amax -> bf16(1e-12))
+    x[4] = (x[4].float() * 1e-6).to(BF16)
+    x[4, 7] = 1.0                                     # most of the row lands in the fp8 subnormal range
+    x[5] = torch.where(torch.rand(width, generator=g) < 0.5, torch.tensor(1.0), torch.tensor(-1.0)).to(BF16) * 0.0625
+    x[5, 3] = 7.0                                     # quotients 448/7 * 0.0625 = 4 exactly, and the maximum saturates
+    x[6] = (torch.arange(width).float() * (1.0 / 256.0) - 24.0).to(BF16)
+    q, s = K.quantize_to_fp8(x.cuda())
+    rq, rs = O.quantize_to_fp8(x)
+    assert torch.equal(s.cpu(), rs)
+    assert torch.equal(q.cpu().view(torch.uint8), rq.view(torch.uint8))
+
+
 def test_quant_strided_input(K):
     g = gen(77)
     big = rbf(g, 100, 9216)
