@@ -4,7 +4,7 @@
 #include "../../fastdm_amd/csrc/gemm.hip"
 #include <cstdio>
 #include <cstring>
-namespace fdm { int g_last_hip_error = 0; }
+namespace fdm { thread_local int g_last_hip_error = 0; int device_cu_count() { return 256; } }
 #include <vector>
 
 static uint64_t rng = 0x9E3779B97F4A7C15ull;
