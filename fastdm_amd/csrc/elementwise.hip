@@ -100,6 +100,25 @@ __global__ void __launch_bounds__(THREADS) rms_norm_row_kernel(bf16_t* __restric
   }
 }
 
+// Any width / alignment (the reference kernel takes any last_dim, csrc/elmwise_ops.cu:56-84): one wave per row, scalar bf16
+// accesses.  Same arithmetic as the vector kernels: fp32 sum of squares, rsqrt(mean + eps), bf16(x * rs) * w -> bf16.
+__global__ void __launch_bounds__(256) rms_norm_scalar_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ in,
+                                                              const bf16_t* __restrict__ w, float eps, int64_t rows, int hidden) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* src = in + row * hidden;
+  float ss = 0.f;
+  for (int c = lane; c < hidden; c += 64) {
+    const float x = bf2f(src[c]);
+    ss += x * x;
+  }
+  ss = wave_reduce(ss, OpSum());
+  const float rs = rsqrtf(ss / (float)hidden + eps);
+  bf16_t* dst = out + row * hidden;
+  for (int c = lane; c < hidden; c += 64) dst[c] = f2bf(rbf(bf2f(src[c]) * rs) * bf2f(w[c]));
+}
+
 // ------------------------------------------------------------------------------------ rope
 // One thread per 8 consecutive elements (4 pairs GPT-J / 8 lows or highs NeoX) of q or k.
 template <bool NEOX>
@@ -688,14 +707,18 @@ int fdm_ln_modulate_f32(void* out_bf16, void* out_q, float* out_scale, int32_t* 
 
 int fdm_rms_norm(void* out, const void* in, const void* weight, float eps, int64_t rows, int hidden, fdm_stream_t stream) {
   (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
-  if (rows == 0 && hidden > 0 && !(hidden & 7)) return FDM_OK;
-  if (!out || !in || !weight || rows < 0 || hidden <= 0 || (hidden & 7) || !aligned16(out) || !aligned16(in) || !aligned16(weight))
-    return FDM_ERR_INVALID;
+  if (!out || !in || !weight || rows < 0 || hidden <= 0) return FDM_ERR_INVALID;
   if (rows == 0) return FDM_OK;
   hipStream_t s = to_stream(stream);
   auto o = (bf16_t*)out;
   auto i = (const bf16_t*)in;
   auto w = (const bf16_t*)weight;
+  if ((hidden & 7) || !aligned16(out) || !aligned16(in) || !aligned16(weight)) {   // odd widths / unaligned rows: scalar path
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(weight)) & 1) return FDM_ERR_INVALID;
+    rms_norm_scalar_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(o, i, w, eps, rows, hidden);
+    FDM_CHECK_LAUNCH();
+    return FDM_OK;
+  }
   const int lpr = hidden / 8;
   if (lpr <= 64 && (lpr & (lpr - 1)) == 0) {
     const int rpw = 64 / lpr;

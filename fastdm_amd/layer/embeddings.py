@@ -138,54 +138,53 @@ class QwenTimestepProjEmbeddings:
 
 
 class QwenEmbedRope:
-    """embeddings.py:762-857.  Complex unit-vector tables for 4096 positive and 4096 negative positions per axis;
-    `forward` returns (video_freqs [frame*h*w, hd/2], text_freqs [max_txt, hd/2]) as complex64.  Built on the CPU
-    (tables are tiny and only rebuilt when the image shape changes), moved to `device`."""
+    """Rotary table of Qwen-Image (the reference keeps diffusers' implementation, embeddings.py:762-857), restated from its
+    formula rather than from its code:
+
+        token (f, y, x) of image `idx` and axis a with width d_a:  angle_{a,k} = p_a * theta^(-2k / d_a),  k < d_a / 2
+        p_frame = idx + f;   p_height = y - ceil(H / 2), p_width = x - ceil(W / 2) when `scale_rope` centres the grid, else y, x
+        text token n: the same three axis tables at position n + max(H, W) (or max(H // 2, W // 2) when centred)
+        entry = exp(i * angle) as complex64 (torch.polar of an fp32 angle = fp32(position) * fp32(inverse frequency))
+
+    `forward` returns (video_freqs [sum F*H*W, hd/2], text_freqs [max_txt, hd/2]); tables are built on the CPU with the
+    reference's dtypes (bit-identical: tests/golden/tiny_qwen.npz) and cached per image shape."""
 
     def __init__(self, theta: int, axes_dim: List[int], scale_rope=False):
+        assert all(d % 2 == 0 for d in axes_dim)
         self.theta, self.axes_dim, self.scale_rope = theta, axes_dim, scale_rope
-        pos_index = torch.arange(4096)
-        neg_index = torch.arange(4096).flip(0) * -1 - 1
-        self.pos_freqs = torch.cat([self.rope_params(pos_index, d, theta) for d in axes_dim], dim=1)
-        self.neg_freqs = torch.cat([self.rope_params(neg_index, d, theta) for d in axes_dim], dim=1)
+        self._inv_freq = [1.0 / torch.pow(theta, torch.arange(0, d, 2).to(torch.float32).div(d)) for d in axes_dim]
         self.rope_cache = {}
 
-    @staticmethod
-    def rope_params(index, dim, theta=10000):
-        assert dim % 2 == 0
-        freqs = torch.outer(index, 1.0 / torch.pow(theta, torch.arange(0, dim, 2).to(torch.float32).div(dim)))
-        return torch.polar(torch.ones_like(freqs), freqs)
+    def _axis(self, axis: int, positions: torch.Tensor) -> torch.Tensor:
+        """complex64 [len(positions), d_axis / 2]: unit vectors at angle position * inverse frequency"""
+        angle = positions.to(torch.int64).to(torch.float32)[:, None] * self._inv_freq[axis][None, :]
+        return torch.polar(torch.ones_like(angle), angle)
 
-    def _compute_video_freqs(self, frame, height, width, idx=0):
-        seq_lens = frame * height * width
-        freqs_pos = self.pos_freqs.split([x // 2 for x in self.axes_dim], dim=1)
-        freqs_neg = self.neg_freqs.split([x // 2 for x in self.axes_dim], dim=1)
-        freqs_frame = freqs_pos[0][idx: idx + frame].view(frame, 1, 1, -1).expand(frame, height, width, -1)
-        if self.scale_rope:
-            freqs_height = torch.cat([freqs_neg[1][-(height - height // 2):], freqs_pos[1][: height // 2]], dim=0)
-            freqs_width = torch.cat([freqs_neg[2][-(width - width // 2):], freqs_pos[2][: width // 2]], dim=0)
-        else:
-            freqs_height, freqs_width = freqs_pos[1][:height], freqs_pos[2][:width]
-        freqs_height = freqs_height.view(1, height, 1, -1).expand(frame, height, width, -1)
-        freqs_width = freqs_width.view(1, 1, width, -1).expand(frame, height, width, -1)
-        return torch.cat([freqs_frame, freqs_height, freqs_width], dim=-1).reshape(seq_lens, -1).clone().contiguous()
+    def _grid_positions(self, n: int) -> torch.Tensor:
+        return torch.arange(n) - (n - n // 2) if self.scale_rope else torch.arange(n)
+
+    def _video_table(self, idx: int, frames: int, height: int, width: int) -> torch.Tensor:
+        tok = torch.arange(frames * height * width)
+        per_axis = (self._axis(0, idx + torch.arange(frames))[tok // (height * width)],
+                    self._axis(1, self._grid_positions(height))[(tok // width) % height],
+                    self._axis(2, self._grid_positions(width))[tok % width])
+        return torch.cat(per_axis, dim=-1).contiguous()
 
     def forward(self, video_fhw, txt_seq_lens, device):
-        if isinstance(video_fhw, list):
-            video_fhw = video_fhw[0]
-        if not isinstance(video_fhw, list):
-            video_fhw = [video_fhw]
-        vid_freqs, max_vid_index = [], 0
-        for idx, fhw in enumerate(video_fhw):
-            frame, height, width = fhw
-            key = (idx, frame, height, width)
+        shapes = video_fhw[0] if isinstance(video_fhw, list) and isinstance(video_fhw[0], list) else video_fhw
+        if not isinstance(shapes, list):
+            shapes = [shapes]
+        tables, first_text_pos = [], 0
+        for idx, (frames, height, width) in enumerate(shapes):
+            key = (idx, frames, height, width)
             if key not in self.rope_cache:
-                self.rope_cache[key] = self._compute_video_freqs(frame, height, width, idx)
-            vid_freqs.append(self.rope_cache[key])
-            max_vid_index = max(height // 2, width // 2, max_vid_index) if self.scale_rope else max(height, width, max_vid_index)
-        max_len = max(txt_seq_lens)
-        txt_freqs = self.pos_freqs[max_vid_index: max_vid_index + max_len, ...]
-        return torch.cat(vid_freqs, dim=0).to(device), txt_freqs.to(device)
+                self.rope_cache[key] = self._video_table(idx, frames, height, width)
+            tables.append(self.rope_cache[key])
+            extent = max(height // 2, width // 2) if self.scale_rope else max(height, width)
+            first_text_pos = max(first_text_pos, extent)
+        text_pos = first_text_pos + torch.arange(max(txt_seq_lens))
+        text = torch.cat([self._axis(a, text_pos) for a in range(len(self.axes_dim))], dim=1)
+        return torch.cat(tables, dim=0).to(device), text.to(device)
 
 
 class WanRotaryPosEmbed:

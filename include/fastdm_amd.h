@@ -48,7 +48,8 @@ const char* fdm_last_hip_error_string(void);
 int fdm_abi_version(void);
 
 /* ---- replaces cuda_ops.rms_norm_ (ops.h:17-20; csrc/elmwise_ops.cu:56-84,433-449) -------------
- * out[r,:] = bf16(bf16(x[r,:] * rsqrt(mean(x^2)+eps)) * w[:]);  rows x hidden, contiguous.   */
+ * out[r,:] = bf16(bf16(x[r,:] * rsqrt(mean(x^2)+eps)) * w[:]);  rows x hidden, contiguous.  Any hidden >= 1: widths that
+ * are multiples of 8 on 16-byte aligned buffers take the vector kernels, everything else a scalar kernel (same arithmetic). */
 int fdm_rms_norm(void* out, const void* in, const void* weight, float eps,
                  int64_t rows, int hidden, fdm_stream_t stream);
 /* Same arithmetic on rows that are slices of wider matrices (Wan: q / k columns of the fused qkv projection,

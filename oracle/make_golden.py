@@ -1179,6 +1179,34 @@ def gen_c3_equal_inputs(rows=128, seed=0):
     use_backend("torch")
     return d
 
+def gen_radial_full():
+    """BASELINE.json configs[4] at its real size: Wan2.2-T2V-A14B 768x1280x81f = 21 latent frames x 48 x 80 tokens (S = 80 640),
+    the reference's own radial-attention config (examples/sparse/radial_attn_wan.json: block 64, decay 0.3).  The reference's mask
+    generator (fastdm/sparse/xsparse.py:71-183) runs on CPU in about a minute; the 1260 x 1260 block mask and the kernel-format
+    mask are stored bit-packed."""
+    import_reference()
+    import contextlib
+    import io
+    import json
+    from fastdm.sparse.xsparse import SparseAttn, sparge_mask_convert
+    cfg = json.load(open(os.path.join(REF, "examples", "sparse", "radial_attn_wan.json")))
+    frames, tpf = 21, 48 * 80
+    sa = SparseAttn.from_dict(cfg)
+    sa.post_init(video_token_num=frames * tpf, num_frame=frames)
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        lm = sa.gen_log_mask_shrinked(frames * tpf, torch.device("cpu"))
+    km = sparge_mask_convert(lm, block_size=int(cfg["block_size"]), arch="sm80")
+    print(f"radial mask {tuple(lm.shape)} -> kernel mask {tuple(km.shape)} in {time.time() - t0:.0f}s; density {lm.float().mean():.4f}")
+    d = {"geom": np.array([frames, tpf, int(cfg["block_size"])], dtype=np.int64), "decay": float(cfg["decay_factor"]),
+         "log_mask_shape": np.array(lm.shape, dtype=np.int64), "kernel_mask_shape": np.array(km.shape, dtype=np.int64),
+         "log_mask_bits": np.packbits(lm.to(torch.uint8).numpy().reshape(-1)),
+         "kernel_mask_bits": np.packbits(km.to(torch.uint8).numpy().reshape(-1))}
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, "wan_radial_mask_a14b_768x1280x81f.npz")
+    np.savez_compressed(path, **d)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB")
+
 
 def main():
     ap = argparse.ArgumentParser()

@@ -7,7 +7,9 @@ import torch.nn.functional as F
 
 from oracle import ops as O
 from oracle import wan as OW
-from oracle.make_golden import load
+import os
+
+from oracle.make_golden import GOLD, load
 
 pytestmark = pytest.mark.gpu
 BF16, FP8 = torch.bfloat16, torch.float8_e4m3fn
@@ -288,3 +290,55 @@ def test_full_width_wan_against_reference_core(tag, qt):
     print(f"Wan full width {tag}: max|d| {d.max().item():.4f} mean|d| {d.mean().item():.5f} on mean|ref| {ref.float().abs().mean().item():.3f}")
     lim = {"bf16": (6e-2, 6e-3), "fp8": (2.5e-1, 3e-2)}[tag]
     assert torch.isfinite(out.float()).all() and d.max() <= lim[0] and d.mean() <= lim[1], (tag, d.max().item(), d.mean().item())
+
+
+# ------------------------------------------------------------------ BASELINE.json configs[4] at its real size
+def test_radial_mask_and_sparse_attention_at_a14b_size():
+    """Wan2.2-T2V-A14B 768x1280x81f = 21 x 48 x 80 = 80 640 video tokens with the reference's own radial config
+    (examples/sparse/radial_attn_wan.json: block 64, decay 0.3).
+    (1) the GPU mask generator reproduces the reference generator's 1260 x 1260 block mask and its kernel-format mask bit for
+        bit (tests/golden/wan_radial_mask_a14b_768x1280x81f.npz, `python -m oracle.make_golden radial_full`);
+    (2) one A14B-width attention (40 heads x 128) over all 80 640 tokens through the block-sparse kernel with that mask equals
+        the oracle's definition (fp32 softmax over the keys of the kept blocks, -inf elsewhere) on sampled query rows, at the
+        reference's tolerance for dense attention (tests/test_attention.py:94)."""
+    import numpy as np
+    from fastdm_amd import _native as N
+    from fastdm_amd.kernel import fused
+    from fastdm_amd.sparse import SparseAttn
+    path = os.path.join(GOLD, "wan_radial_mask_a14b_768x1280x81f.npz")
+    if not os.path.exists(path):
+        pytest.skip("full-size radial mask fixture not generated")
+    g = np.load(path)
+    frames, tpf, bs = (int(v) for v in g["geom"])
+    S = frames * tpf
+    want_lm = torch.from_numpy(np.unpackbits(g["log_mask_bits"])[: int(np.prod(g["log_mask_shape"]))].reshape(tuple(g["log_mask_shape"])))
+    want_km = torch.from_numpy(np.unpackbits(g["kernel_mask_bits"])[: int(np.prod(g["kernel_mask_shape"]))].reshape(tuple(g["kernel_mask_shape"])))
+    sa = SparseAttn.from_dict({"sparse_algorithm": "radial", "model_type": "wan", "block_size": bs, "enable_sparse": True,
+                               "decay_factor": float(g["decay"]), "dense_layers": 1, "dense_steps": 11})
+    sa.post_init(video_token_num=S, num_frame=frames)
+    lm = sa.gen_log_mask_shrinked(S, torch.device("cuda"))
+    assert torch.equal(lm.cpu().to(torch.uint8), want_lm)
+    km = sa.kernel_mask(S, torch.device("cuda"))
+    assert km.shape == (S // 128, S // 64) and torch.equal(km.cpu().to(torch.uint8), want_km)
+    density = km.float().mean().item()
+    assert 0.15 < density < 0.35, density          # the reference config keeps about a quarter of the blocks
+    # (2) sparse attention at full size against the oracle's definition on sampled rows
+    H, hd = 40, 128
+    D = H * hd
+    q, k, v = (fused.synth_fill(torch.empty((S, D), dtype=BF16, device="cuda"), seed, 0, 1.0 / 37837.0) for seed in (21, 22, 23))   # ~N(0,1)
+    mask = km[None, None].expand(1, H, -1, -1).contiguous()
+    out = torch.empty_like(q)
+    N.check(N.lib().fdm_attn_fwd(N.ptr(out), N.ptr(q), N.ptr(k), N.ptr(v), 1, S, S, H, H, hd, D, D, D, D, hd ** -0.5, N.ptr(mask), 128, 64,
+                                 None, 0, N.stream()), "radial block-sparse attention")
+    assert torch.isfinite(out[::1024].float()).all()
+    rows = torch.tensor([0, 1, 127, 128, 3839, 3840, 40320, 40321 + 128, S - 3841, S - 129, S - 1], device="cuda")
+    key_keep = km[(rows // 128)].bool().repeat_interleave(64, dim=1)          # [rows, S]: keys of the kept 64-key blocks
+    worst_max, worst_mean = 0.0, 0.0
+    for h in (0, 19, 39):
+        sl = slice(h * hd, (h + 1) * hd)
+        sc = (q[rows][:, sl].float() @ k[:, sl].float().t()) * hd ** -0.5
+        sc = sc.masked_fill(~key_keep, float("-inf"))
+        ref = torch.softmax(sc, dim=-1) @ v[:, sl].float()
+        d = (out[rows][:, sl].float() - ref).abs()
+        worst_max, worst_mean = max(worst_max, d.max().item()), max(worst_mean, d.mean().item())
+    assert worst_max <= 1.8e-2 and worst_mean <= 1e-3, (worst_max, worst_mean)
