@@ -35,14 +35,19 @@ HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128>", "attn_sparse_bf16"
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, made by
-    tools/gpu_evidence.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950 guide
-    prescribes).  None when the file does not hold this kernel for this workload."""
+    """(HBM bytes per launch of `kernel`, provenance) from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    made by tools/gpu_evidence.sh: FETCH_SIZE and WRITE_SIZE in separate passes -- counters cannot be collected inside a
+    timed run -- FETCH_SIZE doubled as the gfx950 guide prescribes).  The file records the digest of the kernel sources it
+    was taken with: if the running library was built from other sources the number is stale and None is reported."""
     try:
+        from fastdm_amd import _native
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
-    except Exception:  # noqa: BLE001
-        return None
+            d = json.load(f)
+        if d.get("srcdigest") != _native.current_source_digest():
+            return None, f"profiles/pmc_traffic.json is stale (taken at source digest {str(d.get('srcdigest'))[:12]}, library is {_native.current_source_digest()[:12]})"
+        return d["kernels"][kernel]["hbm_bytes_per_launch"], f"profiles/pmc_traffic.json ({d.get('note', '')[:60]}; source digest {d['srcdigest'][:12]} = this library)"
+    except Exception as e:  # noqa: BLE001
+        return None, f"no PMC record for this kernel ({type(e).__name__})"
 
 
 def cpu_baseline_leg(height, width, n_txt, quant_tag):
@@ -391,10 +396,10 @@ def main():
                              "achieved_TFLOPs": tf, "peak_TFLOPs": PEAK_TFLOPS[dt], "frac": tf / PEAK_TFLOPS[dt]}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         default_workload = (args.model, args.height, args.width, args.max_seq_len, args.quant, args.cache_config) == ("flux", 1024, 2048, 512, "fp8", None)
+        traffic, traffic_src = pmc_traffic(HIP_KERNEL.get(dom, dom)) if default_workload else (None, "not the default workload")
         out["roofline"] = {"kernel": HIP_KERNEL.get(dom, dom), "span": dom, "bound": "mfma", "achieved": kernels[dom]["achieved_TFLOPs"],
                            "peak": kernels[dom]["peak_TFLOPs"], "unit": "TFLOP/s", "frac": kernels[dom]["frac"],
-                           "traffic": pmc_traffic(HIP_KERNEL.get(dom, dom)) if default_workload else None,
-                           "avg_launch_ms": kernels[dom]["avg_ms"]}
+                           "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": kernels[dom]["avg_ms"]}
         out["kernels"] = kernels
         flops_step = sum(s["work"] for s in summ.values()) / args.steps
         out["step_TFLOP"] = flops_step / 1e12

@@ -85,13 +85,18 @@ def _source_digest(srcs) -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False) -> str:
-    """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU).  The library is rebuilt only
-    when the sources' content digest changed (file times do not survive a copy to another machine)."""
+def current_source_digest() -> str:
+    """Content digest of everything libfastdm_amd.so is built from (kernel sources, build script, the C-ABI header)."""
     srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))
             if f.endswith((".hip", ".h", ".sh"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "fastdm_amd.h"))
-    digest = _source_digest(srcs)
+    return _source_digest(srcs)
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU).  The library is rebuilt only
+    when the sources' content digest changed (file times do not survive a copy to another machine)."""
+    digest = current_source_digest()
     stamp = LIB_PATH + ".srcdigest"
     if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
         return LIB_PATH

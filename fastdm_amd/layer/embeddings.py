@@ -265,10 +265,14 @@ class WanTimeTextImageEmbedding:
                                if image_embed_dim is not None else None)
 
     def forward(self, timestep, encoder_hidden_states, encoder_hidden_states_image=None, timestep_seq_len=None):
-        assert timestep_seq_len is None, "per-token timesteps (wan2.2 ti2v) are not built"
+        """timestep [B], or [B * S] with `timestep_seq_len` = S (wan2.2 ti2v: one timestep per token, embeddings.py:979-980):
+        temb and timestep_proj then carry a token axis ([B, S, D] / [B, S, 6 D])."""
         ts = self.timesteps_proj.forward(timestep).to(torch.float32)
         temb = self.time_embedder.forward(ts).type_as(encoder_hidden_states)
         timestep_proj = self.time_proj.forward(F.silu(temb))
+        if timestep_seq_len is not None:
+            temb = temb.unflatten(0, (-1, timestep_seq_len))
+            timestep_proj = timestep_proj.unflatten(0, (-1, timestep_seq_len))
         img = self.image_embedder.forward(encoder_hidden_states_image) if encoder_hidden_states_image is not None else None
         return temb, timestep_proj, self.text_embedder.forward(encoder_hidden_states), img
 

@@ -27,7 +27,12 @@ class JointTransformerBlock:
     def __init__(self, dim: int, num_attention_heads: int, attention_head_dim: int, context_pre_only: bool = False,
                  qk_norm: Optional[str] = None, use_dual_attention: bool = False, data_type: torch.dtype = BF16):
         if qk_norm != "rms_norm":
-            raise NotImplementedError("SD3.0 (qk_norm=None) is not built; SD3.5 uses rms_norm")
+            # upstream cannot run this either: its loader reads attn.norm_q / norm_k / norm_added_* from the checkpoint
+            # unconditionally (fastdm/model/sd35.py:303-304,311-312) and its Attention always applies them
+            # (layer/transformer.py:203,274-275), so an SD3.0 checkpoint (no q/k norm weights) fails in init_weight there:
+            # there is no reference behaviour to match
+            raise NotImplementedError("SD3.0 (qk_norm=None): the reference itself cannot load a checkpoint without q/k norm weights "
+                                      "(fastdm/model/sd35.py:303-304); SD3.5 uses rms_norm")
         self.use_dual_attention, self.context_pre_only = use_dual_attention, context_pre_only
         self.norm1 = SD35AdaLayerNormZeroX(dim, data_type=data_type) if use_dual_attention else AdaLayerNormZero(dim, data_type=data_type)
         self.norm1_context = (AdaLayerNormContinuous(dim, dim, elementwise_affine=False, eps=1e-6, bias=True, data_type=data_type)

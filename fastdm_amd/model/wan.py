@@ -50,13 +50,20 @@ class WanTransformerBlock:
 
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, temb: torch.Tensor, rotary_emb,
                 sparse_attn=None, layer_index: Optional[int] = None, encoder_q=None) -> torch.Tensor:
-        """hidden_states [B, S, D] bf16; temb [B, 6, D]; rotary_emb: the merged [S, head_dim] table (or the reference's
-        (cos, sin) pair); encoder_q: optional pre-quantised text rows shared by all blocks."""
-        assert temb.ndim == 3, "per-token modulation (wan2.2 ti2v) is not built"
+        """hidden_states [B, S, D] bf16; temb [B, 6, D], or [B, S, 6, D] for per-token modulation (wan2.2 ti2v, wan.py:77-88: the
+        fp32 LN-modulate kernel and the fp32 gate epilogue then index their vectors per row instead of per batch element);
+        rotary_emb: the merged [S, head_dim] table (or the reference's (cos, sin) pair); encoder_q: optional pre-quantised text
+        rows shared by all blocks."""
         B, S, D = hidden_states.shape
         x = hidden_states.reshape(B * S, D)
-        shift_msa, scale_msa, gate_msa, c_shift, c_scale, c_gate = [t.squeeze(1).contiguous() for t in
-                                                                    (self.scale_shift_table + temb.float()).chunk(6, dim=1)]
+        if temb.ndim == 4:
+            shift_msa, scale_msa, gate_msa, c_shift, c_scale, c_gate = [t.reshape(B * S, D).contiguous() for t in
+                                                                        (self.scale_shift_table.unsqueeze(0) + temb.float()).chunk(6, dim=2)]
+            rpb = 1                      # rows per modulation vector
+        else:
+            shift_msa, scale_msa, gate_msa, c_shift, c_scale, c_gate = [t.squeeze(1).contiguous() for t in
+                                                                        (self.scale_shift_table + temb.float()).chunk(6, dim=1)]
+            rpb = S
         rope = rotary_emb
         if rope is not None and not torch.is_tensor(rope):
             rope = torch.cat((rope[0].squeeze()[:, 0::2], rope[1].squeeze()[:, 1::2]), dim=-1).to(hidden_states.dtype).contiguous()
@@ -67,11 +74,11 @@ class WanTransformerBlock:
             return pair[1] if quant is not None else pair[0]
 
         # 1. self-attention
-        n = pick(fused.ln_modulate_f32(x, scale_msa, shift_msa, S, quant=quant, eps=self.eps))
+        n = pick(fused.ln_modulate_f32(x, scale_msa, shift_msa, rpb, quant=quant, eps=self.eps))
         o = a1.attend(n, B, S, rope, sparse_attn=sparse_attn, layer_index=layer_index or 0)
         oq = a1.to_out.quantize_input(o) if a1.to_out.quant_type is not None else o
         x1 = torch.empty_like(x)
-        a1.to_out.forward_q(oq, epilogue=N.EPI_GATE_RESIDUAL_F32, gate=gate_msa, res=x, rows_per_batch=S, out=x1)
+        a1.to_out.forward_q(oq, epilogue=N.EPI_GATE_RESIDUAL_F32, gate=gate_msa, res=x, rows_per_batch=rpb, out=x1)
         # 2. cross-attention (plain bf16 residual add = gate 1)
         if self.cross_attn_norm:
             n = pick(self.norm2.forward_bf16(x1, quant=quant))
@@ -99,8 +106,8 @@ class WanTransformerBlock:
         x2 = torch.empty_like(x)
         a2.to_out.forward_q(oq, epilogue=N.EPI_GATE_RESIDUAL, gate=self._ones, res=x1, rows_per_batch=B * S, out=x2)
         # 3. feed-forward
-        n = pick(fused.ln_modulate_f32(x2, c_scale, c_shift, S, quant=quant, eps=self.eps))
-        x3 = self.ffn.forward_fused(n, c_gate, x2, S, gate_epilogue=N.EPI_GATE_RESIDUAL_F32)
+        n = pick(fused.ln_modulate_f32(x2, c_scale, c_shift, rpb, quant=quant, eps=self.eps))
+        x3 = self.ffn.forward_fused(n, c_gate, x2, rpb, gate_epilogue=N.EPI_GATE_RESIDUAL_F32)
         return x3.view(B, S, D)
 
 
@@ -211,8 +218,12 @@ class WanTransformer3DModelCore(BaseModelCore):
         x = self.patch_embedding.forward_q(patches).view(B, S, self.inner_dim)
         if encoder_hidden_states_image is not None:
             encoder_hidden_states_image = encoder_hidden_states_image.to(dev)
-        temb, timestep_proj, enc, enc_img = self.condition_embedder.forward(timestep, encoder_hidden_states, encoder_hidden_states_image)
-        timestep_proj = timestep_proj.unflatten(1, (6, -1))
+        ts_len = None
+        if timestep.ndim == 2:                        # wan2.2 ti2v: [B, S] timesteps, one per token (wan.py:319-322)
+            ts_len, timestep = timestep.shape[1], timestep.flatten()
+        temb, timestep_proj, enc, enc_img = self.condition_embedder.forward(timestep, encoder_hidden_states, encoder_hidden_states_image,
+                                                                            timestep_seq_len=ts_len)
+        timestep_proj = timestep_proj.unflatten(2, (6, -1)) if ts_len is not None else timestep_proj.unflatten(1, (6, -1))
         a2 = self.blocks[0].attn2
         e2 = enc.reshape(B * enc.shape[1], -1).contiguous()
         # every block quantises the same text rows for its to_kv projection: do it once
@@ -231,9 +242,14 @@ class WanTransformer3DModelCore(BaseModelCore):
         finally:
             self._enc_q = None
         # output norm: (scale_shift_table + temb) in bf16, `1 + scale` rounded to bf16 by the reference's type promotion (wan.py:353-362)
-        shift, scale = (self.scale_shift_table + temb.unsqueeze(1)).chunk(2, dim=1)
-        scale_f = (1 + scale.squeeze(1)).float() - 1.0
-        y, _ = fused.ln_modulate_f32(x.reshape(B * S, -1), scale_f.contiguous(), shift.squeeze(1).float().contiguous(), S, quant=None, eps=self.eps)
+        if temb.ndim == 3:                            # per token (wan.py:355-359)
+            shift, scale = [t.reshape(B * S, -1) for t in (self.scale_shift_table.unsqueeze(0) + temb.unsqueeze(2)).chunk(2, dim=2)]
+            out_rpb = 1
+        else:
+            shift, scale = [t.squeeze(1) for t in (self.scale_shift_table + temb.unsqueeze(1)).chunk(2, dim=1)]
+            out_rpb = S
+        scale_f = (1 + scale).float() - 1.0
+        y, _ = fused.ln_modulate_f32(x.reshape(B * S, -1), scale_f.contiguous(), shift.float().contiguous(), out_rpb, quant=None, eps=self.eps)
         y = self.proj_out.forward_q(y)
         y = y.reshape(B, ppf, pph, ppw, p_t, p_h, p_w, -1).permute(0, 7, 1, 4, 2, 5, 3, 6)
         output = y.flatten(6, 7).flatten(4, 5).flatten(2, 3)

@@ -520,6 +520,29 @@ def gen_tiny_wan_i2v():
     save("tiny_wan_i2v.npz", d)
 
 
+def gen_tiny_wan_ti2v():
+    """Wan2.2-TI2V: a [B, S] timestep tensor (one timestep per token: the conditioning frame's tokens sit at t = 0), i.e.
+    per-token AdaLN modulation in every block and in the output norm (wan.py:77-88, 319-329, 355-359), on the tiny core
+    through the reference."""
+    import_reference()
+    from oracle import wan as OW
+    cfg = OW.TINY
+    sd = OW.synth_state_dict(cfg, seed=33)
+    inp = OW.synth_inputs(cfg, batch=2, frames=3, height=8, width=8, n_txt=9, seed=33)
+    S = 3 * 4 * 4
+    ts = torch.full((2, S), 812.0)
+    ts[:, :16] = 0.0                      # first latent frame = the clean conditioning image
+    ts[1, 16:] = 377.0
+    d = {"seed": 33, "batch": 2, "frames": 3, "height": 8, "width": 8, "n_txt": 9, "timestep": ts}
+    for tag, qt in (("bf16", None), ("fp8", torch.float8_e4m3fn), ("int8", torch.int8)):
+        use_backend("cpu_fp8" if qt == torch.float8_e4m3fn else "torch")
+        core = ref_wan_core(cfg, qt, sd)
+        out = core.forward(hidden_states=inp["hidden_states"], timestep=ts, encoder_hidden_states=inp["encoder_hidden_states"], return_dict=False)
+        d[f"out_{tag}"] = out[0] if isinstance(out, (tuple, list)) else out
+    use_backend("torch")
+    save("tiny_wan_ti2v.npz", d)
+
+
 def controlnet_residuals(tag, shapes, seed=0, scale=0.25):
     """Stand-ins for the tensors a ControlNet would hand over: N(0, scale^2) from the shared counter-based generator."""
     from oracle import synth
@@ -1210,7 +1233,7 @@ def gen_radial_full():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3", "c3_traj", "radial_full", "c3_equal"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3", "c3_traj", "radial_full", "c3_equal", "wan_ti2v"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     ap.add_argument("--steps", type=int, default=4, help="c3_traj: denoise steps of the 25-step schedule")
@@ -1239,6 +1262,8 @@ def main():
         gen_controlnet_residual_inputs()
     if args.what in ("small", "wan_i2v"):
         gen_tiny_wan_i2v()
+    if args.what in ("small", "wan_ti2v"):
+        gen_tiny_wan_ti2v()
     if args.what in ("small", "sd3_wan_cache"):
         gen_cache_sd3_wan()
     if args.what in ("small", "sdxl"):

@@ -178,8 +178,10 @@ class WanConditionEmbedder:
         h = m["f2"](F.gelu(m["f1"](h)))                                       # FeedForward(mult=1, activation_fn="gelu"): erf GELU
         return fp32_layer_norm(h, *m["n2"], eps=1e-5).to(h.dtype)
 
-    def __call__(self, timestep, encoder_hidden_states):
+    def __call__(self, timestep, encoder_hidden_states, timestep_seq_len=None):
         ts = L.timestep_embedding(timestep, self.freq_dim)                       # fp32 [cos | sin]
+        if timestep_seq_len is not None:                                         # wan2.2 ti2v: one timestep per token (embeddings.py:979-980)
+            ts = ts.unflatten(0, (-1, timestep_seq_len))
         temb = (F.silu(ts @ self.w1.t() + self.b1) @ self.w2.t() + self.b2)     # fp32 QLinear: torch.addmm (qlinear.py:76)
         temb = temb.type_as(encoder_hidden_states)
         timestep_proj = self.time_proj(F.silu(temb))
@@ -326,7 +328,11 @@ class WanTransformerBlock:
         self.eps = cfg.eps
 
     def __call__(self, hidden, encoder, temb6, rope, block_mask=None):
-        shift_msa, scale_msa, gate_msa, c_shift, c_scale, c_gate = (self.table + temb6.float()).chunk(6, dim=1)
+        if temb6.ndim == 4:      # [B, S, 6, D]: per-token modulation (wan2.2 ti2v, wan.py:77-88)
+            shift_msa, scale_msa, gate_msa, c_shift, c_scale, c_gate = [t.squeeze(2) for t in
+                                                                        (self.table.unsqueeze(0) + temb6.float()).chunk(6, dim=2)]
+        else:
+            shift_msa, scale_msa, gate_msa, c_shift, c_scale, c_gate = (self.table + temb6.float()).chunk(6, dim=1)
         n = (fp32_layer_norm(hidden, eps=self.eps) * (1 + scale_msa) + shift_msa).type_as(hidden)
         a = self.attn1(n, None, rope, block_mask)
         hidden = (hidden.float() + a * gate_msa).type_as(hidden)
@@ -369,8 +375,11 @@ class WanCore:
         rope = wan_rope_cache(cfg, Fr, H, W, hidden_states.dtype)
         x = F.conv3d(hidden_states, self.patch_w, self.patch_b, cfg.patch_size)
         x = x.flatten(2).transpose(1, 2)
-        temb, tproj, enc = self.cond(timestep, encoder_hidden_states)
-        tproj = tproj.unflatten(1, (6, -1))
+        ts_len = None
+        if timestep.ndim == 2:                                       # wan2.2 ti2v (wan.py:319-322)
+            ts_len, timestep = timestep.shape[1], timestep.flatten()
+        temb, tproj, enc = self.cond(timestep, encoder_hidden_states, timestep_seq_len=ts_len)
+        tproj = tproj.unflatten(2, (6, -1)) if ts_len is not None else tproj.unflatten(1, (6, -1))
         if encoder_hidden_states_image is not None:                  # wan.py:333-334
             enc = torch.concat([self.cond.image_embed(encoder_hidden_states_image), enc], dim=1)
         if getattr(self, "cache_fn", None) is not None:      # step cache hook (wan.py:339-349): f(core, hidden, encoder, temb6, rope)
@@ -378,7 +387,10 @@ class WanCore:
         else:
             for li, blk in enumerate(self.blocks):
                 x = blk(x, enc, tproj, rope, self.block_mask(li, x.shape[1], ppf, B))
-        shift, scale = (self.table + temb.unsqueeze(1)).chunk(2, dim=1)
+        if temb.ndim == 3:                                           # per token (wan.py:355-359)
+            shift, scale = [t.squeeze(2) for t in (self.table.unsqueeze(0) + temb.unsqueeze(2)).chunk(2, dim=2)]
+        else:
+            shift, scale = (self.table + temb.unsqueeze(1)).chunk(2, dim=1)
         x = (fp32_layer_norm(x, eps=cfg.eps) * (1 + scale) + shift).type_as(x)
         x = self.proj_out(x)
         x = x.reshape(B, ppf, pph, ppw, pt, ph, pw, -1).permute(0, 7, 1, 4, 2, 5, 3, 6)

@@ -267,6 +267,24 @@ def test_wan_i2v_tiny_core_matches_reference(tag, qt):
     assert d.max() <= lim[0] and d.mean() <= lim[1], (tag, d.max().item(), d.mean().item())
 
 
+@pytest.mark.parametrize("tag,qt", [("bf16", None), ("fp8", torch.float8_e4m3fn), ("int8", torch.int8)])
+def test_oracle_tiny_wan_ti2v_against_reference(tag, qt):
+    """Wan2.2-TI2V: [B, S] timesteps = per-token AdaLN modulation in every block and in the output norm (wan.py:77-88,319-329,
+    355-359), against the reference itself (tests/golden/tiny_wan_ti2v.npz)."""
+    from oracle import wan as OW
+    g = load("tiny_wan_ti2v.npz")
+    cfg = OW.TINY
+    sd = OW.synth_state_dict(cfg, seed=int(g["seed"]))
+    inp = OW.synth_inputs(cfg, int(g["batch"]), int(g["frames"]), int(g["height"]), int(g["width"]), int(g["n_txt"]), seed=int(g["seed"]))
+    out = OW.WanCore(sd, cfg, qt).forward(inp["hidden_states"], g["timestep"], inp["encoder_hidden_states"])[0]
+    ref = g[f"out_{tag}"]
+    assert out.shape == ref.shape == (2, 16, 3, 8, 8)
+    d = (out.float() - ref.float()).abs()
+    # measured: bf16 0.020 / 0.0031, fp8 0.070 / 0.0110, int8 0.031 / 0.0050 (fp32-softmax attention vs the reference's torch SDPA)
+    lim = {"bf16": (3e-2, 5e-3), "fp8": (1.2e-1, 1.8e-2), "int8": (5e-2, 8e-3)}[tag]
+    assert d.max() <= lim[0] and d.mean() <= lim[1], (tag, d.max().item(), d.mean().item())
+
+
 def test_wan_radial_masks_bit_exact():
     """The radial block-sparse mask generator (fastdm/sparse/xsparse.py:71-183) and the kernel-mask conversion
     (xsparse.py:227-250, non-sm90 branch -> 128 x 64 blocks) against masks produced by the reference on CPU."""

@@ -292,6 +292,29 @@ def test_full_width_wan_against_reference_core(tag, qt):
     assert torch.isfinite(out.float()).all() and d.max() <= lim[0] and d.mean() <= lim[1], (tag, d.max().item(), d.mean().item())
 
 
+@pytest.mark.parametrize("tag,qt", [("bf16", None), ("fp8", FP8), ("int8", torch.int8)])
+def test_tiny_wan_ti2v_per_token_timesteps_against_reference_golden(tag, qt):
+    """Wan2.2-TI2V (wan.py:77-88,319-329,355-359): a [B, S] timestep tensor -- the conditioning frame's tokens at t = 0 -- gives
+    per-token fp32 modulation vectors: fdm_ln_modulate_f32 and the fp32 gate epilogue index them per row (rows_per_batch = 1).
+    Against the reference itself (tests/golden/tiny_wan_ti2v.npz)."""
+    from oracle.make_golden import load
+    g = load("tiny_wan_ti2v.npz")
+    cfg = OW.TINY
+    model = tiny_core(qt, seed=int(g["seed"]), cfg=cfg)
+    inp = OW.synth_inputs(cfg, int(g["batch"]), int(g["frames"]), int(g["height"]), int(g["width"]), int(g["n_txt"]), seed=int(g["seed"]))
+    out = model(hidden_states=inp["hidden_states"].cuda(), timestep=g["timestep"].cuda(), encoder_hidden_states=inp["encoder_hidden_states"].cuda(),
+                return_dict=False)[0]
+    assert out.shape == (2, 16, 3, 8, 8)
+    lim = {"bf16": (4e-2, 6e-3), "fp8": (1.4e-1, 2.2e-2), "int8": (6e-2, 1e-2)}[tag]
+    close(out, g[f"out_{tag}"], lim[0], lim[1], f"tiny wan ti2v {tag}")
+    # a constant [B, S] timestep tensor is the [B] path, bit for bit (same vectors, indexed per row instead of per batch element)
+    t = torch.tensor([700.0, 333.0]).cuda()
+    a = model(hidden_states=inp["hidden_states"].cuda(), timestep=t, encoder_hidden_states=inp["encoder_hidden_states"].cuda(), return_dict=False)[0]
+    b = model(hidden_states=inp["hidden_states"].cuda(), timestep=t[:, None].expand(2, 48).contiguous(), encoder_hidden_states=inp["encoder_hidden_states"].cuda(),
+              return_dict=False)[0]
+    assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------ BASELINE.json configs[4] at its real size (VERDICT r1, weak 3)
 def test_radial_mask_and_sparse_attention_at_a14b_size():
     """Wan2.2-T2V-A14B 768x1280x81f = 21 x 48 x 80 = 80 640 video tokens with the reference's own radial config
