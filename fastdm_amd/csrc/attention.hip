@@ -460,7 +460,7 @@ __device__ unsigned long long g_att_stamps[4096 * 8];
 #define FDM_STAMP(VAR)
 #endif
 
-template <int D>
+template <int D, bool MASKED>
 __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) {
   static_assert(D == 128, "64-row kernel: head_dim 128");
   constexpr int KT = 64, NST = 4, CPR = D / 8;
@@ -495,9 +495,52 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
   const uint8_t* vbase = reinterpret_cast<const uint8_t*>(p.v + ((int64_t)b * p.sk) * p.v_ts + (int64_t)kvh * D);
 
   const int ntiles = (int)((p.sk + KT - 1) / KT);
-  const int t_begin = is_part ? (int)((int64_t)part * ntiles / p.split) : 0;
-  const int t_end = is_part ? (int)((int64_t)(part + 1) * ntiles / p.split) : ntiles;
   const int t_tail = (p.sk % KT != 0) ? ntiles - 1 : -1;   // the one tile whose keys need masking
+
+  // ---- block mask (MASKED): a 256-row block spans the mask rows of its four waves (two rows of a 128 x 64 block mask).
+  //      The block walks the UNION of their active key tiles; entry = tile index | (wave w's row keeps it) << (12 + w),
+  //      compacted once into LDS by wave 0 (ballot + popcount).  A wave whose own row drops a tile of the union still
+  //      runs its MFMAs (the block moves in lockstep behind one barrier per tile) and overwrites the scores with -inf.
+  //      The loop then runs over list positions instead of tile indices.
+  constexpr int MAXL = MASKED ? 4096 : 4, LPAD = 16;
+  __shared__ __attribute__((aligned(16))) uint16_t slist[MAXL + LPAD];
+  __shared__ int s_nlist;
+  if constexpr (MASKED) {
+    if (wave == 0) {
+      const int8_t* mrow[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        int64_t r = (q0 + w * 64) / p.mask_bq;
+        if (r > p.mask_nq - 1) r = p.mask_nq - 1;
+        mrow[w] = p.mask + (((int64_t)b * p.heads + head) * p.mask_nq + r) * p.mask_nk;
+      }
+      int cnt = 0, last_t = 0;
+      for (int base = 0; base < ntiles; base += 64) {
+        const int tt = base + lane;
+        unsigned bits = 0;
+        if (tt < ntiles) {
+          const int c = (int)(((int64_t)tt * KT) / p.mask_bk);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) bits |= (mrow[w][c] != 0 ? 1u : 0u) << w;
+        }
+        const unsigned long long bal = __ballot(bits != 0);
+        if (bits != 0) slist[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(tt | (bits << 12));
+        if (bal != 0) last_t = base + 63 - __builtin_clzll(bal);
+        cnt += __popcll(bal);
+      }
+      if (lane < LPAD) slist[cnt + lane] = (uint16_t)last_t;   // run-ahead DMAs past the end re-read the last tile (no wave keeps it)
+      if (lane == 0) s_nlist = cnt;
+    }
+    __syncthreads();
+  }
+  const int t_begin = MASKED ? 0 : (is_part ? (int)((int64_t)part * ntiles / p.split) : 0);
+  const int t_end = MASKED ? s_nlist : (is_part ? (int)((int64_t)(part + 1) * ntiles / p.split) : ntiles);
+  int le[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // MASKED: list entries of positions g .. g+7 (g = the 4-step group's first position), wave-uniform
+  if constexpr (MASKED) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) le[i] = __builtin_amdgcn_readfirstlane((int)slist[i]);
+  }
+  const uint32_t list_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)slist;
 
   // ---- K/V staging by LDS-DMA: lane-linear destination, swizzle on the source side (as in attn_fwd_kernel).  The source
   //      is a wave-uniform tile base (SALU) plus a 32-bit per-lane offset that never changes; the rows of a partial last
@@ -536,12 +579,14 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
   };
   static_for<4>([&](auto s_) {
     bool last;
-    const uint8_t* src = tile_src(kbase, p.k_ts, t_begin + decltype(s_)::value, last);
+    auto& le_ = le;
+    const uint8_t* src = tile_src(kbase, p.k_ts, MASKED ? (le_[decltype(s_)::value] & 0xfff) : t_begin + decltype(s_)::value, last);
     static_for<4>([&](auto i) { dma_k(src, last, decltype(s_)::value, i); });
   });
   static_for<3>([&](auto s_) {
     bool last;
-    const uint8_t* src = tile_src(vbase, p.v_ts, t_begin + decltype(s_)::value, last);
+    auto& le_ = le;
+    const uint8_t* src = tile_src(vbase, p.v_ts, MASKED ? (le_[decltype(s_)::value] & 0xfff) : t_begin + decltype(s_)::value, last);
     static_for<4>([&](auto i) { dma_v(src, last, decltype(s_)::value, i); });
   });
 
@@ -712,7 +757,18 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
     }
   };
   // decision for tile t: tail masking and the wave-wide vote on the row maxima mx (of S' = scores - reference)
-  auto decide = [&](f32x16 (&S)[2][2], float (&mx)[2], int t, bool first, bool have_mx) {
+  auto decide = [&](f32x16 (&S)[2][2], float (&mx)[2], int t, bool first, bool have_mx, bool dead) {
+    if (dead) {   // MASKED: this wave's mask row drops the tile
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) S[kb][qb][e] = -INFINITY;
+      mx[0] = mx[1] = -INFINITY;
+      if (first) fixup(S, mx, true);   // a row without any key yet keeps reference 0
+      return;
+    }
     const bool tail = (t == ntiles - 1) && (p.sk % KT != 0);
     if (tail) {
       const int rem = (int)(p.sk - (int64_t)t * KT) - 4 * h;
@@ -755,8 +811,17 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
 #endif
     FDM_STAMP(ts0);
     bool klast, vlast;
-    const uint8_t* ksrc = tile_src(kbase, p.k_ts, t + 4, klast);
-    const uint8_t* vsrc = tile_src(vbase, p.v_ts, t + 3, vlast);
+    int tk = t + 4, tv = t + 3, tn = t + 1;   // tiles: K DMA (position t+4), V DMA (t+3), the S tile of phase A (t+1)
+    bool dead = false;
+    if constexpr (MASKED) {
+      auto& le_ = le;
+      tk = le_[I + 4] & 0xfff;
+      tv = le_[I + 3] & 0xfff;
+      tn = le_[I + 1] & 0xfff;
+      dead = ((le_[I + 1] >> (12 + wave)) & 1) == 0;
+    }
+    const uint8_t* ksrc = tile_src(kbase, p.k_ts, tk, klast);
+    const uint8_t* vsrc = tile_src(vbase, p.v_ts, tv, vlast);
     FDM_FENCE();
     // ---- phase A
     static_for<32>([&](auto g_) {
@@ -768,7 +833,8 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
         } else if constexpr (F + 3 < 16) FDM_READ_K(KS1, (F + 3 < 16 ? F + 3 : 0));
         else FDM_READ_V(VS0, (F + 3 - 16 >= 0 ? F + 3 - 16 : 0));
         // reads issued after fragment F's: K fragments count 1, V^T fragments 2
-        constexpr int newer = F <= 12 ? 3 : (F == 13 ? 4 : (F == 14 ? 5 : 6));
+        // (MASKED, first step of a group: the list read issued in front of the step sits between K fragments 2 and 3)
+        constexpr int newer = (F <= 12 ? 3 : (F == 13 ? 4 : (F == 14 ? 5 : 6))) + ((MASKED && I == 0 && F < 3) ? 1 : 0);
         if constexpr (!(FDM_A64_ABL & (2 | 128))) FDM_LGKM(newer);
       }
       if constexpr (ks == 0) FDM_MFMA_S_FIRST(Sn[kb][qb], kf[F & 3], qa_[qb][ks], mneg_[qb]);
@@ -871,7 +937,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
     // MFMA result -> VALU read of Sn: the ordering asm keeps every reader of Sn below the P.V MFMAs above
     asm volatile("" : "+v"(Sn[0][0]), "+v"(Sn[0][1]), "+v"(Sn[1][0]), "+v"(Sn[1][1]));
     // fix-up path only if some row's S' reached 1 (vote), or tile t+1 is the sequence's masked last tile
-    if (t + 1 < t_end && (vote != 0 || t + 1 == t_tail)) decide(Sn, mx, t + 1, false, true);
+    if (t + 1 < t_end && (vote != 0 || tn == t_tail || dead)) decide(Sn, mx, tn, false, true, dead);
     FDM_STAMP(ts4);
 #ifdef FDM_ATT_STAMPS
     st_a += ts1 - ts0; st_w += ts2 - ts1; st_b += ts3 - ts2; st_d += ts4 - ts3; st_n += 1;
@@ -905,7 +971,8 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
     });
     asm volatile("s_nop 7\n\ts_nop 7" : "+v"(Sa[0][0]), "+v"(Sa[0][1]), "+v"(Sa[1][0]), "+v"(Sa[1][1]));
     float mx[2];
-    decide(Sa, mx, t_begin, true, false);
+    if constexpr (MASKED) decide(Sa, mx, le[0] & 0xfff, true, false, ((le[0] >> (12 + wave)) & 1) == 0);
+    else decide(Sa, mx, t_begin, true, false, false);
     FDM_FENCE();
     FDM_READ_K(1, 0);
     FDM_READ_K(1, 1);
@@ -915,10 +982,21 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
   __builtin_amdgcn_s_barrier();   // every wave has read the first K tile: step 0 refills its ring slot
   FDM_FENCE();
   for (int t = t_begin; t < t_end; t += 4) {
+    i32x2 nxt;
+    if constexpr (MASKED) {   // list entries of the NEXT group's positions t+8 .. t+11, consumed behind step 3 (dozens of counted waits later)
+      asm volatile("ds_read_b64 %0, %1" : "=v"(nxt) : "v"(list_base + 2u * (uint32_t)(t + 8)) : FDM_VREGS);
+      FDM_FENCE();
+    }
     step(Sa, Sb, t, ic<0>{});
     if (t + 1 < t_end) step(Sb, Sa, t + 1, ic<1>{});
     if (t + 2 < t_end) step(Sa, Sb, t + 2, ic<2>{});
     if (t + 3 < t_end) step(Sb, Sa, t + 3, ic<3>{});
+    if constexpr (MASKED) {
+      int s0, s1;
+      asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(s0), "=s"(s1) : "v"(nxt[0]), "v"(nxt[1]) : FDM_VREGS);
+      le[0] = le[4]; le[1] = le[5]; le[2] = le[6]; le[3] = le[7];
+      le[4] = s0 & 0xffff; le[5] = (int)((unsigned)s0 >> 16); le[6] = s1 & 0xffff; le[7] = (int)((unsigned)s1 >> 16);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // run-ahead DMAs / fragment reads must not outlive the block
 #ifdef FDM_ATT_STAMPS
@@ -1068,7 +1146,8 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
   p.batch = (int)batch;
   p.heads = q_heads;
   p.kv_heads = kv_heads;
-  const int qb_rows = block_mask != nullptr ? 128 : QB;   // block-sparse: 4-wave blocks, one mask row each
+  const bool mask_v2 = FDM_ATT_V2 && block_mask != nullptr && head_dim == 128 && (sk + 63) / 64 <= 4096;   // 64-row-wave kernel, union of the block's mask rows
+  const int qb_rows = (block_mask != nullptr && !mask_v2) ? 128 : QB;   // old block-sparse path: 4-wave blocks, one mask row each
   p.n_qblocks = (int)((sq + qb_rows - 1) / qb_rows);
   p.mask_bq = p.mask_bk = 1;
   p.mask_nq = p.mask_nk = 0;
@@ -1124,12 +1203,14 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
       }
     }
   }
-  if (block_mask != nullptr) {
+  if (mask_v2) {
+    attn_fwd64_kernel<128, true><<<(unsigned)grid, 256, 0, s>>>(p);
+  } else if (block_mask != nullptr) {
     if (head_dim == 128) attn_fwd_kernel<128, 256, KT_MASK><<<(unsigned)grid, 256, 0, s>>>(p);
     else attn_fwd_kernel<64, 256, KT_MASK><<<(unsigned)grid, 256, 0, s>>>(p);
   } else {
 #if FDM_ATT_V2
-    if (head_dim == 128) attn_fwd64_kernel<128><<<(unsigned)grid, 256, 0, s>>>(p);
+    if (head_dim == 128) attn_fwd64_kernel<128, false><<<(unsigned)grid, 256, 0, s>>>(p);
 #else
     if (head_dim == 128) attn_fwd_kernel<128, 512, KT_DENSE><<<(unsigned)grid, 512, 0, s>>>(p);
 #endif

@@ -10,8 +10,10 @@ cd "$TMP"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wno-unused-result -save-temps \
     -c "$HERE/../../fastdm_amd/csrc/attention.hip" -o a.o 2> err.txt || { tail -20 err.txt; exit 1; }
 S=attention-hip-amdgcn-amd-amdhsa-gfx950.s
-awk '/^_ZN3fdm17attn_fwd64_kernelILi128EEEvNS_10AttnParamsE:/,/^\.Lfunc_end/' $S > k.s
-grep -A40 "amdhsa_kernel _ZN3fdm17attn_fwd64" $S | grep -E "next_free_vgpr|accum_offset|private_segment_fixed_size"
+# MASKED=1 audits the block-mask instantiation
+K="_ZN3fdm17attn_fwd64_kernelILi128ELb${MASKED:-0}EEEvNS_10AttnParamsE"
+awk -v k="^$K:" '$0 ~ k {on=1} on {print} on && /^\.Lfunc_end/ {exit}' $S > k.s
+grep -A40 "amdhsa_kernel _ZN3fdm17attn_fwd64_kernelILi128ELb${MASKED:-0}" $S | grep -E "next_free_vgpr|accum_offset|private_segment_fixed_size"
 python3 - <<'PY'
 import re, sys
 lines = open("k.s").read().split("\n")
