@@ -10,10 +10,10 @@ cd "$TMP"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wno-unused-result -save-temps \
     -c "$HERE/../../fastdm_amd/csrc/attention.hip" -o a.o 2> err.txt || { tail -20 err.txt; exit 1; }
 S=attention-hip-amdgcn-amd-amdhsa-gfx950.s
-# MASKED=1 audits the block-mask instantiation
-K="_ZN3fdm17attn_fwd64_kernelILi128ELb${MASKED:-0}EEEvNS_10AttnParamsE"
+# MASKED=1 audits the block-mask instantiation, HD=64 the head_dim-64 one
+K="_ZN3fdm17attn_fwd64_kernelILi${HD:-128}ELb${MASKED:-0}EEEvNS_10AttnParamsE"
 awk -v k="^$K:" '$0 ~ k {on=1} on {print} on && /^\.Lfunc_end/ {exit}' $S > k.s
-grep -A40 "amdhsa_kernel _ZN3fdm17attn_fwd64_kernelILi128ELb${MASKED:-0}" $S | grep -E "next_free_vgpr|accum_offset|private_segment_fixed_size"
+grep -A40 "amdhsa_kernel _ZN3fdm17attn_fwd64_kernelILi${HD:-128}ELb${MASKED:-0}" $S | grep -E "next_free_vgpr|accum_offset|private_segment_fixed_size"
 python3 - <<'PY'
 import re, sys
 lines = open("k.s").read().split("\n")
