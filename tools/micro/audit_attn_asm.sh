@@ -21,14 +21,15 @@ inasm = False
 bad = []
 loop_start = None
 for i, l in enumerate(lines):
-    if "Loop Header" in l and loop_start is None:
-        loop_start = i
+    if "Loop Header" in l:
+        loop_start = i          # the tile loop is the LAST loop of the kernel (the masked variant builds its tile list in an earlier one)
+for i, l in enumerate(lines):
     if "#ASMSTART" in l: inasm = True; continue
     if "#ASMEND" in l: inasm = False; continue
     code = l.split(";")[0]
     if not inasm and re.search(r"\ba(24[0-9]|25[0-5])\b|a\[(2[0-9][0-9]):(24[0-9]|25[0-5])\]", code):
         bad.append((i, l.strip()))
-    if not inasm and loop_start is not None and re.search(r"^\s*(s_load|s_buffer_load|ds_)", code) and "s_endpgm" not in code:
+    if not inasm and loop_start is not None and i > loop_start and re.search(r"^\s*(s_load|s_buffer_load|ds_)", code) and "s_endpgm" not in code:
         # compiler-generated scalar loads / LDS ops inside the loop region (the epilogue's ds_bpermute comes after the loop: allow ds_bpermute)
         if "ds_bpermute" not in code:
             bad.append((i, "in-loop: " + l.strip()))
