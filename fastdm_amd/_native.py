@@ -29,6 +29,8 @@ SIGNATURES = {
     "fdm_gemm_w8a8_fp8": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_gemm_w8a8_fp8_x2": (I32, [P, P, P]),
     "fdm_gemm_w8a8_int8_x2": (I32, [P, P, P]),
+    "fdm_gemm_w8a8_int8_x2_ws": (I32, [P, P, P, I64, P]),
+    "fdm_gemm_int8_workspace_bytes": (I64, []),
     "fdm_gemm_w8a8_int8": (I32, [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_gemm_bf16": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_attn_fwd": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I32, I32, P, I64, P]),
@@ -46,7 +48,7 @@ SIGNATURES = {
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
 }
 
-ABI_VERSION = 8          # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
+ABI_VERSION = 9          # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL, EPI_GATE_RESIDUAL_F32 = 0, 1, 2, 3, 4
 
 
@@ -174,4 +176,19 @@ def attn_workspace(device, head_dim):
         nbytes = int(lib().fdm_attn_fwd_workspace_bytes(head_dim))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _attn_ws[key] = ws
+    return ws
+
+
+_gemm_ws = {}
+
+
+def gemm_int8_workspace(device):
+    """Per-device scratch of fdm_gemm_w8a8_int8_x2_ws's split-K tail (64 MiB, allocated once).  One buffer per device is
+    enough for launches on ONE stream (the library's merge launch has consumed it before the next GEMM's parts write)."""
+    import torch
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _gemm_ws.get(key)
+    if ws is None:
+        ws = torch.empty(int(lib().fdm_gemm_int8_workspace_bytes()), dtype=torch.uint8, device=device)
+        _gemm_ws[key] = ws
     return ws

@@ -74,6 +74,11 @@ struct GemmGroup {
   GemmProblem p[2];
   int n;            // 1 or 2 problems
   int total_tiles;
+  // int8 split-K tail (exact: int32 partial sums): the last `split_tiles` tiles of the concatenated tile list are cut into
+  // `splits` K ranges each; their blocks write int32 accumulators to `ws` ([tile][part][32 quads][512 threads] x 16 B) and a
+  // second launch of the same kernel (mode 1, one block per tail tile) sums the parts and runs the epilogue.
+  int split_tiles, splits, mode, n_blocks, spread_shift;
+  int32_t* ws;
 #ifdef FDM_DEBUG_BUILD
   int debug;        // bring-up ablation (env FDM_GEMM_DEBUG, debug builds only): 4 = no stores
 #endif
@@ -227,11 +232,33 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
 
   // ---- block -> (problem, tile): XCD-contiguous ranges of the concatenated tile list, grouped raster inside a problem
   int prob = 0, m0, n0;
+  int part = 0, part_slot = 0;   // int8 split-K tail: this block's K range and workspace slot (is_part)
+  bool is_part = false;
   {
     const int nwg = grp.total_tiles;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    if constexpr (DT == DT_INT8) {
+      if (grp.mode == 1) {
+        t = grp.total_tiles - grp.split_tiles + (bid >> grp.spread_shift);   // merge launch: 1 << spread_shift blocks per tail tile
+      } else if (grp.splits > 1) {
+        // Blocks are dealt to the XCDs round-robin, so every XCD gets the same NUMBER of blocks: give each one an equal
+        // share of whole tiles (a contiguous range, dispatched first) and an equal share of the K parts (its last round).
+        const int tf = grp.total_tiles - grp.split_tiles, nb = grp.n_blocks;
+        const int fq = tf / 8 + (xcd < tf % 8 ? 1 : 0), fbase = xcd * (tf / 8) + min(xcd, tf % 8);
+        const int cbase = xcd * (nb / 8) + min(xcd, nb % 8), local = bid >> 3;
+        if (local < fq) {
+          t = fbase + local;
+        } else {
+          const int pi = (cbase - fbase) + (local - fq);   // part index 0 .. split_tiles * splits - 1
+          t = tf + pi / grp.splits;
+          part = pi % grp.splits;
+          part_slot = pi;          // = (tail tile) * splits + part
+          is_part = true;
+        }
+      }
+    }
     const int t0 = grp.p[0].tiles_m * grp.p[0].tiles_n;
     if (t >= t0) {
       prob = 1;
@@ -252,6 +279,16 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
   if (tid == 0) stamp[0] = __builtin_readcyclecounter();
 #endif
 
+  int64_t Kb = p.Kb, k_off = 0;
+  if constexpr (DT == DT_INT8) {
+    if (is_part) {   // K range of this part, in whole 64-byte steps; the last part takes the K tail
+      const int nk_all = (int)((p.Kb + BKB - 1) / BKB);
+      const int kt0 = (int)((int64_t)part * nk_all / grp.splits), kt1 = (int)((int64_t)(part + 1) * nk_all / grp.splits);
+      k_off = (int64_t)kt0 * BKB;
+      Kb = min(p.Kb - k_off, (int64_t)(kt1 - kt0) * BKB);
+    }
+  }
+
   // ---- staging: thread t, round i moves the 16-byte chunk that lands at (row = i*128 + t/4, slot = t%4)
   const int srow = tid >> 2;
   const int schunk = (tid & 3) ^ ((srow >> 2) & 3);  // source chunk for that slot
@@ -261,10 +298,9 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
   for (int i = 0; i < 2; ++i) {
     const int ra = min(m0 + i * 128 + srow, p.M - 1);
     const int rb = min(n0 + i * 128 + srow, p.N - 1);
-    ga[i] = p.A + (int64_t)ra * p.lda + schunk * 16;
-    gb[i] = p.B + (int64_t)rb * p.ldb + schunk * 16;
+    ga[i] = p.A + (int64_t)ra * p.lda + k_off + schunk * 16;
+    gb[i] = p.B + (int64_t)rb * p.ldb + k_off + schunk * 16;
   }
-  const int64_t Kb = p.Kb;
   const int nk = (int)((Kb + BKB - 1) / BKB);
 
   // Every step issues exactly 4 DMAs per wave, also past the end of K (then from a 16-byte zero page, which
@@ -284,8 +320,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
   // Steps whose whole 64-byte K slice lies inside K need no per-lane bounds select: the source is a wave-uniform base
   // (tile origin + K offset, SALU) plus a loop-invariant 32-bit lane offset, which the compiler can issue in the
   // saddr + voffset form -- no 64-bit VALU address math or v_cndmask in the steady state.
-  const uint8_t* baseA = p.A + (int64_t)min(m0, p.M - 1) * p.lda;
-  const uint8_t* baseB = p.B + (int64_t)min(n0, p.N - 1) * p.ldb;
+  const uint8_t* baseA = p.A + (int64_t)min(m0, p.M - 1) * p.lda + k_off;
+  const uint8_t* baseB = p.B + (int64_t)min(n0, p.N - 1) * p.ldb + k_off;
   uint32_t oa[2], ob[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -346,49 +382,93 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
 
-  // ---- prologue: DMAs of steps 0..2 in flight, fragments of step 0 in registers
-  stage(0);
-  stage(1);
-  stage(2);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  // int8 split-K tail, merge launch: the accumulators are the sum of the parts' int32 partials (exact), no K loop
+  bool merged = false;
+  if constexpr (DT == DT_INT8) {
+    if (grp.mode == 1) {
+      // A CU pulls ~11 B/clk, so reading S x 256 KB through one CU costs as much as a good part of the K loop it replaces:
+      // a tile is merged by 1, 2 or 4 blocks (as many as fit one round), each running the waves of its share of the tile
+      // (the epilogue below is wave-private).
+      merged = true;
+      const int32_t* src = grp.ws + ((int64_t)(blockIdx.x >> grp.spread_shift) * grp.splits) * (32 * 512 * 4) + tid * 4;
+      const int n_parts = (wave >> (3 - grp.spread_shift)) == (int)(blockIdx.x & ((1 << grp.spread_shift) - 1)) ? grp.splits : 0;
+      for (int sp = 0; sp < n_parts; ++sp, src += 32 * 512 * 4) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) read_a(0, i);
-  read_b(fb0, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const i32x4 v = *reinterpret_cast<const i32x4*>(src + ((i * 2 + j) * 4 + q) * (512 * 4));
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] += v[c];
+            }
+      }
+    }
+  }
+  if (!merged) {
+  // ---- prologue: DMAs of steps 0..2 in flight, fragments of step 0 in registers
+    stage(0);
+    stage(1);
+    stage(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) read_a(0, i);
+    read_b(fb0, 0);
 #ifdef FDM_GEMM_STAMPS
-  if (tid == 0) stamp[1] = __builtin_readcyclecounter();
+    if (tid == 0) stamp[1] = __builtin_readcyclecounter();
 #endif
 
-  // One step: wait for DMA(t+1) (leaving DMA(t+2) in flight), barrier, issue DMA(t+3), then MFMA(t) with the
-  // fragments of step t+1 streaming in behind it.
-  auto step = [&](auto inner_c, Frag (&bc)[NS][2], Frag (&bn)[NS][2], int t) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if constexpr (decltype(inner_c)::value) stage_inner(t + 3);
-    else stage(t + 3);
-    read_b(bn, t + 1);
+    // One step: wait for DMA(t+1) (leaving DMA(t+2) in flight), barrier, issue DMA(t+3), then MFMA(t) with the
+    // fragments of step t+1 streaming in behind it.
+    auto step = [&](auto inner_c, Frag (&bc)[NS][2], Frag (&bn)[NS][2], int t) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if constexpr (decltype(inner_c)::value) stage_inner(t + 3);
+      else stage(t + 3);
+      read_b(bn, t + 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = M::run(bc[s][j], fa[s][i], acc[i][j]);  // swapped: rows = n, cols = m
-      read_a(t + 1, i);
+          for (int j = 0; j < 2; ++j) acc[i][j] = M::run(bc[s][j], fa[s][i], acc[i][j]);  // swapped: rows = n, cols = m
+        read_a(t + 1, i);
+      }
+    };
+    const int nk2 = (nk + 1) & ~1;
+    const int nk_full = (int)(Kb / BKB);          // slices that lie completely inside K
+    int t = 0;
+    for (; t + 4 < nk_full; t += 2) {              // issues slices t+3 and t+4: both complete
+      step(std::true_type{}, fb0, fb1, t);
+      step(std::true_type{}, fb1, fb0, t + 1);
     }
-  };
-  const int nk2 = (nk + 1) & ~1;
-  const int nk_full = (int)(Kb / BKB);          // slices that lie completely inside K
-  int t = 0;
-  for (; t + 4 < nk_full; t += 2) {              // issues slices t+3 and t+4: both complete
-    step(std::true_type{}, fb0, fb1, t);
-    step(std::true_type{}, fb1, fb0, t + 1);
-  }
-  for (; t < nk2; t += 2) {                      // K tail and the zero-filled padding slices
-    step(std::false_type{}, fb0, fb1, t);
-    step(std::false_type{}, fb1, fb0, t + 1);
+    for (; t < nk2; t += 2) {                      // K tail and the zero-filled padding slices
+      step(std::false_type{}, fb0, fb1, t);
+      step(std::false_type{}, fb1, fb0, t + 1);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // retire the padding DMAs and the dead fragment reads
   __builtin_amdgcn_s_barrier();                                  // every wave is done with the ring: reuse it below
+  if constexpr (DT == DT_INT8) {
+    if (grp.mode == 1 && (wave >> (3 - grp.spread_shift)) != (int)(blockIdx.x & ((1 << grp.spread_shift) - 1))) return;   // merge launch: the other quarters belong to sibling blocks
+    if (is_part) {   // int32 partial sums of this K range -> workspace; the merge launch runs the epilogue
+      int32_t* dst = grp.ws + ((int64_t)part_slot) * (32 * 512 * 4) + tid * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            i32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = acc[i][j][4 * q + c];
+            *reinterpret_cast<i32x4*>(dst + ((i * 2 + j) * 4 + q) * (512 * 4)) = v;
+          }
+      return;
+    }
+  }
 
 #ifdef FDM_GEMM_STAMPS
   if (tid == 0) stamp[2] = __builtin_readcyclecounter();
@@ -580,8 +660,10 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
 unsigned long long* g_gemm_stamps = nullptr;  // >= 4 * grid words, set by the micro-benchmark
 #endif
 
+constexpr int64_t SPLIT_PART_BYTES = (int64_t)BM * BN * 4;   // one K part of one tile: 256 x 256 int32
+
 template <int DT>
-static int launch_gemm(const GemmGroup& grp, hipStream_t s) {
+static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, int64_t ws_bytes = 0) {
 #ifdef FDM_GEMM_STAMPS
   const_cast<GemmGroup&>(grp).stamps = g_gemm_stamps;
 #endif
@@ -595,6 +677,44 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s) {
   const_cast<GemmGroup&>(grp).debug = debug;
 #endif
   const bool res = grp.p[0].epi == FDM_EPI_GATE_RESIDUAL || (grp.n > 1 && grp.p[1].epi == FDM_EPI_GATE_RESIDUAL);
+  if constexpr (DT == DT_INT8) {
+    // Split-K tail (int8 only: int32 partial sums add exactly, so the result does not depend on the split).  When the last
+    // round of one-tile-per-CU work fills at most half of the chip, its `rem` tiles are cut into S K ranges (rem * S blocks
+    // run side by side) and merged by a second launch.  Worth it only if a part still has >= 8 K steps and the int32
+    // partials (256 KB per part, written and read once) cost less than the fraction of a round they save.
+    const int cu = device_cu_count();
+    const int rem = grp.total_tiles % cu;
+    int64_t nk_min = (grp.p[0].Kb + BKB - 1) / BKB;
+    if (grp.n > 1) nk_min = nk_min < (grp.p[1].Kb + BKB - 1) / BKB ? nk_min : (grp.p[1].Kb + BKB - 1) / BKB;
+    int S = 1;
+    if (ws != nullptr && rem > 0 && rem * 2 <= cu && grp.total_tiles > cu) {
+      S = cu / rem;
+      if (S > 8) S = 8;
+      if (S > nk_min / 8) S = (int)(nk_min / 8);
+      while (S > 1 && (int64_t)rem * S * SPLIT_PART_BYTES > ws_bytes) --S;
+      if (rem * S < 8) S = 1;
+      // Measured on MI355X (Qwen-Image's K = 12288 down-projection, 336 tiles: 346 -> 307 us): a part stores 256 KB through
+      // one CU (~12 us) and the merge launch costs ~35-40 us (launch gap, S x 256 KB re-read, epilogue), so the split pays
+      // only for long K loops: >= 160 steps of 64 bytes (a tile of >= ~120 us).  K = 3072 tiles (46 us) are never split.
+      if (nk_min < 160) S = 1;
+    }
+    if (S > 1) {
+      GemmGroup g2 = grp;
+      g2.split_tiles = rem;
+      g2.splits = S;
+      g2.n_blocks = grp.total_tiles - rem + rem * S;
+      g2.ws = reinterpret_cast<int32_t*>(ws);
+      if (res) gemm_kernel<DT, true><<<g2.n_blocks, GEMM_THREADS, 0, s>>>(g2);
+      else gemm_kernel<DT, false><<<g2.n_blocks, GEMM_THREADS, 0, s>>>(g2);
+      FDM_CHECK_LAUNCH();
+      g2.mode = 1;
+      g2.spread_shift = rem * 4 <= cu ? 2 : (rem * 2 <= cu ? 1 : 0);   // as many merge blocks per tile as fit ONE round
+      if (res) gemm_kernel<DT, true><<<rem << g2.spread_shift, GEMM_THREADS, 0, s>>>(g2);
+      else gemm_kernel<DT, false><<<rem << g2.spread_shift, GEMM_THREADS, 0, s>>>(g2);
+      FDM_CHECK_LAUNCH();
+      return FDM_OK;
+    }
+  }
   if (res) gemm_kernel<DT, true><<<grid, GEMM_THREADS, 0, s>>>(grp);
   else gemm_kernel<DT, false><<<grid, GEMM_THREADS, 0, s>>>(grp);
   FDM_CHECK_LAUNCH();
@@ -657,6 +777,12 @@ static void finish_group(GemmGroup& g, int n) {
   g.n = n;
   g.total_tiles = 0;
   for (int i = 0; i < n; ++i) g.total_tiles += g.p[i].tiles_m * g.p[i].tiles_n;
+  g.split_tiles = 0;
+  g.splits = 1;
+  g.mode = 0;
+  g.n_blocks = g.total_tiles;
+  g.spread_shift = 0;
+  g.ws = nullptr;
   if (n == 1) {
     g.p[1] = g.p[0];
     g.p[1].tiles_m = g.p[1].tiles_n = 0;
@@ -821,14 +947,24 @@ int fdm_gemm_w8a8_int8(void* out, const void* a, const void* b, const float* sca
   return launch_gemm<DT_INT8>(g, to_stream(stream));
 }
 
+int64_t fdm_gemm_int8_workspace_bytes(void) { return 256 * SPLIT_PART_BYTES; }   // rem * S <= the CUs of the device
+
 int fdm_gemm_w8a8_int8_x2(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_desc* d1, fdm_stream_t stream) {
-  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!d0 || !d1) return FDM_ERR_INVALID;
+  return fdm_gemm_w8a8_int8_x2_ws(d0, d1, nullptr, 0, stream);
+}
+
+int fdm_gemm_w8a8_int8_x2_ws(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_desc* d1, void* workspace, int64_t workspace_bytes,
+                             fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (!d0) return FDM_ERR_INVALID;
+  if (workspace != nullptr && ((reinterpret_cast<uintptr_t>(workspace) & 15) || workspace_bytes < 0)) return FDM_ERR_INVALID;
   const fdm_gemm_int8_desc* ds[2] = {d0, d1};
   GemmGroup g;
   int n = 0;
   for (int i = 0; i < 2; ++i) {
     const fdm_gemm_int8_desc* d = ds[i];
+    if (d == nullptr) continue;
     if (d->M == 0 && d->N > 0 && d->K > 0) continue;
     int rc = fill_problem(g.p[n], d->out, d->a, d->b, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, 1, (int)d->epilogue, d->epi_gate,
                           d->epi_gate_stride, d->epi_res, d->epi_rows_per_batch, d->out_plane_cols);
@@ -845,7 +981,7 @@ int fdm_gemm_w8a8_int8_x2(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_desc
   }
   if (n == 0) return FDM_OK;
   finish_group(g, n);
-  return launch_gemm<DT_INT8>(g, to_stream(stream));
+  return launch_gemm<DT_INT8>(g, to_stream(stream), workspace, workspace_bytes);
 }
 
 int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda,

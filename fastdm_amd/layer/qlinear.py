@@ -120,11 +120,11 @@ class QLinear:
                                           N.ptr(self.bias), M, Nn, K, a.stride(0), wt.stride(1), out.stride(0), epilogue,
                                           g_ptr, g_stride, N.ptr(res), rows_per_batch, N.stream()), "fp8 linear")
         elif self.quant_type == torch.int8:
+          import ctypes
+          d, _, _ = self._desc(x, epilogue, gate, res, rows_per_batch, out)
+          ws = N.gemm_int8_workspace(a.device)     # split-K tail: exact for int32 accumulators (bit-identical to the unsplit GEMM)
           with span("gemm_w8a8_int8_res" if epilogue >= N.EPI_GATE_RESIDUAL else "gemm_w8a8_int8", flops):
-            N.check(lib.fdm_gemm_w8a8_int8(N.ptr(out), N.ptr(a), N.ptr(wt), N.ptr(x.scale), N.ptr(self.weight_quant_scale),
-                                           N.ptr(self.weight_asym_sumcol) if x.azp is not None else None, N.ptr(x.azp),
-                                           N.ptr(self.bias), M, Nn, K, a.stride(0), wt.stride(1), out.stride(0), epilogue,
-                                           g_ptr, g_stride, N.ptr(res), rows_per_batch, N.stream()), "int8 linear")
+            N.check(lib.fdm_gemm_w8a8_int8_x2_ws(ctypes.byref(d), None, N.ptr(ws), ws.numel(), N.stream()), "int8 linear")
         else:
             assert a.dtype == self.dtype and a.stride(1) == 1
             with span("gemm_bf16_res" if epilogue >= N.EPI_GATE_RESIDUAL else "gemm_bf16", flops):
@@ -171,7 +171,8 @@ class QLinear:
             d0, o0, f0 = lin0._desc(x0, epilogue, gate0, res0, rpb0, out0)
             d1, o1, f1 = lin1._desc(x1, epilogue, gate1, res1, rpb1, out1)
             with span("gemm_w8a8_int8_res" if epilogue >= N.EPI_GATE_RESIDUAL else "gemm_w8a8_int8", f0 + f1):
-                N.check(N.lib().fdm_gemm_w8a8_int8_x2(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "int8 linear pair")
+                ws = N.gemm_int8_workspace(x0.q.device)
+                N.check(N.lib().fdm_gemm_w8a8_int8_x2_ws(ctypes.byref(d0), ctypes.byref(d1), N.ptr(ws), ws.numel(), N.stream()), "int8 linear pair")
             return o0, o1
         return (lin0.forward_q(x0, epilogue, gate0, res0, rpb0, out0), lin1.forward_q(x1, epilogue, gate1, res1, rpb1, out1))
 
@@ -208,9 +209,13 @@ class QLinear:
             else:
                 d1, f1 = type(d0)(), 0.0
                 d1.M, d1.N, d1.K = 0, 1, 1          # an empty problem: skipped by the library
-            fn, name = (N.lib().fdm_gemm_w8a8_fp8_x2, "gemm_w8a8_fp8") if qt == FP8 else (N.lib().fdm_gemm_w8a8_int8_x2, "gemm_w8a8_int8")
-            with span(name, f0 + f1):
-                N.check(fn(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "plane-split linear")
+            with span("gemm_w8a8_fp8" if qt == FP8 else "gemm_w8a8_int8", f0 + f1):
+                if qt == FP8:
+                    N.check(N.lib().fdm_gemm_w8a8_fp8_x2(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "plane-split linear")
+                else:
+                    ws = N.gemm_int8_workspace(planes.device)
+                    N.check(N.lib().fdm_gemm_w8a8_int8_x2_ws(ctypes.byref(d0), ctypes.byref(d1), N.ptr(ws), ws.numel(), N.stream()),
+                            "plane-split linear")
 
     def forward(self, input_tensor: torch.Tensor) -> torch.Tensor:
         """fastdm/layer/qlinear.py:56-81: quantise per token, scaled GEMM (+bias), restore the leading dims."""

@@ -44,7 +44,7 @@ const char* fdm_last_hip_error_string(void);
 
 /* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
  * refuse to run instead of passing arguments at the wrong positions. */
-#define FDM_ABI_VERSION 8
+#define FDM_ABI_VERSION 9
 int fdm_abi_version(void);
 
 /* ---- replaces cuda_ops.rms_norm_ (ops.h:17-20; csrc/elmwise_ops.cu:56-84,433-449) -------------
@@ -150,6 +150,17 @@ typedef struct fdm_gemm_int8_desc {
   int64_t out_plane_stride;
 } fdm_gemm_int8_desc;
 int fdm_gemm_w8a8_int8_x2(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_desc* d1, fdm_stream_t stream);
+
+/* The same one or two int8 problems (d1 may be NULL) with a split-K tail: when the last round of 256 x 256 output tiles
+ * (one per CU at a time) would fill at most half of the device, those tiles are cut into up to 8 K ranges that run side by
+ * side, write int32 partial accumulators into `workspace` and are merged -- sum of the parts, then the usual epilogue -- by a
+ * second launch on the same stream.  int32 sums are exact: the output is BIT-IDENTICAL to fdm_gemm_w8a8_int8[_x2]
+ * whatever the split (no such entry point exists for fp8, whose fp32 accumulation order would change).
+ * workspace: 16-byte aligned device memory of fdm_gemm_int8_workspace_bytes() (64 MiB; smaller is allowed and limits the
+ * split; NULL = never split), owned by the caller, reusable by consecutive calls on ONE stream.                            */
+int64_t fdm_gemm_int8_workspace_bytes(void);
+int fdm_gemm_w8a8_int8_x2_ws(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_desc* d1, void* workspace,
+                             int64_t workspace_bytes, fdm_stream_t stream);
 
 /* ---- bf16 GEMM (QLinear's un-quantised branch: torch.addmm, layer/qlinear.py:76) --------------
  * out[M,N] = bf16(acc_f32(A[M,K] bf16 row-major x B[K,N] bf16 column-major) + bias[N])          */

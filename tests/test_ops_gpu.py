@@ -264,6 +264,63 @@ def test_int8_matmul_reference_shapes(K, M, Kd, Nn):
     assert torch.equal(got[rows], ref), f"int8 {M}x{Kd}x{Nn}: max diff {(got[rows].float() - ref.float()).abs().max()}"
 
 
+@pytest.mark.parametrize("M,Kd,Nn,M2,epi", [(7017, 12288, 3072, 0, "res"),      # Qwen-Image ff2: 336 tiles = 1.31 rounds -> 80 tail tiles x 3 parts
+                                             (3300, 10240, 6144, 128, "gelu"),   # paired with a text-stream problem: 312 + 24 tiles
+                                             (6000, 10256, 3088, 0, "none"),     # ragged N tile, K tail inside the last part, 56 tiles x 4 parts, 4 merge blocks per tile
+                                             (300, 4096, 256, 0, "none")])       # fewer tiles than CUs: never split
+def test_int8_gemm_split_k_tail_is_bit_identical(K, M, Kd, Nn, M2, epi):
+    """fdm_gemm_w8a8_int8_x2_ws cuts the tiles of a sparse last round into K ranges (int32 partials through a workspace, merge
+    launch).  int32 sums are exact, so every output bit equals the unsplit fdm_gemm_w8a8_int8[_x2], with asymmetric zero points,
+    bias, GELU and gate+residual epilogues; sampled rows also equal the oracle."""
+    import ctypes
+    from fastdm_amd import _native as N
+    g = gen(M + Kd + Nn)
+    e = {"none": N.EPI_NONE, "gelu": N.EPI_GELU_TANH, "res": N.EPI_GATE_RESIDUAL}[epi]
+
+    def problem(m):
+        a = torch.randint(-128, 128, (m, Kd), generator=g).to(torch.int8).cuda()
+        b = torch.randint(-128, 128, (Nn, Kd), generator=g).to(torch.int8).cuda()           # [N, K]: the [K, N] weight with stride(0) == 1
+        sa, sb = (torch.rand(m, 1, generator=g) * 0.01 + 0.001).cuda(), (torch.rand(Nn, 1, generator=g) * 0.01 + 0.001).cuda()
+        adj = b.to(torch.int32).sum(dim=1, dtype=torch.int32).contiguous()
+        azp = torch.randint(-128, 127, (m, 1), generator=g).to(torch.int32).cuda()
+        bias = rbf(g, Nn).cuda()
+        gate, res = (rbf(g, 1, Nn).cuda(), rbf(g, m, Nn).cuda()) if epi == "res" else (None, None)
+        return dict(a=a, b=b, sa=sa, sb=sb, adj=adj, azp=azp, bias=bias, gate=gate, res=res, m=m)
+
+    def desc(pr, out):
+        d = N.GemmInt8Desc()
+        d.out, d.a, d.b, d.scale_a, d.scale_b = N.ptr(out), N.ptr(pr["a"]), N.ptr(pr["b"]), N.ptr(pr["sa"]), N.ptr(pr["sb"])
+        d.azp_adj, d.azp, d.bias = N.ptr(pr["adj"]), N.ptr(pr["azp"]), N.ptr(pr["bias"])
+        d.M, d.N, d.K, d.lda, d.ldb, d.ldc = pr["m"], Nn, Kd, Kd, Kd, Nn
+        d.epilogue = e
+        d.epi_gate, d.epi_gate_stride, d.epi_res, d.epi_rows_per_batch = N.ptr(pr["gate"]), Nn, N.ptr(pr["res"]), pr["m"]
+        return d
+
+    probs = [problem(M)] + ([problem(M2)] if M2 else [])
+    ws = N.gemm_int8_workspace(torch.device("cuda"))
+    outs = {}
+    for tag in ("plain", "split", "small_ws"):
+        o = [torch.full((pr["m"], Nn), 7.0, dtype=BF16, device="cuda") for pr in probs]
+        ds = [desc(pr, oo) for pr, oo in zip(probs, o)]
+        d1 = ctypes.byref(ds[1]) if len(ds) > 1 else None
+        w_ptr, w_bytes = {"plain": (None, 0), "split": (N.ptr(ws), ws.numel()), "small_ws": (N.ptr(ws), 170 * 256 * 256 * 4)}[tag]
+        N.check(N.lib().fdm_gemm_w8a8_int8_x2_ws(ctypes.byref(ds[0]), d1, w_ptr, w_bytes, N.stream()), tag)
+        outs[tag] = o
+    torch.cuda.synchronize()
+    for i in range(len(probs)):
+        assert torch.equal(outs["split"][i], outs["plain"][i]), f"problem {i}: split-K tail changed {int((outs['split'][i] != outs['plain'][i]).sum())} outputs"
+        assert torch.equal(outs["small_ws"][i], outs["plain"][i]), f"problem {i}: a smaller workspace (fewer parts) changed the output"
+    if epi == "none":     # and the unsplit result is the oracle's (sampled rows)
+        pr, rows = probs[0], sample_rows(M)
+        ref = O.int8_matmul(pr["a"].cpu()[rows], pr["b"].cpu().t(), pr["sa"].cpu()[rows], pr["sb"].cpu(), BF16, pr["adj"].cpu()[None], pr["azp"].cpu()[rows],
+                            pr["bias"].cpu())
+        assert torch.equal(outs["split"][0].cpu()[rows], ref)
+    # misaligned workspace: an error, not a silent unsplit launch
+    o = torch.empty((M, Nn), dtype=BF16, device="cuda")
+    d = desc(probs[0], o)
+    assert N.lib().fdm_gemm_w8a8_int8_x2_ws(ctypes.byref(d), None, N.ptr(ws) + 4, 1 << 20, N.stream()) == -1      # FDM_ERR_INVALID
+
+
 @pytest.mark.parametrize("quant", ["fp8", "int8", "bf16"])
 @pytest.mark.parametrize("C", [256, 152])      # plane width: a multiple of the 256-column tile, and one that straddles tiles
 def test_plane_split_projection_equals_plain_output(K, quant, C):

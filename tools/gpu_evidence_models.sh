@@ -4,9 +4,12 @@ tag=${1:-r01}
 out=$PWD/gpurun_out
 mkdir -p "$out"
 python3 bench.py --model qwen > "$out/${tag}_qwen_bench.json" 2> "$out/${tag}_qwen.err"
+python3 bench.py --model qwen --batch-cfg > "$out/${tag}_qwen_batchcfg_bench.json" 2> "$out/${tag}_qwen_batchcfg.err"
+python3 bench.py --quant bf16 --height 1024 --width 1024 > "$out/${tag}_flux_bf16_1024_bench.json" 2> "$out/${tag}_flux_bf16_1024.err"
+python3 bench.py --quant int8 > "$out/${tag}_flux_int8_bench.json" 2> "$out/${tag}_flux_int8.err"
 python3 bench.py --model sd35 > "$out/${tag}_sd35_bench.json" 2> "$out/${tag}_sd35.err"
 python3 bench.py --model sdxl > "$out/${tag}_sdxl_bench.json" 2> "$out/${tag}_sdxl.err"
 python3 bench.py --model sdxl --graph > "$out/${tag}_sdxl_graph_bench.json" 2> "$out/${tag}_sdxl_graph.err"
 python3 bench.py --model wan > "$out/${tag}_wan_dense_bench.json" 2> "$out/${tag}_wan_dense.err"
 python3 bench.py --model wan --start-step 11 --sparse-config examples/sparse/radial_attn_wan.json > "$out/${tag}_wan_sparse_bench.json" 2> "$out/${tag}_wan_sparse.err"
-for f in qwen sd35 sdxl sdxl_graph wan_dense wan_sparse; do echo "$f: $(tail -1 $out/${tag}_${f}_bench.json | cut -c1-60) ... $(tail -1 $out/${tag}_${f}_bench.json | grep -o '"ms_per_step": [0-9.]*')"; done
+for f in qwen qwen_batchcfg flux_bf16_1024 flux_int8 sd35 sdxl sdxl_graph wan_dense wan_sparse; do echo "$f: $(tail -1 $out/${tag}_${f}_bench.json | cut -c1-60) ... $(tail -1 $out/${tag}_${f}_bench.json | grep -o '"ms_per_step": [0-9.]*')"; done
