@@ -29,7 +29,7 @@ import torch  # noqa: E402
 PEAK_TFLOPS = {"fp8": 5000.0, "bf16": 2500.0, "int8": 5000.0}   # dense MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 IMAGE_STEPS = 25
 # timing-span name -> HIP kernel it launches (the name rocprofv3 reports; profiles/*_summary.txt)
-HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128>", "attn_sparse_bf16": "fdm::attn_fwd_kernel<128, 256, 64>", "gemm_w8a8_fp8": "fdm::gemm_kernel<0, false>", "gemm_w8a8_fp8_res": "fdm::gemm_kernel<0, true>",
+HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128, false>", "attn_sparse_bf16": "fdm::attn_fwd64_kernel<128, true>", "gemm_w8a8_fp8": "fdm::gemm_kernel<0, false>", "gemm_w8a8_fp8_res": "fdm::gemm_kernel<0, true>",
               "gemm_w8a8_int8": "fdm::gemm_kernel<1, false>", "gemm_w8a8_int8_res": "fdm::gemm_kernel<1, true>",
               "gemm_bf16": "fdm::gemm_kernel<2, false>", "gemm_bf16_res": "fdm::gemm_kernel<2, true>"}
 
