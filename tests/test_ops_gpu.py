@@ -524,8 +524,8 @@ def test_sparse_attention_masks(K):
     torch.testing.assert_close(got, ref, rtol=0.0, atol=1.8e-2)
 
 
-@pytest.mark.parametrize("S,seed", [(2500, 1), (1536, 2), (700, 3)])
-def test_sparse_attention_random_masks(K, S, seed):
+@pytest.mark.parametrize("S,seed,density", [(2500, 1, 0.3), (1536, 2, 0.3), (700, 3, 0.3), (900, 4, 0.0), (64, 5, 0.0), (2500, 6, 0.9)])
+def test_sparse_attention_random_masks(K, S, seed, density):
     """Random block masks whose rows differ inside a 256-row kernel block: the kernel walks the union of its waves' mask rows
     and a wave overwrites the tiles its own row drops (first tile of the union dropped for some waves, tail tile kept
     or dropped, lists longer than several 4-step groups).  Every mask row keeps at least one tile (a row without keys is
@@ -534,13 +534,16 @@ def test_sparse_attention_random_masks(K, S, seed):
     B, H, hd = 1, 2, 128
     q, k, v = rbf(g, B, S, H * hd), rbf(g, B, S, H * hd), rbf(g, B, S, H * hd)
     nq, nk = -(-S // 128), -(-S // 64)
-    m = (torch.rand(B, H, nq, nk, generator=g) < 0.3).to(torch.int8)
-    m[..., 0] = 0
-    m[:, :, ::2, 0] = 1                                   # even rows keep the first tile, odd rows do not
-    keep = torch.randint(1, nk, (B, H, nq), generator=g)
-    m.scatter_(3, keep[..., None], 1)
-    m[:, 0, :, nk - 1] = 1                                # head 0: every row keeps the (partial) last tile
-    m[:, 1, 1::2, nk - 1] = 0
+    m = (torch.rand(B, H, nq, nk, generator=g) < density).to(torch.int8)
+    if density > 0:
+        m[..., 0] = 0
+        m[:, :, ::2, 0] = 1                               # even rows keep the first tile, odd rows do not
+    keep = torch.randint(1 if nk > 1 else 0, nk, (B, H, nq), generator=g)
+    m.scatter_(3, keep[..., None], 1)                     # density 0: ONE tile per mask row -> union lists of 1-2 entries per kernel block
+    if density > 0:
+        m[:, 0, :, nk - 1] = 1                            # head 0: every row keeps the (partial) last tile
+        m[:, 1, 1::2, nk - 1] = 0
+        m.scatter_(3, keep[..., None], 1)
     got = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=m.cuda()).cpu()
     ref = O.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5, block_mask=m)
     assert torch.isfinite(got.float()).all()
