@@ -100,13 +100,23 @@ def build(force: bool = False) -> str:
     when the sources' content digest changed (file times do not survive a copy to another machine)."""
     digest = current_source_digest()
     stamp = LIB_PATH + ".srcdigest"
-    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+
+    def current():
+        return os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest
+
+    if not force and current():
         return LIB_PATH
-    res = subprocess.run(["bash", BUILD_SCRIPT], capture_output=True, text=True)
-    if res.returncode != 0 or not os.path.exists(LIB_PATH):
-        raise NativeLibraryError(f"building libfastdm_amd.so failed:\n{res.stdout}\n{res.stderr}")
-    with open(stamp, "w") as f:
-        f.write(digest)
+    # one builder at a time: the ranks of a multi-GPU launch all come through here
+    import fcntl
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not current():          # another process may have finished the build while this one waited
+            res = subprocess.run(["bash", BUILD_SCRIPT], capture_output=True, text=True)
+            if res.returncode != 0 or not os.path.exists(LIB_PATH):
+                raise NativeLibraryError(f"building libfastdm_amd.so failed:\n{res.stdout}\n{res.stderr}")
+            with open(stamp, "w") as f:
+                f.write(digest)
     return LIB_PATH
 
 
