@@ -114,6 +114,28 @@ def spawn_ranks(n: int) -> int:
     return 0
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too -- RCCL prints its version banner through C stdio,
+    which a pipe delivers at process exit, i.e. BEHIND the JSON line -- so file descriptor 1 is pointed at stderr for the
+    whole run and the result line goes to a private duplicate of the real stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_result(line: str):
+    sys.stdout.flush()
+    if _RESULT_FD is None:
+        print(line, flush=True)
+    else:
+        os.write(_RESULT_FD, (line + "\n").encode())
+
+
 ARCH_NAME = {"flux": "FLUX.1-dev", "qwen": "Qwen-Image", "wan": "Wan2.2-T2V-A14B", "sd35": "SD3.5-large", "sdxl": "SDXL-base-1.0"}
 
 
@@ -159,6 +181,7 @@ def main():
     if args.cfg_pair and (args.model == "flux" or args.gpus % 2):
         sys.exit("--cfg-pair needs a two-forward model (qwen / wan / sd35 / sdxl) and an even --gpus")
 
+    claim_stdout()
     from fastdm_amd import distributed as D
     rank, world, local_rank = D.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run or let bench.py spawn the ranks"
@@ -409,7 +432,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline_leg(args.height, args.width, args.max_seq_len, args.quant)
         except Exception as e:  # noqa: BLE001  -- the baseline leg must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e}"}
-    print(json.dumps(out), flush=True)
+    emit_result(json.dumps(out))
     D.shutdown()
 
 

@@ -52,3 +52,20 @@ def test_bench_spawns_its_own_ranks():
     assert res.returncode == 0, res.stderr[-4000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["ranks_in_process_group"] == 2 and line["value"] > 0
+
+
+@pytest.mark.parametrize("model", ["flux", "sd35", "sdxl"])
+def test_bench_collectives_over_rccl_single_rank(model):
+    """FDM_FORCE_DIST=1: bench.py initialises a one-rank RCCL process group, so its barrier, max-over-ranks all-reduce and the
+    final all-gather of latents run through RCCL on a 1-GPU box too.  sd35 / sdxl carry a batch-2 CFG tensor of which only the
+    image's own row is gathered (the gather used to receive both rows and raise)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FDM_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--model", model, "--gpus", "1", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-kernel-timing"], capture_output=True, text=True, timeout=1800, env=env)
+    assert res.returncode == 0, res.stderr[-4000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["ranks_in_process_group"] == 1 and line["value"] > 0
