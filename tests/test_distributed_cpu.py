@@ -171,3 +171,17 @@ def test_cfg_pair_guards():
             D.gather_latents(torch.zeros(2, 3), 1, 0, 1)
         finally:
             dist.destroy_process_group()
+
+
+def test_bench_stdout_carries_only_the_result_line():
+    """bench.py points file descriptor 1 at stderr for the run (RCCL writes its version banner to C stdout, which a pipe
+    delivers at exit -- behind the JSON line) and writes the result to a private duplicate of the real stdout."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.claim_stdout(); "
+            "os.write(1, b'library banner on fd 1\\n'); print('python print'); bench.emit_result('{\"ok\": 1}'); os.write(1, b'late banner\\n')" % root)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert res.stdout == '{"ok": 1}\n', repr(res.stdout)
+    assert "library banner on fd 1" in res.stderr and "python print" in res.stderr and "late banner" in res.stderr
