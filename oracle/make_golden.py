@@ -116,6 +116,30 @@ def save(name, d):
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+def provenance():
+    """Where a long-running fixture came from (a fixture nobody can re-derive is not evidence):
+    stored as meta_* strings next to the tensors."""
+    import platform
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def git(*a):
+        try:
+            return subprocess.run(["git", "-C", root, *a], capture_output=True, text=True, timeout=20).stdout.strip()
+        except Exception:
+            return "?"
+    cpu = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    dirty = git("status", "--porcelain", "--", "oracle", "fastdm_amd/pipeline.py")
+    return {"torch": torch.__version__, "numpy": np.__version__, "threads": torch.get_num_threads(), "cpu": cpu, "machine": platform.machine(),
+            "git_head": git("rev-parse", "HEAD"), "git_dirty_oracle": "clean" if dirty == "" else dirty.replace("\n", "; ")}
+
+
 def randn_bf16(gen, *shape, scale=1.0):
     return (torch.randn(*shape, generator=gen) * scale).to(torch.bfloat16)
 
@@ -960,19 +984,31 @@ def gen_dicache():
 
 
 # ------------------------------------------------------------------ full-width C3 fixture
-def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=0, sub=64):
+def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=0, sub=64, attention="ref", rec_double=None,
+           rec_single=None, name=None):
     """Full-width FLUX.1-dev at 1024x2048 (S = 8192 + 512) through the reference's own block
     classes, streamed one block at a time so RSS stays small.  The block objects,
     their weight loading/quantisation and forward are the reference's; only the loop over blocks
     (flux.py:445-485) is spelled out here so that each block's weights can be freed."""
-    import_reference()
+    reg = import_reference()
     from oracle import flux as OF
+    from oracle import ops as OO
     from fastdm.model.flux import FluxTransformer2DModelCore, FluxTransformerBlock, FluxSingleTransformerBlock
     import contextlib
     import io
     cfg = OF.FluxConfig(num_layers=n_double, num_single_layers=n_single)
     inp = OF.synth_inputs(cfg, 1, img_h, img_w, n_txt, seed)
     t0 = time.time()
+    rec_double = (0, n_double - 1) if rec_double is None else tuple(rec_double)
+    rec_single = (0, n_single - 1) if rec_single is None else tuple(rec_single)
+    attn_key, saved_attn = "sdpa", None          # fastdm/kernel/torch/attention.py:7 registers the op as 'sdpa'
+    if attention == "fp32":                      # the A/B control of gen_c3_traj: fp32-score / fp32-softmax attention
+        saved_attn = dict(reg._registry[attn_key])
+
+        def attn_fp32(query, key, value, num_q_heads, num_kv_heads, head_dim, is_causal=False, scale=None):
+            return OO.scaled_dot_product_attention(query, key, value, num_q_heads, num_kv_heads, head_dim, is_causal=is_causal, scale=scale)
+        for b in list(reg._registry[attn_key]):
+            reg._registry[attn_key][b] = attn_fp32
 
     def specs_with_prefix(prefix):
         full = OF.FluxConfig()
@@ -1024,7 +1060,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
                 encoder, hidden = core.transformer_blocks[0].forward(
                     hidden_states=hidden, encoder_hidden_states=encoder, temb=temb, image_rotary_emb=rope)
                 print(f"[{tag}] double {i} done  t={time.time() - t0:.0f}s  |h|={hidden.float().abs().mean():.4f}", flush=True)
-                if i in (0, n_double - 1):
+                if i in rec_double:
                     d[f"hidden_d{i}_sub"] = hidden[:, ::sub].clone()
                     d[f"encoder_d{i}_sub"] = encoder[:, ::sub].clone()
             x = torch.cat([encoder, hidden], dim=1)
@@ -1036,7 +1072,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
                 load_part(core, names, core._FluxTransformer2DModelCore__single_trans_block_loading)
                 x = core.single_transformer_blocks[0].forward(hidden_states=x, temb=temb, image_rotary_emb=rope)
                 print(f"[{tag}] single {i} done  t={time.time() - t0:.0f}s  |x|={x.float().abs().mean():.4f}", flush=True)
-                if i in (0, n_single - 1):
+                if i in rec_single:
                     d[f"x_s{i}_sub"] = x[:, ::sub].clone()
             hidden = x[:, n_txt:]
             hidden = core.norm_out.forward(hidden, temb)
@@ -1046,9 +1082,27 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
         meta = {"seed": seed, "img_h": img_h, "img_w": img_w, "n_txt": n_txt, "sub": sub, "n_double": n_double,
                 "n_single": n_single, "timestep": 1.0, "guidance": 3.5}
         d.update({f"meta_{k}": v for k, v in meta.items()})
-        save(f"flux_c3_{tag}_{n_double}x{n_single}.npz", d)
+        if name is None:
+            save(f"flux_c3_{tag}_{n_double}x{n_single}.npz", d)
+        else:
+            d.update({f"meta_prov_{k}": str(v) for k, v in provenance().items()})
+            d["meta_attention"] = attention
+            save(name.format(tag=tag, attention=attention), d)
+    if saved_attn is not None:
+        reg._registry[attn_key].update(saved_attn)
     use_backend("torch")
     return results
+
+
+def gen_c3_depth(quant_tags, attentions, n_double=8, n_single=4, sub=16):
+    """DEPTH CURVE (VERDICT r2 'Next round' 1d): after 57 random-weight blocks any 1-ulp difference has saturated at the
+    network's chaos floor, so a full-depth comparison cannot see a systematic error.  This fixture is a full-WIDTH C3 forward of
+    8 double + 4 single blocks through the reference's own block classes with sub-sampled intermediates after 1, 2, 4, 8 double
+    and 1, 2, 4 single blocks -- with the reference's attention ('ref') and with the fp32-softmax control ('fp32').  At these
+    depths |control - ref| is still far below saturation, and the HIP path is held to 1.25 x of it at every depth."""
+    for att in attentions:
+        gen_c3(n_double, n_single, quant_tags, sub=sub, attention=att, rec_double=(0, 1, 3, 7), rec_single=(0, 1, 3),
+               name="flux_c3_depth_{tag}_{attention}_%dx%d.npz" % (n_double, n_single))
 
 def gen_c3_traj(n_double, n_single, tag, n_steps=4, attention="ref", img_h=64, img_w=128, n_txt=512, seed=0, sub=8):
     """A multi-step TRAJECTORY of the full-width, full-depth C3 denoise loop through the reference's own block classes
@@ -1144,9 +1198,16 @@ def gen_c3_traj(n_double, n_single, tag, n_steps=4, attention="ref", img_h=64, i
             d[f"lat_s{step}"] = lat if last else lat[:, ::sub].clone()
             print(f"[{tag}/{attention}] step {step} sigma {sig[step]:.4f} done  t={time.time() - t0:.0f}s  |out|={out.float().abs().mean():.4f} "
                   f"|lat|={lat.float().abs().mean():.4f}", flush=True)
+            c3_path = os.path.join(GOLD, f"flux_c3_{tag}_{n_double}x{n_single}.npz")
+            if step == 0 and attention == "ref" and os.path.exists(c3_path):
+                # the single-forward fixture is the same model, inputs and t = 1.0: step 0 must reproduce it bit for bit
+                same = torch.equal(load(os.path.basename(c3_path))["out"], out)
+                print(f"[{tag}/{attention}] step-0 output == flux_c3_{tag}_{n_double}x{n_single}.npz: {same}", flush=True)
+                assert same, "trajectory step 0 does not reproduce the single-forward fixture: environment or tree differs"
     meta = {"seed": seed, "img_h": img_h, "img_w": img_w, "n_txt": n_txt, "sub": sub, "n_double": n_double, "n_single": n_single,
             "n_steps": n_steps, "guidance": 3.5, "schedule_steps": 25}
     d.update({f"meta_{k}": v for k, v in meta.items()})
+    d.update({f"meta_prov_{k}": str(v) for k, v in provenance().items()})
     d["sigmas"] = torch.from_numpy(sig[: n_steps + 1].copy())
     save(f"flux_c3_traj_{tag}_{attention}_{n_double}x{n_single}_{n_steps}steps.npz", d)
     if saved_attn is not None:
@@ -1233,7 +1294,7 @@ def gen_radial_full():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3", "c3_traj", "radial_full", "c3_equal", "wan_ti2v"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3", "c3_traj", "c3_depth", "radial_full", "c3_equal", "wan_ti2v"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     ap.add_argument("--steps", type=int, default=4, help="c3_traj: denoise steps of the 25-step schedule")
@@ -1282,6 +1343,8 @@ def main():
         for tag in args.quant:
             for att in args.attention:
                 gen_c3_traj(args.blocks[0], args.blocks[1], tag, n_steps=args.steps, attention=att)
+    if args.what == "c3_depth":
+        gen_c3_depth(args.quant, args.attention)
     if args.what == "radial_full":
         gen_radial_full()
     if args.what == "c3_equal":
