@@ -30,7 +30,15 @@ int main(int argc, char** argv) {
                                {"dbl ff1 img", 8192, 3072, 12288, 1, 19},  {"dbl ff2 img", 8192, 12288, 3072, 3, 19},
                                {"sgl qkv", 8704, 3072, 9216, 0, 38},       {"sgl mlp", 8704, 3072, 12288, 2, 38},
                                {"sgl out", 8704, 15360, 3072, 3, 38}};
-  const bool nohash = argc > 1 && argv[1][0] == 'n';
+  if (argc > 5 && argv[1][0] == 'c') {   // custom: c M K N epi [M K N epi ...]
+    shapes.clear();
+    static char cn[32][48];
+    for (int a = 2, n = 0; a + 3 < argc && n < 32; a += 4, ++n) {
+      snprintf(cn[n], 48, "M%s K%s N%s e%s", argv[a], argv[a + 1], argv[a + 2], argv[a + 3]);
+      shapes.push_back({cn[n], atol(argv[a]), atol(argv[a + 1]), atol(argv[a + 2]), atoi(argv[a + 3]), 0});
+    }
+  }
+  const bool nohash = argc > 1 && (argv[1][0] == 'n' || argv[1][0] == 'c');
   const int64_t maxA = 8704 * 15360, maxB = 12288 * 3072 * 2, maxC = 8704 * 12288;
   uint8_t *A, *B; uint16_t *C, *R, *G, *bias; float *sa, *sb;
   hipMalloc(&A, maxA); hipMalloc(&B, maxB); hipMalloc(&C, maxC * 2); hipMalloc(&R, maxC * 2);
