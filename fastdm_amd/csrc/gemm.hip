@@ -43,12 +43,6 @@ constexpr int GEMM_THREADS = 512;
 constexpr int NSTAGE = 4;
 constexpr int STAGE_BYTES = (BM + BN) * BKB;  // 32 KiB
 constexpr int GROUP_M = 4;
-// K bytes per barrier: 64 = the 4-stage ring of 32 KiB stages described above; 128 = two 64 KiB stages of 128-byte rows: every
-// LDS-DMA instruction then moves 8 FULL 128-byte lines (instead of 16 half lines) and the block meets at one barrier per 2048
-// MFMA cycles.
-#ifndef FDM_GEMM_KSTEP
-#define FDM_GEMM_KSTEP 128
-#endif
 
 __device__ __attribute__((aligned(16))) uint8_t g_zero_page[16] = {0};
 
@@ -223,7 +217,7 @@ __device__ __forceinline__ void unpack4(const i32x2 v, float (&o)[4]) {
 
 // RES: the launch contains a FDM_EPI_GATE_RESIDUAL problem (a separate instantiation keeps that epilogue's
 // residual registers out of the common kernels).
-template <int DT, bool RES, int KSTEP = FDM_GEMM_KSTEP>
+template <int DT, bool RES>
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup grp) {
   using M = Mma<DT>;
   using Acc = typename M::Acc;
@@ -412,113 +406,6 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
       }
     }
   }
-  if constexpr (KSTEP == 128) {
-   if (!merged) {
-    // ---- 128-byte K steps, two 64 KiB stages.  Stage layout: 512 rows (256 of A, then 256 of B) x 128 B; 16-byte chunk c of
-    // row r lives in slot c ^ ((r >> 1) & 7) (two rows fill the 256-byte bank row: conflict-free for the ds_read_b128 lane
-    // groups).  One LDS-DMA instruction of a wave fills 8 whole rows, lane l -> row l / 8, slot l % 8 (lane-linear), reading
-    // the swizzled chunk of its row: 8 lanes together fetch one full 128-byte line.
-    constexpr int SB = (BM + BN) * 128;
-    const int drow = wave * 8 + (lane >> 3);                 // row inside a 64-row round
-    const int dchunk = (lane & 7) ^ ((drow >> 1) & 7);       // source chunk for this lane's slot
-    const uint8_t* bA = p.A + (int64_t)min(m0, p.M - 1) * p.lda + k_off;
-    const uint8_t* bB = p.B + (int64_t)min(n0, p.N - 1) * p.ldb + k_off;
-    uint32_t da[4], db[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      da[r] = (uint32_t)((min(m0 + r * 64 + drow, p.M - 1) - min(m0, p.M - 1)) * p.lda) + dchunk * 16;
-      db[r] = (uint32_t)((min(n0 + r * 64 + drow, p.N - 1) - min(n0, p.N - 1)) * p.ldb) + dchunk * 16;
-    }
-    const uint8_t* zero_page = g_zero_page;
-    auto stage2 = [&](auto inner_c, int kt) {
-      uint8_t* sA = smem + (kt & 1) * SB + wave * 1024;
-      uint8_t* sB = sA + BM * 128;
-      const int64_t koff = (int64_t)kt * 128;
-      if constexpr (decltype(inner_c)::value) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) glds16(bA + koff + da[r], sA + r * 8192);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) glds16(bB + koff + db[r], sB + r * 8192);
-      } else {
-        const bool ok = koff + dchunk * 16 < Kb;   // K % 16 == 0: a chunk is inside K or outside
-#pragma unroll
-        for (int r = 0; r < 4; ++r) glds16(ok ? bA + koff + da[r] : zero_page, sA + r * 8192);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) glds16(ok ? bB + koff + db[r] : zero_page, sB + r * 8192);
-      }
-    };
-    const int lrow2 = lane & 31, g2 = lane >> 5;
-    const int fsw = (lrow2 >> 1) & 7;
-    const int a_row2 = (wm * 128 + lrow2) * 128;
-    const int b_row2 = BM * 128 + (wn * 64 + lrow2) * 128;
-    Frag fa[NS][4], fb0[NS][2], fb1[NS][2];
-    auto slots = [&](int h, int s, int& c0, int& c1) {     // h = 64-byte half of the step
-      if constexpr (M::KS == 64) {
-        c0 = ((h * 4 + g2 * 2) ^ fsw) * 16;
-        c1 = ((h * 4 + g2 * 2 + 1) ^ fsw) * 16;
-      } else {
-        c0 = ((h * 4 + s * 2 + g2) ^ fsw) * 16;
-        c1 = c0;
-      }
-    };
-    auto read_a2 = [&](int buf, int h, int i) {
-      const uint8_t* st = smem + buf * SB + a_row2 + i * 32 * 128;
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        int c0, c1;
-        slots(h, s, c0, c1);
-        fa[s][i] = lds_frag<Frag>(st + c0, st + c1);
-      }
-    };
-    auto read_b2 = [&](Frag (&fb)[NS][2], int buf, int h) {
-      const uint8_t* st = smem + buf * SB + b_row2;
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        int c0, c1;
-        slots(h, s, c0, c1);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[s][j] = lds_frag<Frag>(st + j * 32 * 128 + c0, st + j * 32 * 128 + c1);
-      }
-    };
-    const int nk128 = (int)((Kb + 127) / 128);
-    const int nk128_full = (int)(Kb / 128);
-    stage2(std::false_type{}, 0);
-    stage2(std::false_type{}, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) read_a2(0, 0, i);
-    read_b2(fb0, 0, 0);
-#ifdef FDM_GEMM_STAMPS
-    if (tid == 0) stamp[1] = __builtin_readcyclecounter();
-#endif
-    // MFMAs of one 64-byte half with the fragments of the next half streaming in behind them
-    auto half = [&](Frag (&bc)[NS][2], Frag (&bn)[NS][2], int nbuf, int nh) {
-      read_b2(bn, nbuf, nh);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = M::run(bc[s][j], fa[s][i], acc[i][j]);  // swapped: rows = n, cols = m
-        read_a2(nbuf, nh, i);
-      }
-    };
-    // Step t: half 0 computes on (t, 0) while (t, 1) is read from stage t; then every wave has read all of stage t and the
-    // DMAs of stage t + 1 (issued a whole step ago) have landed: ONE barrier, the DMAs of stage t + 2 go into stage t's
-    // buffer, half 1 computes on (t, 1) while (t + 1, 0) is read.
-    auto step2 = [&](auto inner_c, int t) {
-      half(fb0, fb1, t & 1, 1);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      stage2(inner_c, t + 2);
-      half(fb1, fb0, (t + 1) & 1, 0);
-    };
-    int t = 0;
-    for (; t + 2 < nk128_full; ++t) step2(std::true_type{}, t);
-    for (; t < nk128; ++t) step2(std::false_type{}, t);
-   }
-  } else {
   if (!merged) {
   // ---- prologue: DMAs of steps 0..2 in flight, fragments of step 0 in registers
     stage(0);
@@ -561,7 +448,6 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
       step(std::false_type{}, fb0, fb1, t);
       step(std::false_type{}, fb1, fb0, t + 1);
     }
-  }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // retire the padding DMAs and the dead fragment reads
   __builtin_amdgcn_s_barrier();                                  // every wave is done with the ring: reuse it below
