@@ -43,6 +43,9 @@ constexpr int GEMM_THREADS = 512;
 constexpr int NSTAGE = 4;
 constexpr int STAGE_BYTES = (BM + BN) * BKB;  // 32 KiB
 constexpr int GROUP_M = 4;
+#ifndef FDM_GEMM_W4
+#define FDM_GEMM_W4 1
+#endif
 
 __device__ __attribute__((aligned(16))) uint8_t g_zero_page[16] = {0};
 
@@ -139,6 +142,17 @@ __device__ __forceinline__ i32x4 lds_frag<i32x4>(const uint8_t* p0, const uint8_
 __device__ __forceinline__ void glds16(const uint8_t* gsrc, uint8_t* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// LDS-DMA in the saddr + 32-bit voffset form (wave-uniform 64-bit base in SGPRs, one VGPR per lane): hipcc, given a 64-bit
+// pointer, keeps a VGPR PAIR per DMA alive.
+__device__ __forceinline__ void glds16_sv(const uint8_t* sbase, uint32_t voff, uint32_t lds_addr) {
+  // M0 is written and read inside this statement and NOT restored: hipcc's own LDS-DMAs (the builtin, tail path) set M0
+  // themselves right before each use (tools/micro/audit_gemm_asm.sh checks that), nothing else in these kernels reads it.
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" : : "s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const uint8_t* p) {
+  return (uint32_t)reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) uint8_t*)p);
 }
 
 // cheap activations for the epilogue (libm tanhf/erff cost ~40 VALU each; x128 values per lane that is
@@ -656,6 +670,551 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
 #endif
 }
 
+
+// =====================================================================================================================
+// gemm_w4_kernel: the same 256 x 256 tile, laid out for the POWER limit of the chip (profiles/r03_experiments.md: with all
+// 256 CUs in MFMA-dense code the clock falls to ~1.35 GHz, so wall time follows energy per flop, not cycles).
+//   waves     4 (ONE per SIMD), 2 (M) x 2 (N), wave tile 128 x 128: a wave reads 128 + 128 operand rows per K byte instead of
+//             128 + 64, i.e. 64 KB of LDS fragment reads per 64 bytes of K and CU instead of 96 KB
+//   MFMA      16x16 shapes: v_mfma_scale_f32_16x16x128_f8f6f4 / v_mfma_i32_16x16x64_i8 / v_mfma_f32_16x16x32_bf16 (the chip
+//             holds a higher clock on them than on the 32x32 shapes)
+//   K step    128 bytes, two 64 KiB stages (512 rows x 128 B): an LDS-DMA instruction moves 8 whole 128-byte lines.
+//             16-byte chunk c of row r sits in slot ((c >> 1) ^ g(r)) * 2 + (c & 1), g(r) = bit 1 of r | bit 3 of r << 1: the
+//             16-lane groups of ds_read_b128 (lanes {0-3, 12-15, 20-27}, ...) then cover all 64 banks for both fragment
+//             shapes (fp8: lane (i, q) reads 32 bytes = chunk pair q of row i, odd q take the odd chunk first -- A and B
+//             operands alike, so products still pair up; int8 / bf16: chunk 4 s + q).
+//   pipeline  B fragments of step t + 1 (64 registers) are read during the first half of step t, A fragments stream one
+//             16-row block ahead of their MFMAs.  ONE barrier per step, after the last A read of stage t: behind it the DMAs
+//             of A(t + 2) go into A(t)'s buffer and those of B(t + 3) into B(t + 1)'s (already in registers); both have a
+//             whole step to land (vmcnt(0) + the next barrier).
+//   epilogue  same arithmetic as gemm_kernel; the wave's 128 x 128 bf16 sub-tile goes through 32 KiB of the dead ring
+//             (8-byte pieces in, 16-byte row-contiguous pieces out: every global access is a full 256-byte row segment).
+// Outputs: int8 bit-identical to gemm_kernel (integer sums); fp8 / bf16 within fp32 summation-order effects of the MFMA.
+// The 256 accumulator registers of a wave (64 blocks of 16 x 16) live in a[0:255] and are touched by inline asm ONLY: hipcc, given
+// 64 x f32x4 accumulators and a 256 + 256 register split, rotates them through copies (492 v_accvgpr moves per two K steps).
+// The kernel must therefore never spill to AGPRs: tools/micro/audit_gemm_asm.sh checks the .s (no compiler v_accvgpr_*, no
+// scratch).  Block IDX = mb * 8 + nb -> a[4 IDX : 4 IDX + 3].
+#define FDM_A16(b) "a" #b
+#define FDM_ACLOB16(x) FDM_A16(x##0), FDM_A16(x##1), FDM_A16(x##2), FDM_A16(x##3), FDM_A16(x##4), FDM_A16(x##5), FDM_A16(x##6), FDM_A16(x##7), FDM_A16(x##8), FDM_A16(x##9)
+#define FDM_ACLOB_ALL                                                                                                               \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", FDM_ACLOB16(1), FDM_ACLOB16(2), FDM_ACLOB16(3), FDM_ACLOB16(4), FDM_ACLOB16(5), \
+      FDM_ACLOB16(6), FDM_ACLOB16(7), FDM_ACLOB16(8), FDM_ACLOB16(9), FDM_ACLOB16(10), FDM_ACLOB16(11), FDM_ACLOB16(12), FDM_ACLOB16(13),     \
+      FDM_ACLOB16(14), FDM_ACLOB16(15), FDM_ACLOB16(16), FDM_ACLOB16(17), FDM_ACLOB16(18), FDM_ACLOB16(19), FDM_ACLOB16(20),                 \
+      FDM_ACLOB16(21), FDM_ACLOB16(22), FDM_ACLOB16(23), FDM_ACLOB16(24), "a250", "a251", "a252", "a253", "a254", "a255"
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+template <int DT>
+struct Mma16;
+template <>
+struct Mma16<DT_FP8> {
+  using Acc = f32x4;
+  static constexpr int KS = 128;  // bytes of K per MFMA
+  using Frag = i32x8;
+  template <int IDX>
+  static __device__ __forceinline__ void run(const Frag& a, const Frag& b) {   // unit E8M0 scales (0x7f = 2^0) for both operands
+    const int one = 0x7f7f7f7f;
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 a[%c2:%c3], %0, %1, a[%c2:%c3], %4, %4 op_sel_hi:[0,0,0]" ::"v"(a), "v"(b),
+                 "n"(4 * IDX), "n"(4 * IDX + 3), "v"(one));
+  }
+};
+template <>
+struct Mma16<DT_INT8> {
+  using Acc = i32x4;
+  static constexpr int KS = 64;
+  using Frag = i32x4;
+  template <int IDX>
+  static __device__ __forceinline__ void run(const Frag& a, const Frag& b) {
+    asm volatile("v_mfma_i32_16x16x64_i8 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(4 * IDX), "n"(4 * IDX + 3));
+  }
+};
+template <>
+struct Mma16<DT_BF16> {
+  using Acc = f32x4;
+  static constexpr int KS = 64;
+  using Frag = i32x4;
+  template <int IDX>
+  static __device__ __forceinline__ void run(const Frag& a, const Frag& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(4 * IDX), "n"(4 * IDX + 3));
+  }
+};
+// accumulator block IDX as raw 32-bit words (float bits for fp8 / bf16, int32 for int8)
+template <int IDX>
+__device__ __forceinline__ i32x4 acc_get() {
+  int a, b, c, d;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+               : "=v"(a), "=v"(b), "=v"(c), "=v"(d)
+               : "n"(4 * IDX), "n"(4 * IDX + 1), "n"(4 * IDX + 2), "n"(4 * IDX + 3));
+  return i32x4{a, b, c, d};
+}
+template <int IDX>
+__device__ __forceinline__ void acc_set(const i32x4& v) {
+  asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
+               :
+               : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "n"(4 * IDX), "n"(4 * IDX + 1), "n"(4 * IDX + 2), "n"(4 * IDX + 3));
+}
+
+constexpr int W4_THREADS = 256;
+constexpr int W4_STAGE = (BM + BN) * 128;   // 64 KiB
+
+template <int DT, bool RES>
+__global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup grp) {
+  using M = Mma16<DT>;
+  using Acc = typename M::Acc;
+  using Frag = typename M::Frag;
+  constexpr int NS = 128 / M::KS;  // MFMA k-slices per step (1 for fp8, 2 for int8 / bf16)
+  __shared__ __attribute__((aligned(1024))) uint8_t smem[2 * W4_STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- block -> (problem, tile): as gemm_kernel
+  int prob = 0, m0, n0;
+  int part = 0, part_slot = 0;
+  bool is_part = false;
+  {
+    const int nwg = grp.total_tiles;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    if constexpr (DT == DT_INT8) {
+      if (grp.mode == 1) {
+        t = grp.total_tiles - grp.split_tiles + (bid >> grp.spread_shift);
+      } else if (grp.splits > 1) {
+        const int tf = grp.total_tiles - grp.split_tiles, nb = grp.n_blocks;
+        const int fq = tf / 8 + (xcd < tf % 8 ? 1 : 0), fbase = xcd * (tf / 8) + min(xcd, tf % 8);
+        const int cbase = xcd * (nb / 8) + min(xcd, nb % 8), local = bid >> 3;
+        if (local < fq) {
+          t = fbase + local;
+        } else {
+          const int pi = (cbase - fbase) + (local - fq);
+          t = tf + pi / grp.splits;
+          part = pi % grp.splits;
+          part_slot = pi;
+          is_part = true;
+        }
+      }
+    }
+    const int t0 = grp.p[0].tiles_m * grp.p[0].tiles_n;
+    if (t >= t0) {
+      prob = 1;
+      t -= t0;
+    }
+    const GemmProblem& pp = grp.p[prob];
+    const int in_group = GROUP_M * pp.tiles_n;
+    const int gid = t / in_group;
+    const int first_m = gid * GROUP_M;
+    const int gsz = min(pp.tiles_m - first_m, GROUP_M);
+    const int rem = t - gid * in_group;
+    m0 = (first_m + rem % gsz) * BM;
+    n0 = (rem / gsz) * BN;
+  }
+  const GemmProblem& p = grp.p[prob];
+#ifdef FDM_GEMM_STAMPS
+  unsigned long long* stamp = grp.stamps + (size_t)blockIdx.x * 4;
+  if (tid == 0) stamp[0] = __builtin_readcyclecounter();
+#endif
+
+  int64_t Kb = p.Kb, k_off = 0;
+  if constexpr (DT == DT_INT8) {
+    if (is_part) {   // K range of this part in 64-byte units (the host's split arithmetic); the last part takes the K tail
+      const int nk_all = (int)((p.Kb + BKB - 1) / BKB);
+      const int kt0 = (int)((int64_t)part * nk_all / grp.splits), kt1 = (int)((int64_t)(part + 1) * nk_all / grp.splits);
+      k_off = (int64_t)kt0 * BKB;
+      Kb = min(p.Kb - k_off, (int64_t)(kt1 - kt0) * BKB);
+    }
+  }
+
+  // ---- staging: round r (0..15) of a stage moves rows r * 32 + wave * 8 + lane / 8 (rounds 0-7: A, 8-15: B); lane -> slot lane % 8
+  const int drow = wave * 8 + (lane >> 3);
+  const int dg = ((drow >> 1) & 1) | (((drow >> 3) & 1) << 1);
+  const int dchunk = ((((lane & 7) >> 1) ^ dg) << 1) | (lane & 1);     // source chunk of this lane's slot
+  const uint8_t* bA = p.A + (int64_t)min(m0, p.M - 1) * p.lda + k_off;
+  const uint8_t* bB = p.B + (int64_t)min(n0, p.N - 1) * p.ldb + k_off;
+  uint32_t da[8], db[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    da[r] = (uint32_t)((min(m0 + r * 32 + drow, p.M - 1) - min(m0, p.M - 1)) * p.lda) + dchunk * 16;
+    db[r] = (uint32_t)((min(n0 + r * 32 + drow, p.N - 1) - min(n0, p.N - 1)) * p.ldb) + dchunk * 16;
+  }
+  const uint8_t* zero_page = g_zero_page;
+  // Stage kt: A rows in smem[(kt & 1) * 64 KiB ..], B rows 32 KiB behind them.  A and B are issued separately: B runs one
+  // stage further ahead (its fragments are read a whole step before their MFMAs).
+  auto stage_half = [&](auto inner_c, int kt, const uint8_t* gbase, const uint32_t (&doff)[8], int lds_off) {
+    uint8_t* sX = smem + (kt & 1) * W4_STAGE + lds_off + wave * 1024;
+    const int64_t koff = (int64_t)kt * 128;
+    if constexpr (decltype(inner_c)::value) {
+      const uint32_t la = lds_addr_of(sX);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) glds16_sv(gbase + koff, doff[r], la + r * 4096);
+    } else {
+      const bool ok = koff + dchunk * 16 < Kb;   // K % 16 == 0: a chunk lies inside K or outside
+      // (the offsets are made opaque so that hipcc does not keep 16 loop-invariant 64-bit lane addresses alive for this path)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        uint32_t o = doff[r];
+        asm volatile("" : "+v"(o));
+        glds16(ok ? gbase + koff + o : zero_page, sX + r * 4096);
+      }
+    }
+  };
+  auto stage_a = [&](auto inner_c, int kt) { stage_half(inner_c, kt, bA, da, 0); };
+  auto stage_b = [&](auto inner_c, int kt) { stage_half(inner_c, kt, bB, db, BM * 128); };
+  // DMA j (0..15) of the set issued behind step t's barrier: rounds 0..7 of A(t + 2), then rounds 0..7 of B(t + 3)
+  auto dma_one = [&](auto inner_c, auto jc, int t) {
+    constexpr int j = decltype(jc)::value, r = j & 7;
+    const int kt = j < 8 ? t + 2 : t + 3;
+    const uint8_t* gbase = j < 8 ? bA : bB;
+    const uint32_t off = j < 8 ? da[r] : db[r];
+    uint8_t* sX = smem + (kt & 1) * W4_STAGE + (j < 8 ? 0 : BM * 128) + wave * 1024 + r * 4096;
+    const int64_t koff = (int64_t)kt * 128;
+    if constexpr (decltype(inner_c)::value) {
+#ifndef FDM_W4_NODMA      // (timing ablation only)
+      glds16_sv(gbase + koff, off, lds_addr_of(sX));
+#endif
+    } else {
+      uint32_t o = off;
+      asm volatile("" : "+v"(o));
+      glds16(koff + dchunk * 16 < Kb ? gbase + koff + o : zero_page, sX);
+    }
+  };
+
+  // ---- fragment reads: lane (fi = lane % 16, fq = lane / 16) of block b reads row b * 16 + fi
+  const int fi = lane & 15, fq = lane >> 4;
+  const int fg = ((fi >> 1) & 1) | (((fi >> 3) & 1) << 1);
+  const int a_row = (wm * 128 + fi) * 128, b_row = BM * 128 + (wn * 128 + fi) * 128;
+  // fp8: chunk pair fq, odd fq first take the odd chunk (bank spread; same rule for both operands)
+#ifdef FDM_W4_NOSWAP
+  const int f8_0 = ((fq ^ fg) << 1) * 16, f8_1 = f8_0 ^ 16;
+#else
+  const int f8_0 = (((fq ^ fg) << 1) | (fq & 1)) * 16, f8_1 = f8_0 ^ 16;
+#endif
+  auto read_frag = [&](Frag (&f)[NS], const uint8_t* st_row, int blk) {
+    const uint8_t* rp = st_row + blk * 16 * 128;
+    if constexpr (M::KS == 128) {
+      f[0] = lds_frag<Frag>(rp + f8_0, rp + f8_1);
+    } else {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int c = s * 4 + fq;
+        f[s] = lds_frag<Frag>(rp + ((((c >> 1) ^ fg) << 1) | (c & 1)) * 16, nullptr);
+      }
+    }
+  };
+
+  // accumulator block [mb][nb] = a[4 (8 mb + nb) ..]: lane (fi, fq) holds C[m = mb * 16 + fi][n = nb * 16 + fq * 4 + 0..3].
+  // This statement (clobbering every AGPR) is also what makes the kernel descriptor allocate a[0:255].
+  asm volatile(
+      ".set fdm_i, 0\n\t.rept 256\n\tv_accvgpr_write_b32 a[fdm_i], 0\n\t.set fdm_i, fdm_i + 1\n\t.endr" ::
+          : FDM_ACLOB_ALL);
+
+  // int8 split-K tail, merge launch: accumulators = sum of the parts' int32 partials (exact), no K loop
+  bool merged = false;
+  if constexpr (DT == DT_INT8) {
+    if (grp.mode == 1) {
+      merged = true;
+      const int32_t* src = grp.ws + ((int64_t)(blockIdx.x >> grp.spread_shift) * grp.splits) * (64 * 256 * 4) + tid * 4;
+      const int n_parts = (wave >> (2 - grp.spread_shift)) == (int)(blockIdx.x & ((1 << grp.spread_shift) - 1)) ? grp.splits : 0;
+      static_for<64>([&](auto ic) {
+        constexpr int IDX = decltype(ic)::value;
+        i32x4 sum = {0, 0, 0, 0};
+        for (int sp = 0; sp < n_parts; ++sp) sum += *reinterpret_cast<const i32x4*>(src + (int64_t)sp * (64 * 256 * 4) + IDX * (256 * 4));
+        acc_set<IDX>(sum);
+      });
+    }
+  }
+  if (!merged) {
+    Frag fbx[NS][8], fby[NS][8];   // B fragments of the current / next step, [k-slice][nb]
+    Frag fa[2][NS];                // A fragments, one 16-row block ahead of their MFMAs
+    auto read_b_blk = [&](Frag (&fb)[NS][8], int buf, int nb) {
+      Frag f[NS];
+      read_frag(f, smem + buf * W4_STAGE + b_row, nb);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) fb[s][nb] = f[s];
+    };
+    const int nk = (int)((Kb + 127) / 128);
+    const int nk_full = (int)(Kb / 128);
+    stage_a(std::false_type{}, 0);
+    stage_b(std::false_type{}, 0);
+    stage_a(std::false_type{}, 1);
+    stage_b(std::false_type{}, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) read_b_blk(fbx, 0, nb);
+    read_frag(fa[0], smem + a_row, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // every wave holds B(0) in registers: its buffer takes B(2)
+    stage_b(std::false_type{}, 2);
+#ifdef FDM_GEMM_STAMPS
+    if (tid == 0) stamp[1] = __builtin_readcyclecounter();
+#endif
+    // One step = 8 groups of 8 (NS x 8) MFMAs, group g on A block g.  Per group, in this order (pinned by sched_barriers):
+    //   wait until A block g has landed -- it was issued a whole group ago, followed only by that group's 4 B reads: a COUNTED
+    //   lgkmcnt(4) (LDS returns in order; at most 10 reads are ever outstanding, the counter holds 15);
+    //   issue the reads of A block g + 1 (2) and, for g < 4, of B blocks 2 g, 2 g + 1 of step t + 1 (4);
+    //   the MFMAs.
+    // The block's one barrier per step sits in group 7 behind the wait: every read of stage t has returned and the DMAs issued
+    // a step ago (A(t + 1), B(t + 2)) have landed; behind it A(t + 2) goes into A(t)'s buffer and B(t + 3) into B(t + 1)'s
+    // (in registers since group 3), and A block 0 of stage t + 1 is read.
+    auto step = [&](auto inner_c, auto first_c, Frag (&bc)[NS][8], Frag (&bn)[NS][8], int t) {
+      const int cur = t & 1, nxt = cur ^ 1;
+      const uint8_t* sa_cur = smem + cur * W4_STAGE + a_row;
+      static_for<8>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g == 7) {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifndef FDM_W4_NOBAR      // (timing ablation only)
+          __builtin_amdgcn_s_barrier();
+#endif
+          __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0) again, for hipcc's own bookkeeping (nothing is outstanding)
+          __builtin_amdgcn_sched_barrier(0);
+          read_frag(fa[0], smem + nxt * W4_STAGE + a_row, 0);
+        } else {
+          constexpr int cnt = (g >= 1 && g <= 4) ? 4 : 0;
+          __builtin_amdgcn_s_waitcnt(0xC07F | (cnt << 8));    // lgkmcnt(cnt) only
+          __builtin_amdgcn_sched_barrier(0);
+          read_frag(fa[(g + 1) & 1], sa_cur, g + 1);
+          if constexpr (g < 4) {
+            read_b_blk(bn, nxt, 2 * g);
+            read_b_blk(bn, nxt, 2 * g + 1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NS * 8>([&](auto jc) {
+          constexpr int s = decltype(jc)::value / 8, nb = decltype(jc)::value % 8;
+          M::template run<g * 8 + nb>(bc[s][nb], fa[g & 1][s]);   // swapped operands: MFMA rows = n, columns = m
+          // The 16 DMAs that follow step t's barrier are spread thinly: a burst from all four waves queues on the CU's one
+          // load path and the waves then meet skewed at the next barrier (21 % of the loop, measured).  4 in group 7 of step t,
+          // 3 in each of groups 0..3 of step t + 1 -- all land well before that step's barrier.
+          constexpr int q = decltype(jc)::value, every = NS * 2;      // one DMA slot after every 2nd (NS = 1) / 4th MFMA
+          if constexpr (q % every == every - 1) {
+            constexpr int slot = q / every;                            // 0..3
+            if constexpr (g == 7) dma_one(inner_c, std::integral_constant<int, slot>{}, t);
+            if constexpr (g < 4 && slot < 3 && !decltype(first_c)::value) dma_one(inner_c, std::integral_constant<int, 4 + 3 * g + slot>{}, t - 1);
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    const int nk2 = (nk + 1) & ~1;
+    // step 0 has no DMAs left over from a previous step (the prologue issued A(1), B(2) whole)
+    step(std::false_type{}, std::true_type{}, fbx, fby, 0);
+    step(std::false_type{}, std::false_type{}, fby, fbx, 1);
+    int t = 2;
+    for (; t + 4 < nk_full; t += 2) {            // issues stages up to t + 4: all complete
+      step(std::true_type{}, std::false_type{}, fbx, fby, t);
+      step(std::true_type{}, std::false_type{}, fby, fbx, t + 1);
+    }
+    for (; t < nk2; t += 2) {                     // K tail and (odd nk) one zero-filled padding step
+      step(std::false_type{}, std::false_type{}, fbx, fby, t);
+      step(std::false_type{}, std::false_type{}, fby, fbx, t + 1);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15" ::: "memory");  // retire the padding DMAs and the dead fragment reads; MFMA -> v_accvgpr_read distance
+  __builtin_amdgcn_s_barrier();                                  // every wave is done with the ring: reuse it below
+  if constexpr (DT == DT_INT8) {
+    if (grp.mode == 1 && (wave >> (2 - grp.spread_shift)) != (int)(blockIdx.x & ((1 << grp.spread_shift) - 1))) return;
+    if (is_part) {   // int32 partial sums of this K range -> workspace ([tile * splits + part][64 blocks][256 threads] x 16 B)
+      int32_t* dst = grp.ws + ((int64_t)part_slot) * (64 * 256 * 4) + tid * 4;
+      static_for<64>([&](auto ic) {
+        constexpr int IDX = decltype(ic)::value;
+        *reinterpret_cast<i32x4*>(dst + IDX * (256 * 4)) = acc_get<IDX>();
+      });
+      return;
+    }
+  }
+#ifdef FDM_GEMM_STAMPS
+  if (tid == 0) stamp[2] = __builtin_readcyclecounter();
+#endif
+
+  // ---- epilogue.  Wave-private LDS tile: 128 rows x 256 B; 16-byte chunk c of row r stored at chunk c ^ (r & 15).
+  uint8_t* wt = smem + wave * 32768;
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  auto epilogue = [&](auto epi_c) {
+    constexpr int EPI = decltype(epi_c)::value;
+    float sam[8];
+    int azpm[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const int mc = min(m0 + wm * 128 + mb * 16 + fi, p.M - 1);
+      sam[mb] = 1.0f;
+      azpm[mb] = 0;
+      if constexpr (DT != DT_BF16) sam[mb] = p.sa[mc];
+      if constexpr (DT == DT_INT8) {
+        if (p.azp != nullptr) azpm[mb] = p.azp[mc];
+      }
+    }
+    static_for<8>([&](auto nbc) {
+      constexpr int nb = decltype(nbc)::value;
+      const int nc = min(n0 + wn * 128 + nb * 16 + fq * 4, p.N - 4);
+      float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+      f32x4 sbq = {1.f, 1.f, 1.f, 1.f};
+      i32x4 adjq = {0, 0, 0, 0};
+      if constexpr (DT != DT_BF16) sbq = *reinterpret_cast<const f32x4*>(p.sb + nc);
+      if (p.bias != nullptr) unpack4(*reinterpret_cast<const i32x2*>(p.bias + nc), bias4);
+      if constexpr (DT == DT_INT8) {
+        if (p.azp_adj != nullptr) adjq = *reinterpret_cast<const i32x4*>(p.azp_adj + nc);
+      }
+      static_for<2>([&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        float y[16];   // [mm][c]
+        static_for<4>([&](auto mmc) {
+          constexpr int mm = decltype(mmc)::value, mb = h * 4 + mm;
+          const i32x4 av = acc_get<mb * 8 + nb>();
+          const int aw[4] = {av[0], av[1], av[2], av[3]};   // (a bit_cast applied to `av[c]` directly read element 0 for every c)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float yy;
+            if constexpr (DT == DT_FP8) {
+              yy = __builtin_bit_cast(float, aw[c]) * sam[mb] * sbq[c] + bias4[c];
+            } else if constexpr (DT == DT_INT8) {
+              const int a = aw[c] - azpm[mb] * adjq[c];
+              yy = (float)a * (sam[mb] * sbq[c]);
+              if (p.bias != nullptr) yy = rbf(yy) + bias4[c];
+            } else {
+              yy = __builtin_bit_cast(float, aw[c]) + bias4[c];
+            }
+            y[4 * mm + c] = (EPI == FDM_EPI_GELU_TANH || EPI == FDM_EPI_GELU_ERF) ? rbf(yy) : yy;
+          }
+        });
+        gelu16<EPI>(y);
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+          i32x2 o;
+          o[0] = (int)pack2bf(y[4 * mm], y[4 * mm + 1]);
+          o[1] = (int)pack2bf(y[4 * mm + 2], y[4 * mm + 3]);
+          const int r = (h * 4 + mm) * 16 + fi;          // r & 15 == fi
+          *reinterpret_cast<i32x2*>(wt + r * 256 + (((nb * 2 + (fq >> 1)) ^ fi) << 4) + (fq & 1) * 8) = o;
+        }
+      });
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: no block barrier needed
+    __builtin_amdgcn_sched_barrier(0);
+    // pass 2: row-contiguous 16-byte pieces.  Instruction it (0..31): lane -> row 4 * it + lane / 16, chunk lane % 16.
+    const int rsub = lane >> 4, ch = lane & 15;
+    const int ncol = n0 + wn * 128 + ch * 8;
+    const bool n_ok = full || ncol < p.N;      // N % 8 == 0 is required by the host check for this path
+    const int ncc = n_ok ? ncol : 0;
+    const int64_t ccol = p.plane_cols > 0 ? (int64_t)(ncc / p.plane_cols) * p.plane_stride + (ncc % p.plane_cols) : (int64_t)ncc;
+    auto lds_row = [&](int it) -> i32x4 {
+      const int r = it * 4 + rsub;
+      return *reinterpret_cast<const i32x4*>(wt + r * 256 + ((ch ^ (r & 15)) << 4));
+    };
+    auto store_row = [&](int it, const i32x4& v) {
+      const int m = m0 + wm * 128 + it * 4 + rsub;
+      if (n_ok && (full || m < p.M)) *reinterpret_cast<i32x4*>(p.C + (int64_t)m * p.ldc + ccol) = v;
+    };
+    auto combine = [&](auto f32_c, const i32x4& yv, const float (&g8)[8], const i32x4& rv) -> i32x4 {
+      constexpr bool F32 = decltype(f32_c)::value;
+      i32x4 o;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t yw = (uint32_t)yv[w], rw = (uint32_t)rv[w];
+        float plo = g8[2 * w] * __builtin_bit_cast(float, yw << 16);
+        float phi = g8[2 * w + 1] * __builtin_bit_cast(float, yw & 0xffff0000u);
+        if constexpr (!F32) {
+          plo = rbf(plo);
+          phi = rbf(phi);
+        }
+        o[w] = (int)pack2bf(__builtin_bit_cast(float, rw << 16) + plo, __builtin_bit_cast(float, rw & 0xffff0000u) + phi);
+      }
+      return o;
+    };
+    if constexpr (EPI == FDM_EPI_GATE_RESIDUAL) {
+      const int m_first = m0 + wm * 128, m_last = min(m0 + wm * 128 + 128, p.M) - 1;
+      const bool one_batch = (m_first / p.rows_per_batch) == (m_last / p.rows_per_batch);
+      auto res_row = [&](int it) -> i32x4 {
+        const int mc = min(m0 + wm * 128 + it * 4 + rsub, p.M - 1);
+        return *reinterpret_cast<const i32x4*>(p.res + (int64_t)mc * p.ldc + ncc);
+      };
+      auto load_gate = [&](int64_t batch, float (&g8)[8]) {
+        if (p.gate_f32) {
+          const float* gp = reinterpret_cast<const float*>(p.gate) + batch * p.gate_stride + ncc;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(gp), c = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            g8[i] = a[i];
+            g8[4 + i] = c[i];
+          }
+        } else {
+          const i32x4 gv = *reinterpret_cast<const i32x4*>(p.gate + batch * p.gate_stride + ncc);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            g8[2 * w] = __builtin_bit_cast(float, (uint32_t)gv[w] << 16);
+            g8[2 * w + 1] = __builtin_bit_cast(float, (uint32_t)gv[w] & 0xffff0000u);
+          }
+        }
+      };
+      auto pipelined = [&](auto f32_c) {
+        // groups of 8 row-instructions: loads(g) run one group ahead of combine(g - 1) + stores(g - 1); every load of a
+        // group precedes the stores of the previous one in program order (vmcnt retires in order)
+        float g8[8];
+        load_gate(m_first / p.rows_per_batch, g8);
+        i32x4 rr[2][8], oo[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) rr[0][it] = res_row(it);
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+          if (gi < 3) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) rr[(gi + 1) & 1][it] = res_row((gi + 1) * 8 + it);
+          }
+#pragma unroll
+          for (int it = 0; it < 8; ++it) oo[it] = combine(f32_c, lds_row(gi * 8 + it), g8, rr[gi & 1][it]);
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int it = 0; it < 8; ++it) store_row(gi * 8 + it, oo[it]);
+        }
+      };
+      if (one_batch) {
+        if (p.gate_f32) pipelined(std::true_type{});
+        else pipelined(std::false_type{});
+      } else {
+        for (int it = 0; it < 32; ++it) {
+          const int mc = min(m0 + wm * 128 + it * 4 + rsub, p.M - 1);
+          float g8[8];
+          load_gate(mc / p.rows_per_batch, g8);
+          const i32x4 rv = res_row(it);
+          store_row(it, p.gate_f32 ? combine(std::true_type{}, lds_row(it), g8, rv) : combine(std::false_type{}, lds_row(it), g8, rv));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 32; ++it) store_row(it, lds_row(it));
+    }
+  };
+  if constexpr (RES) {
+    if (p.epi == FDM_EPI_GATE_RESIDUAL) epilogue(std::integral_constant<int, FDM_EPI_GATE_RESIDUAL>{});
+    else if (p.epi == FDM_EPI_GELU_TANH) epilogue(std::integral_constant<int, FDM_EPI_GELU_TANH>{});
+    else if (p.epi == FDM_EPI_GELU_ERF) epilogue(std::integral_constant<int, FDM_EPI_GELU_ERF>{});
+    else epilogue(std::integral_constant<int, FDM_EPI_NONE>{});
+  } else {
+    if (p.epi == FDM_EPI_GELU_TANH) epilogue(std::integral_constant<int, FDM_EPI_GELU_TANH>{});
+    else if (p.epi == FDM_EPI_GELU_ERF) epilogue(std::integral_constant<int, FDM_EPI_GELU_ERF>{});
+    else epilogue(std::integral_constant<int, FDM_EPI_NONE>{});
+  }
+#ifdef FDM_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) stamp[3] = __builtin_readcyclecounter();
+#endif
+}
+
+#ifdef FDM_GEMM_AB
+int g_gemm_use_w4 = 1;   // micro-benchmark builds only: both kernels in one process
+#define FDM_W4_ON (g_gemm_use_w4 != 0)
+#else
+#define FDM_W4_ON (FDM_GEMM_W4 != 0)
+#endif
 #ifdef FDM_GEMM_STAMPS
 unsigned long long* g_gemm_stamps = nullptr;  // >= 4 * grid words, set by the micro-benchmark
 #endif
@@ -704,19 +1263,34 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, 
       g2.splits = S;
       g2.n_blocks = grp.total_tiles - rem + rem * S;
       g2.ws = reinterpret_cast<int32_t*>(ws);
-      if (res) gemm_kernel<DT, true><<<g2.n_blocks, GEMM_THREADS, 0, s>>>(g2);
-      else gemm_kernel<DT, false><<<g2.n_blocks, GEMM_THREADS, 0, s>>>(g2);
+      if (FDM_W4_ON) {
+        if (res) gemm_w4_kernel<DT, true><<<g2.n_blocks, W4_THREADS, 0, s>>>(g2);
+        else gemm_w4_kernel<DT, false><<<g2.n_blocks, W4_THREADS, 0, s>>>(g2);
+      } else {
+        if (res) gemm_kernel<DT, true><<<g2.n_blocks, GEMM_THREADS, 0, s>>>(g2);
+        else gemm_kernel<DT, false><<<g2.n_blocks, GEMM_THREADS, 0, s>>>(g2);
+      }
       FDM_CHECK_LAUNCH();
       g2.mode = 1;
       g2.spread_shift = rem * 4 <= cu ? 2 : (rem * 2 <= cu ? 1 : 0);   // as many merge blocks per tile as fit ONE round
-      if (res) gemm_kernel<DT, true><<<rem << g2.spread_shift, GEMM_THREADS, 0, s>>>(g2);
-      else gemm_kernel<DT, false><<<rem << g2.spread_shift, GEMM_THREADS, 0, s>>>(g2);
+      if (FDM_W4_ON) {
+        if (res) gemm_w4_kernel<DT, true><<<rem << g2.spread_shift, W4_THREADS, 0, s>>>(g2);
+        else gemm_w4_kernel<DT, false><<<rem << g2.spread_shift, W4_THREADS, 0, s>>>(g2);
+      } else {
+        if (res) gemm_kernel<DT, true><<<rem << g2.spread_shift, GEMM_THREADS, 0, s>>>(g2);
+        else gemm_kernel<DT, false><<<rem << g2.spread_shift, GEMM_THREADS, 0, s>>>(g2);
+      }
       FDM_CHECK_LAUNCH();
       return FDM_OK;
     }
   }
-  if (res) gemm_kernel<DT, true><<<grid, GEMM_THREADS, 0, s>>>(grp);
-  else gemm_kernel<DT, false><<<grid, GEMM_THREADS, 0, s>>>(grp);
+  if (FDM_W4_ON) {
+    if (res) gemm_w4_kernel<DT, true><<<grid, W4_THREADS, 0, s>>>(grp);
+    else gemm_w4_kernel<DT, false><<<grid, W4_THREADS, 0, s>>>(grp);
+  } else {
+    if (res) gemm_kernel<DT, true><<<grid, GEMM_THREADS, 0, s>>>(grp);
+    else gemm_kernel<DT, false><<<grid, GEMM_THREADS, 0, s>>>(grp);
+  }
   FDM_CHECK_LAUNCH();
   return FDM_OK;
 }

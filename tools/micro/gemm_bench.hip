@@ -4,7 +4,11 @@
 #include "../../fastdm_amd/csrc/gemm.hip"
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 namespace fdm { thread_local int g_last_hip_error = 0; int device_cu_count() { return 256; } }
+#ifdef FDM_GEMM_AB
+namespace fdm { extern int g_gemm_use_w4; }
+#endif
 #include <vector>
 
 static uint64_t rng = 0x9E3779B97F4A7C15ull;
@@ -44,11 +48,48 @@ int main(int argc, char** argv) {
   hipMalloc(&A, maxA); hipMalloc(&B, maxB); hipMalloc(&C, maxC * 2); hipMalloc(&R, maxC * 2);
   hipMalloc(&G, 12288 * 2); hipMalloc(&bias, 12288 * 2); hipMalloc(&sa, 8704 * 4); hipMalloc(&sb, 12288 * 4);
   {
+    // GEMM_DATA=gauss: e4m3 codes of N(0, 1) * 448 / 4 (what a per-row-scaled activation looks like); default: random finite
+    // codes (uniform over sign / exponent / mantissa: 35 binades of product range)
+    const bool gauss = getenv("GEMM_DATA") && !strcmp(getenv("GEMM_DATA"), "gauss");
+    const bool narrow = getenv("GEMM_DATA") && !strcmp(getenv("GEMM_DATA"), "narrow");   // exponents 6..8: every partial sum exact in fp32
+    auto enc = [](float f) -> uint8_t {   // nearest e4m3fn code, saturating
+      const uint8_t sgn = f < 0 ? 0x80 : 0; float a = fabsf(f); if (a > 448.f) a = 448.f;
+      int e; float m = frexpf(a, &e);   // a = m 2^e, m in [0.5, 1)
+      if (a < 0.0009765625f) return sgn;
+      int E = e - 1 + 7; float frac;
+      if (E <= 0) { frac = a / 0.001953125f; const int q = (int)lrintf(frac); return sgn | (uint8_t)(q > 7 ? 8 : q); }
+      frac = (m * 2.f - 1.f) * 8.f; int q = (int)lrintf(frac); if (q == 8) { q = 0; ++E; }
+      if (E > 15 || (E == 15 && q > 6)) { E = 15; q = 6; }
+      return sgn | (uint8_t)(E << 3) | (uint8_t)q;
+    };
+    auto gfill = [&](std::vector<uint8_t>& h) {
+      for (size_t i = 0; i < h.size(); i += 2) {
+        const float u1 = (nextu() + 1.0f) / 4294967808.0f, u2 = nextu() / 4294967296.0f;
+        const float r = sqrtf(-2.f * logf(u1)) * 112.f;
+        h[i] = enc(r * cosf(6.2831853f * u2));
+        if (i + 1 < h.size()) h[i + 1] = enc(r * sinf(6.2831853f * u2));
+      }
+    };
     std::vector<uint8_t> h(maxA);
-    for (auto& x : h) { uint8_t v = (uint8_t)nextu(); if ((v & 0x7f) >= 0x78) v &= 0xc7; x = v; }   // finite e4m3, random sign/exp
+    if (gauss) gfill(h);
+    else for (auto& x : h) { uint8_t v = (uint8_t)nextu(); if ((v & 0x7f) >= 0x78) v &= 0xc7; x = v; }   // finite e4m3, random sign/exp
+    if (getenv("GEMM_DATA") && !strcmp(getenv("GEMM_DATA"), "ident")) {   // A[m][k] = 1.0 at k == m % 128 (row stride: IDENT_K), else 0
+      const int64_t ik = atol(getenv("IDENT_K"));
+      for (size_t i = 0; i < h.size(); ++i) h[i] = ((int64_t)(i % ik) == (int64_t)((i / ik) % ik)) ? 0x38 : 0;
+    }
     hipMemcpy(A, h.data(), maxA, hipMemcpyHostToDevice);
     h.resize(maxB);
-    for (auto& x : h) { uint8_t v = (uint8_t)nextu(); if ((v & 0x7f) >= 0x78) v &= 0xc7; x = v; }
+    if (gauss) gfill(h);
+    else if (narrow) for (auto& x : h) { const uint32_t u = nextu(); x = (uint8_t)((u & 0x87) | ((6 + (u >> 8) % 3) << 3)); }
+    else for (auto& x : h) { uint8_t v = (uint8_t)nextu(); if ((v & 0x7f) >= 0x78) v &= 0xc7; x = v; }
+    if (getenv("GEMM_DATA") && !strcmp(getenv("GEMM_DATA"), "identb")) {   // B[n][k] = 1.0 at k == n % IDENT_K
+      const int64_t ik = atol(getenv("IDENT_K"));
+      const int64_t dd = getenv("IDENT_D") ? atol(getenv("IDENT_D")) : 0;
+      for (size_t i = 0; i < h.size(); ++i) {
+        const int64_t k = i % ik, n = (i / ik) % ik;
+        h[i] = (k == n || (dd && k == (n + dd) % ik)) ? 0x38 : 0;
+      }
+    }
     hipMemcpy(B, h.data(), maxB, hipMemcpyHostToDevice);
     std::vector<uint16_t> r(maxC);
     for (auto& x : r) x = 0x3c00 + (nextu() & 0x3ff);
@@ -74,6 +115,81 @@ int main(int argc, char** argv) {
       if (use_int8) return fdm_gemm_w8a8_int8(C, A, B, sa, sb, azp_adj, azp, bias, s.M, s.N, s.K, s.K, s.K, s.N, s.epi, G, s.N, R, s.M, nullptr);
       return fdm_gemm_w8a8_fp8(C, A, B, sa, sb, bias, s.M, s.N, s.K, s.K, s.K, s.N, s.epi, G, s.N, R, s.M, nullptr);
     };
+#ifdef FDM_GEMM_AB
+    {   // element-wise comparison of the two kernels on this shape (bf16 outputs)
+      std::vector<uint16_t> h0((size_t)s.M * s.N), h1((size_t)s.M * s.N);
+      fdm::g_gemm_use_w4 = 0; run(); hipMemcpy(h0.data(), C, h0.size() * 2, hipMemcpyDeviceToHost);
+      hipMemset(C, 0xff, h0.size() * 2);
+      fdm::g_gemm_use_w4 = 1; run(); hipMemcpy(h1.data(), C, h1.size() * 2, hipMemcpyDeviceToHost);
+      size_t ndiff = 0, nbig = 0; int maxulp = 0;
+      for (size_t i = 0; i < h0.size(); ++i) if (h0[i] != h1[i]) {
+        ++ndiff;
+        const int d = abs((int)(h0[i] & 0x7fff) - (int)(h1[i] & 0x7fff));
+        const bool sign = (h0[i] ^ h1[i]) & 0x8000;
+        const int u = sign ? (h0[i] & 0x7fff) + (h1[i] & 0x7fff) : d;
+        if (u > maxulp) maxulp = u;
+        if (u > 1) ++nbig;
+      }
+      if (getenv("GEMM_DUMP")) {
+        int shown = 0;
+        std::vector<int> per_n(s.N, 0), per_m(s.M, 0);
+        std::vector<uint8_t> ha2((size_t)s.M * s.K), hb2((size_t)s.N * s.K); std::vector<uint16_t> hbias2(s.N);
+        hipMemcpy(ha2.data(), A, ha2.size(), hipMemcpyDeviceToHost); hipMemcpy(hb2.data(), B, hb2.size(), hipMemcpyDeviceToHost);
+        hipMemcpy(hbias2.data(), bias, s.N * 2, hipMemcpyDeviceToHost);
+        auto e4 = [](uint8_t v) -> double { const int sg = v >> 7, e = (v >> 3) & 15, m = v & 7; const double mag = e == 0 ? m * 0.001953125 : (1.0 + m / 8.0) * pow(2.0, e - 7); return sg ? -mag : mag; };
+        for (size_t i = 0; i < h0.size(); ++i) if (h0[i] != h1[i]) {
+          ++per_n[i % s.N]; ++per_m[i / s.N];
+          if (shown++ < 12) {
+            const size_t m = i / s.N, n = i % s.N; double acc = 0;
+            for (int64_t k = 0; k < s.K; ++k) acc += e4(ha2[m * s.K + k]) * e4(hb2[n * s.K + k]);
+            const float f1 = (float)acc * 1e-4f, f2 = f1 * 1e-4f; uint32_t bb = (uint32_t)hbias2[n] << 16; float bf_; memcpy(&bf_, &bb, 4);
+            const float f3 = f2 + bf_; uint32_t u; memcpy(&u, &f3, 4);
+            printf("      m=%zu n=%zu old %04x w4 %04x | acc %.10g fp32 chain %08x bias %04x\n", m, n, h0[i], h1[i], acc, u, hbias2[n]);
+          }
+        }
+        {
+          long hn[16] = {0}, hm[16] = {0}, hnb[8] = {0}, hmb[8] = {0};
+          for (size_t i = 0; i < h0.size(); ++i) if (h0[i] != h1[i]) { const size_t m = i / s.N, n = i % s.N; ++hn[n & 15]; ++hm[m & 15]; ++hnb[(n >> 4) & 7]; ++hmb[(m >> 4) & 7]; }
+          printf("      by n%%16:"); for (int x = 0; x < 16; ++x) printf(" %ld", hn[x]); printf("\n      by m%%16:"); for (int x = 0; x < 16; ++x) printf(" %ld", hm[x]);
+          printf("\n      by nb:"); for (int x = 0; x < 8; ++x) printf(" %ld", hnb[x]); printf("\n      by mb:"); for (int x = 0; x < 8; ++x) printf(" %ld", hmb[x]); printf("\n");
+        }
+        printf("      mismatches per n (first 64):"); for (int n = 0; n < 256 && n < s.N; ++n) printf(" %d", per_n[n]); printf("\n");
+        printf("      mismatches per m (first 64):"); for (int m = 0; m < 256 && m < s.M; ++m) printf(" %d", per_m[m]); printf("\n");
+      }
+      printf("   old vs w4: %zu of %zu elements differ, %zu by more than 1 bf16 ulp, max %d ulp\n", ndiff, h0.size(), nbig, maxulp);
+      if (s.epi == 0 && !use_int8) {   // both against an exact host reference on sampled elements (fp8 products are exact in double)
+        auto e4m3 = [](uint8_t v) -> double {
+          const int sgn = v >> 7, e = (v >> 3) & 15, m = v & 7;
+          const double mag = e == 0 ? m * 0.001953125 : (1.0 + m / 8.0) * pow(2.0, e - 7);
+          return sgn ? -mag : mag;
+        };
+        auto bf = [](uint16_t h) -> double { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+        std::vector<uint8_t> ha((size_t)s.M * s.K), hb((size_t)s.N * s.K);
+        std::vector<uint16_t> hbias(s.N);
+        hipMemcpy(ha.data(), A, ha.size(), hipMemcpyDeviceToHost); hipMemcpy(hb.data(), B, hb.size(), hipMemcpyDeviceToHost);
+        hipMemcpy(hbias.data(), bias, s.N * 2, hipMemcpyDeviceToHost);
+        double e0 = 0, e1 = 0, m0 = 0, m1 = 0; int cnt = 0;
+        for (int smp = 0; smp < 2000; ++smp) {
+          const size_t m = nextu() % s.M, n = nextu() % s.N;
+          double acc = 0;
+          for (int64_t k = 0; k < s.K; ++k) acc += e4m3(ha[m * s.K + k]) * e4m3(hb[n * s.K + k]);
+          const double ref = acc * 1e-4f * 1e-4f + bf(hbias[n]);
+          const double ulp = fabs(ref) * 0.0078125 + 1e-30;
+          const double d0 = fabs(bf(h0[m * s.N + n]) - ref) / ulp, d1 = fabs(bf(h1[m * s.N + n]) - ref) / ulp;
+          if (getenv("GEMM_DUMP") && smp < 24) {
+            // partial sums over the four 32-byte K groups of the first 128-byte step
+            double part[4] = {0, 0, 0, 0};
+            for (int64_t k = 0; k < 128 && k < s.K; ++k) part[k / 32] += e4m3(ha[m * s.K + k]) * e4m3(hb[n * s.K + k]);
+            printf("      m=%zu n=%zu exact acc %.6g (groups %.6g %.6g %.6g %.6g) | old acc %.6g | w4 acc %.6g\n", m, n, acc, part[0], part[1], part[2], part[3],
+                   (bf(h0[m * s.N + n]) - bf(hbias[n])) * 1e8, (bf(h1[m * s.N + n]) - bf(hbias[n])) * 1e8);
+          }
+          e0 += d0; e1 += d1; if (d0 > m0) m0 = d0; if (d1 > m1) m1 = d1; ++cnt;
+        }
+        printf("   vs exact (2000 samples, units of 2^-7 |ref|): old mean %.4f max %.3f | w4 mean %.4f max %.3f\n", e0 / cnt, m0, e1 / cnt, m1);
+      }
+      fdm::g_gemm_use_w4 = getenv("GEMM_OLD") ? 0 : 1;
+    }
+#endif
     for (int i = 0; i < 3; ++i) if (run() != 0) { printf("launch failed\n"); return 1; }
     hipDeviceSynchronize();
     const int iters = 20;
