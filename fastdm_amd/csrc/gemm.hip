@@ -31,6 +31,7 @@
 //             before the first store (vmcnt retires in order).
 //   edges     M/N: source rows clamped, stores masked.  K tail / stream end: lanes fetch a zero page.
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include "common.h"
 
@@ -946,13 +947,13 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     stage_b(std::false_type{}, 0);
     stage_a(std::false_type{}, 1);
     stage_b(std::false_type{}, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // stage 0 (stage 1 lands while its B fragments are read)
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) read_b_blk(fbx, 0, nb);
     read_frag(fa[0], smem + a_row, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // every wave holds B(0) in registers: its buffer takes B(2)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // stage 1 has landed (step 0 reads its B fragments); every wave holds B(0) in registers: its buffer takes B(2)
     stage_b(std::false_type{}, 2);
 #ifdef FDM_GEMM_STAMPS
     if (tid == 0) stamp[1] = __builtin_readcyclecounter();
@@ -1209,12 +1210,43 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
 #endif
 }
 
+// Which tile kernel runs a launch.  Both compute the same 256 x 256 tiles (int8: bit-identical; fp8 / bf16: identical except for
+// the fp32 summation order inside the MFMA shapes, <= 1-2 bf16 ulp on ~1e-6 of the elements).  Measured inside whole denoise steps
+// on MI355X (rocprofv3 / bench.py A/B on one box, profiles/r03_experiments.md): gemm_w4_kernel wins where a launch is a few rounds
+// of long tiles (FLUX N = 3072 down-projections: 325 vs 350 us) and for FLUX bf16 (the 8-wave kernel is MFMA-issue-bound there);
+// many-round K = 3072 launches stay with the 8-wave kernel, whose two waves per SIMD cover each other's prologue / epilogue
+// (214 vs 218 us).
+// FDM_GEMM_KERNEL = w4 | w8 | auto (default) overrides for A/B runs; read once.
 #ifdef FDM_GEMM_AB
 int g_gemm_use_w4 = 1;   // micro-benchmark builds only: both kernels in one process
-#define FDM_W4_ON (g_gemm_use_w4 != 0)
-#else
-#define FDM_W4_ON (FDM_GEMM_W4 != 0)
 #endif
+static int gemm_kernel_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("FDM_GEMM_KERNEL");
+    mode = (e && !strcmp(e, "w4")) ? 1 : (e && !strcmp(e, "w8")) ? 0 : 2;
+  }
+  return mode;
+}
+template <int DT>
+static bool use_w4(const GemmGroup& grp) {
+#ifdef FDM_GEMM_AB
+  return g_gemm_use_w4 != 0;
+#else
+  const int mode = gemm_kernel_mode();
+  if (mode != 2) return mode == 1;
+  // auto: only whole tiles and an even number of 128-byte K steps (ragged problems pay gemm_w4_kernel's longer prologue /
+  // epilogue and its zero-filled padding step for nothing: Qwen-Image M = 7017 +2 %, SD3.5 N = K = 2432 +3 % per step)
+  int64_t kb = grp.p[0].Kb;
+  for (int i = 0; i < grp.n; ++i) {
+    const GemmProblem& q = grp.p[i];
+    if ((q.M % BM) || (q.N % BN) || (q.Kb % 256) || q.Kb < 2048) return false;
+    if (q.Kb < kb) kb = q.Kb;
+  }
+  if (DT == DT_BF16) return true;                                         // FLUX bf16 1024^2: 88.5 vs 94.7 ms per step
+  return kb >= 8192 || grp.total_tiles <= 3 * device_cu_count();           // FLUX fp8 / int8 down-projections: -4 % / -12 % per launch
+#endif
+}
 #ifdef FDM_GEMM_STAMPS
 unsigned long long* g_gemm_stamps = nullptr;  // >= 4 * grid words, set by the micro-benchmark
 #endif
@@ -1263,7 +1295,7 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, 
       g2.splits = S;
       g2.n_blocks = grp.total_tiles - rem + rem * S;
       g2.ws = reinterpret_cast<int32_t*>(ws);
-      if (FDM_W4_ON) {
+      if (use_w4<DT>(grp)) {
         if (res) gemm_w4_kernel<DT, true><<<g2.n_blocks, W4_THREADS, 0, s>>>(g2);
         else gemm_w4_kernel<DT, false><<<g2.n_blocks, W4_THREADS, 0, s>>>(g2);
       } else {
@@ -1273,7 +1305,7 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, 
       FDM_CHECK_LAUNCH();
       g2.mode = 1;
       g2.spread_shift = rem * 4 <= cu ? 2 : (rem * 2 <= cu ? 1 : 0);   // as many merge blocks per tile as fit ONE round
-      if (FDM_W4_ON) {
+      if (use_w4<DT>(grp)) {
         if (res) gemm_w4_kernel<DT, true><<<rem << g2.spread_shift, W4_THREADS, 0, s>>>(g2);
         else gemm_w4_kernel<DT, false><<<rem << g2.spread_shift, W4_THREADS, 0, s>>>(g2);
       } else {
@@ -1284,7 +1316,7 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, 
       return FDM_OK;
     }
   }
-  if (FDM_W4_ON) {
+  if (use_w4<DT>(grp)) {
     if (res) gemm_w4_kernel<DT, true><<<grid, W4_THREADS, 0, s>>>(grp);
     else gemm_w4_kernel<DT, false><<<grid, W4_THREADS, 0, s>>>(grp);
   } else {
