@@ -1266,6 +1266,105 @@ def gen_c3_equal_inputs(rows=128, seed=0):
     use_backend("torch")
     return d
 
+def gen_teacache_at_size(model="flux", n_steps=25):
+    """TeaCache at the SIZE the metric is quoted on (VERDICT r2 missing item 2): full width, reduced depth (FLUX 1024 x 2048, S = 8704,
+    2 double + 2 single blocks, fp8; Qwen-Image 1328 x 1328, 2 blocks, int8, negative cache), the full 25-step flow-match schedule through the
+    reference's own TeaCache.apply_cache (xcaching.py:187-276) with the SHIPPED coefficients and threshold
+    (examples/xcaching/configs/teacache_{flux,qwenimage}.json).  Stored per forward: the decision, the rel-L1 distance of the modulated
+    input and the accumulated rescaled distance; the final latents.  The two random-weight blocks move the modulated input much less per
+    step than a trained 57-block model does, so a second trace with the threshold scaled to the trace's own increments exercises both branches."""
+    import_reference()
+    import contextlib
+    import io
+    from fastdm.caching.xcaching import AutoCache
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from fastdm_amd.pipeline import flow_match_sigmas
+    t0 = time.time()
+    if model == "flux":
+        from oracle import flux as OF
+        cfg = OF.FluxConfig(num_layers=2, num_single_layers=2)
+        sd = OF.synth_state_dict(cfg, seed=0)
+        inp = OF.synth_inputs(cfg, 1, 64, 128, 512, 0)
+        coeffs = json.load(open(os.path.join(REF, "examples/xcaching/configs/teacache_flux.json")))
+        sig = flow_match_sigmas(n_steps, 64 * 128)
+        quant, qname = torch.float8_e4m3fn, "fp8"
+        use_backend("cpu_fp8")
+        conds = [inp["encoder_hidden_states"]]
+    else:
+        from oracle import qwen as OQ
+        cfg = OQ.QwenConfig(num_layers=2)
+        sd = OQ.synth_state_dict(cfg, seed=0)
+        inp = OQ.synth_inputs(cfg, batch=1, img_h=83, img_w=83, n_txt=128, seed=0)
+        neg = OQ.synth_inputs(cfg, batch=1, img_h=83, img_w=83, n_txt=128, seed=1)["encoder_hidden_states"]
+        coeffs = json.load(open(os.path.join(REF, "examples/xcaching/configs/teacache_qwenimage.json")))
+        coeffs["negtive_cache"] = True
+        sig = flow_match_sigmas(n_steps, 83 * 83)
+        quant, qname = torch.int8, "int8"
+        use_backend("torch")
+        conds = [inp["encoder_hidden_states"], neg]
+    print(f"[{model}] synthetic weights {time.time() - t0:.0f}s", flush=True)
+    d = {"meta_model": model, "meta_quant": qname, "meta_n_steps": n_steps, "sigmas": torch.from_numpy(np.asarray(sig, dtype=np.float64).copy()),
+         "coefficients": np.array(coeffs["coefficients"])}
+    if "negtive_coefficients" in coeffs and coeffs.get("negtive_coefficients") is not None:
+        d["negtive_coefficients"] = np.array(coeffs["negtive_coefficients"])
+
+    def run(tag, thr):
+        state = {"step": 0}
+        cfgd = dict(coeffs)
+        cfgd["threshold"] = thr
+        cache = AutoCache.from_dict(cfgd)
+        cache.config.current_steps_callback = lambda: state["step"]
+        core = ref_flux_core(cfg, quant, sd, cache=cache) if model == "flux" else ref_qwen_core(cfg, quant, sd, cache=cache)
+        lat = inp["hidden_states"].clone()
+        dec, rel, acc = [], [], []
+        for i in range(n_steps):
+            state["step"] = i
+            row = []
+            for ci, enc in enumerate(conds):
+                # TeaCache keys: "positive" on the first forward of a step, "negative" on the second (xcaching.py:66-76)
+                prev = {k: v.clone() for k, v in cache.previous_modulated_input_dict.items()}
+                buf = io.StringIO()
+                with contextlib.redirect_stdout(buf):
+                    if model == "flux":
+                        out = core.forward(hidden_states=lat, encoder_hidden_states=enc, pooled_projections=inp["pooled_projections"],
+                                           timestep=torch.tensor([float(sig[i])]), img_ids=inp["img_ids"], txt_ids=inp["txt_ids"],
+                                           guidance=torch.tensor([3.5]))[0]
+                    else:
+                        out = core.forward(hidden_states=lat, encoder_hidden_states=enc, encoder_hidden_states_mask=inp["encoder_hidden_states_mask"],
+                                           timestep=torch.tensor([float(sig[i])]), img_shapes=inp["img_shapes"], txt_seq_lens=inp["txt_seq_lens"])[0]
+                key = "negative" if (len(conds) > 1 and ci == 1) else "positive"     # get_cache_key alternates (xcaching.py:66-76)
+                cur = cache.previous_modulated_input_dict[key]
+                r = float(((cur - prev[key]).abs().mean() / prev[key].abs().mean()).cpu().item()) if key in prev else 0.0
+                rel.append(r)
+                acc.append(float(cache.accumulated_rel_l1_distance_dict[key]))
+                dec.append(0 if "Skipping" in buf.getvalue() else 1)
+                row.append(out)
+            if model == "flux":
+                comb = row[0].float()
+            else:
+                comb = (row[1].float() + 4.0 * (row[0].float() - row[1].float()))[..., : cfg.in_channels]
+            lat = (lat.float() + float(sig[i + 1] - sig[i]) * comb).to(torch.bfloat16)
+            print(f"[{model}/{tag}] step {i} t={time.time() - t0:.0f}s decisions {dec[-len(conds):]} rel {rel[-len(conds):]} acc {acc[-len(conds):]}", flush=True)
+        d[f"{tag}_threshold"] = thr
+        d[f"{tag}_should_calc"] = np.array(dec, dtype=np.int8)
+        d[f"{tag}_rel"] = np.array(rel, dtype=np.float64)
+        d[f"{tag}_acc"] = np.array(acc, dtype=np.float64)
+        d[f"{tag}_final"] = lat
+        return rel
+
+    rel = run("shipped", float(coeffs["threshold"]))
+    # second trace: a threshold of ~2.5 typical per-forward increments of THIS trajectory, so that skips and recomputes alternate
+    polys = {0: np.poly1d(coeffs["coefficients"])}
+    if len(conds) > 1:
+        polys[1] = np.poly1d(coeffs["negtive_coefficients"])
+    incs = [float(polys[j % len(conds)](r)) for j, r in enumerate(rel) if j >= len(conds)]
+    thr2 = float(np.round(2.5 * float(np.median(np.abs(incs))), 6))
+    run("scaled", thr2)
+    d.update({f"meta_prov_{k}": str(v) for k, v in provenance().items()})
+    save(f"teacache_at_size_{model}.npz", d)
+    use_backend("torch")
+
+
 def gen_radial_full():
     """BASELINE.json configs[4] at its real size: Wan2.2-T2V-A14B 768x1280x81f = 21 latent frames x 48 x 80 tokens (S = 80 640),
     the reference's own radial-attention config (examples/sparse/radial_attn_wan.json: block 64, decay 0.3).  The reference's mask
@@ -1297,7 +1396,7 @@ def gen_radial_full():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3", "c3_traj", "c3_depth", "radial_full", "c3_equal", "wan_ti2v"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3", "c3_traj", "c3_depth", "teacache_flux", "teacache_qwen", "radial_full", "c3_equal", "wan_ti2v"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     ap.add_argument("--steps", type=int, default=4, help="c3_traj: denoise steps of the 25-step schedule")
@@ -1346,6 +1445,10 @@ def main():
         for tag in args.quant:
             for att in args.attention:
                 gen_c3_traj(args.blocks[0], args.blocks[1], tag, n_steps=args.steps, attention=att)
+    if args.what == "teacache_flux":
+        gen_teacache_at_size("flux")
+    if args.what == "teacache_qwen":
+        gen_teacache_at_size("qwen")
     if args.what == "c3_depth":
         gen_c3_depth(args.quant, args.attention)
     if args.what == "radial_full":
