@@ -1322,7 +1322,7 @@ def gen_teacache_at_size(model="flux", n_steps=25):
             row = []
             for ci, enc in enumerate(conds):
                 # TeaCache keys: "positive" on the first forward of a step, "negative" on the second (xcaching.py:66-76)
-                prev = {k: v.clone() for k, v in cache.previous_modulated_input_dict.items()}
+                prev = {k: v.clone() for k, v in cache.previous_modulated_input_dict.items() if v is not None}
                 buf = io.StringIO()
                 with contextlib.redirect_stdout(buf):
                     if model == "flux":

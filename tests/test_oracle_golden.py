@@ -542,3 +542,37 @@ def test_controlnet_residual_inputs_flux_sd3_sdxl(monkeypatch):
     out = corex.forward(ix["sample"], torch.tensor(500.0), ix["encoder_hidden_states"], ix["added_cond_kwargs"],
                         down_block_additional_residuals=cn("sdxl.down", shapes), mid_block_additional_residual=cn("sdxl.mid", [(2, c2, 4, 6)])[0])[0]
     assert torch.equal(out, g["sdxl"])
+
+
+# ------------------------------------------------------------------ fixture self-consistency
+@pytest.mark.parametrize("quant", ["fp8", "bf16"])
+def test_trajectory_fixture_step0_equals_single_forward_fixture(quant):
+    """Two fixtures made from the same model, inputs and t = 1.0 by two generator entry points (`c3` and `c3_traj`) must agree
+    bit for bit: a fixture that fails this was made in another environment or from a dirty tree and is not evidence."""
+    import os
+    from oracle.make_golden import GOLD
+    c3, traj = f"flux_c3_{quant}_19x38.npz", f"flux_c3_traj_{quant}_ref_19x38_4steps.npz"
+    if not (os.path.exists(os.path.join(GOLD, c3)) and os.path.exists(os.path.join(GOLD, traj))):
+        pytest.skip("full-depth fixtures not generated")
+    g, t = load(c3), load(traj)
+    sub = int(t["meta_sub"])
+    assert torch.equal(t["out_s0"], g["out"][:, ::sub]), f"{traj}: step 0 does not reproduce {c3}"
+
+
+def test_depth_curve_fixtures_are_below_the_chaos_floor():
+    """The depth-curve fixtures exist to give the full-width comparison teeth where the network has not yet amplified 1-ulp
+    differences to its chaos floor (~4 % of |x| in fp8 after 57 blocks): |control - ref| must grow with depth and stay well below
+    the full-depth envelope at the first depths."""
+    import os
+    from oracle.make_golden import GOLD
+    for quant, floor in (("fp8", 0.041), ("bf16", 0.0117)):
+        names = [f"flux_c3_depth_{quant}_{a}_8x4.npz" for a in ("ref", "fp32")]
+        if not all(os.path.exists(os.path.join(GOLD, n)) for n in names):
+            pytest.skip("depth fixtures not generated")
+        r, c = load(names[0]), load(names[1])
+        means = []
+        for key in ("hidden_d0_sub", "hidden_d1_sub", "hidden_d3_sub", "hidden_d7_sub", "x_s0_sub", "x_s1_sub", "x_s3_sub"):
+            means.append((c[key].float() - r[key].float()).abs().mean().item())
+        assert means[0] < 0.2 * floor, (quant, means)            # after ONE block: an order of magnitude under saturation
+        assert means[-1] > means[0], (quant, means)              # and growing with depth
+        assert r["meta_prov_threads"] == c["meta_prov_threads"]
