@@ -39,6 +39,12 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #ifndef FDM_ATT_V2
 #define FDM_ATT_V2 1
 #endif
+// A/B build (tools/micro, tests): Q is pre-scaled by a power of two only (exact in bf16) and the rest of scale * log2(e) is
+// applied in fp32 to the scores -- the reference's arithmetic -- at one extra VALU per score.  Prices the bf16 rounding of the
+// pre-scaled Q that the shipped kernel takes.
+#ifndef FDM_ATT_EXACT_Q
+#define FDM_ATT_EXACT_Q 0
+#endif
 #ifndef FDM_ATT_THREADS
 #define FDM_ATT_THREADS 512
 #endif
@@ -59,6 +65,8 @@ struct AttnParams {
   int n_qblocks;
   int mask_bq, mask_bk, mask_nq, mask_nk;
   float scale_log2e;
+  float q_prescale;   // what Q is multiplied by before its bf16 rounding (= scale_log2e; FDM_ATT_EXACT_Q: the nearest power of two)
+  float exp_r;        // FDM_ATT_EXACT_Q: scale_log2e / q_prescale, applied in fp32 in front of every exp2 (A/B build only)
   // split-KV tail balancing: block ids >= n_full are parts of tail q-blocks (S parts each, consecutive KV ranges)
   int n_full, split;
   float* ws_o;   // [tail part][256 rows][D] unnormalised fp32 O
@@ -603,7 +611,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         const uint32_t u = (uint32_t)v[w];
-        v[w] = (int)pack2bf(__builtin_bit_cast(float, u << 16) * p.scale_log2e, __builtin_bit_cast(float, u & 0xffff0000u) * p.scale_log2e);
+        v[w] = (int)pack2bf(__builtin_bit_cast(float, u << 16) * p.q_prescale, __builtin_bit_cast(float, u & 0xffff0000u) * p.q_prescale);
       }
       asm volatile("" : "=a"(qa[qb][ks]) : "0"(v));
     }
@@ -692,6 +700,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
   auto sm_exp = [&](f32x16 (&S)[2][2], auto nidx) {
     constexpr int N = decltype(nidx)::value, g = N >> 4, kb = g >> 1, sx = g & 1, qb = (N >> 3) & 1, r = N & 7, e = 8 * sx + r;
     if constexpr (FDM_A64_ABL & 4) asm volatile("" : "+v"(S[kb][qb][e]));
+    else if constexpr (FDM_ATT_EXACT_Q) S[kb][qb][e] = __builtin_amdgcn_exp2f(S[kb][qb][e] * p.exp_r);
     else S[kb][qb][e] = __builtin_amdgcn_exp2f(S[kb][qb][e]);
   };
   auto sm_add = [&](f32x16 (&S)[2][2], auto nidx) {   // one gap after sm_exp(n): the transcendental's latency is not exposed
@@ -724,7 +733,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
       float delta = __builtin_ceilf(mx[qb] + 7.0f);              // integer: every rescale below is a power of two (exact)
       if (!first) delta = fmaxf(delta, 0.f);
       if (!(mx[qb] > -3.0e38f)) delta = 0.f;                     // a fully masked row keeps its reference
-      const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+      const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(FDM_ATT_EXACT_Q ? -delta * p.exp_r : -delta);
       mref[qb] += delta;
       l_run[qb] *= alpha;
 #if FDM_A64_LSUM_MFMA
@@ -756,6 +765,10 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
       asm volatile("" : "=v"(mneg[qb]) : "0"(mn));               // keep 16 live registers: an MFMA's C operand cannot broadcast one
     }
   };
+  // MASKED: a wave whose mask row drops the first tiles of the block's union list has no row reference yet (it stays 0); its first
+  // LIVE tile must set it the way the first tile of a dense row does (delta may be negative), or rows whose kept logits all
+  // lie below ~ -126 (log2 domain) underflow to P = 0 and an all-zero output.  Wave-uniform.
+  bool ref_set = !MASKED;
   // decision for tile t: tail masking and the wave-wide vote on the row maxima mx (of S' = scores - reference)
   auto decide = [&](f32x16 (&S)[2][2], float (&mx)[2], int t, bool first, bool have_mx, bool dead) {
     if (dead) {   // MASKED: this wave's mask row drops the tile
@@ -793,7 +806,13 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
         mx[qb] = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
       }
     }
-    if (first || tail || __any(fmaxf(mx[0], mx[1]) >= 1.0f)) fixup(S, mx, first);
+    if constexpr (MASKED) {
+      const bool f = first || !ref_set;
+      if (f || tail || __any(fmaxf(mx[0], mx[1]) >= 1.0f)) fixup(S, mx, f);
+      ref_set = true;
+    } else {
+      if (first || tail || __any(fmaxf(mx[0], mx[1]) >= 1.0f)) fixup(S, mx, first);
+    }
   };
 
   // One pipeline step for tile t (relative index I = (t - t_begin) % 4 fixes every ring slot at compile time):
@@ -937,7 +956,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
     // MFMA result -> VALU read of Sn: the ordering asm keeps every reader of Sn below the P.V MFMAs above
     asm volatile("" : "+v"(Sn[0][0]), "+v"(Sn[0][1]), "+v"(Sn[1][0]), "+v"(Sn[1][1]));
     // fix-up path only if some row's S' reached 1 (vote), or tile t+1 is the sequence's masked last tile
-    if (t + 1 < t_end && (vote != 0 || tn == t_tail || dead)) decide(Sn, mx, tn, false, true, dead);
+    if (t + 1 < t_end && (vote != 0 || tn == t_tail || dead || (MASKED && !ref_set))) decide(Sn, mx, tn, false, true, dead);
     FDM_STAMP(ts4);
 #ifdef FDM_ATT_STAMPS
     st_a += ts1 - ts0; st_w += ts2 - ts1; st_b += ts3 - ts2; st_d += ts4 - ts3; st_n += 1;
@@ -1040,7 +1059,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
           *reinterpret_cast<f32x4*>(wo + 32 * d + 8 * g4 + 4 * h) = w;
         }
       if (h == 0) {
-        p.ws_ml[(slot * QBT + row) * 2] = t_begin < t_end ? mref[qb] : -1.0e30f;
+        p.ws_ml[(slot * QBT + row) * 2] = t_begin < t_end ? (FDM_ATT_EXACT_Q ? mref[qb] * p.exp_r : mref[qb]) : -1.0e30f;
         p.ws_ml[(slot * QBT + row) * 2 + 1] = l_tot;
       }
       continue;
@@ -1159,6 +1178,13 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
     p.mask_nk = (int)((sk + block_k - 1) / block_k);
   }
   p.scale_log2e = scale * 1.4426950408889634f;
+#if FDM_ATT_EXACT_Q
+  p.q_prescale = exp2f(rintf(log2f(p.scale_log2e)));
+  p.exp_r = p.scale_log2e / p.q_prescale;
+#else
+  p.q_prescale = p.scale_log2e;
+  p.exp_r = 1.0f;
+#endif
   const int64_t bh = batch * q_heads;
   int64_t grid = 8 * ((bh + 7) / 8) * p.n_qblocks;
   hipStream_t s = to_stream(stream);

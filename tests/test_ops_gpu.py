@@ -551,6 +551,29 @@ def test_sparse_attention_random_masks(K, S, seed, density):
     assert (got.float() - ref.float()).abs().mean().item() < 1e-3
 
 
+def test_sparse_attention_negative_logits_with_dropped_first_union_tile(K):
+    """inside a 256-row kernel block the second mask row drops the first tile of the union list, and every kept logit of
+    those rows is far below -126 in the exp2 domain (q . k = -40 per element pair: scale * 128 * -40 * log2 e = -650).  A wave that
+    keeps reference 0 across its dropped first tile underflows to P = 0, l = 0 and writes zeros; the softmax is perfectly defined
+    (it is shift-invariant).  Also at-size discriminating: outputs are O(1)."""
+    g = gen(77)
+    B, S, H, hd = 1, 768, 2, 128
+    q = torch.full((B, S, H * hd), 5.0).to(BF16)
+    k = (torch.full((B, S, H * hd), -8.0) + 0.25 * torch.randn(B, S, H * hd, generator=g)).to(BF16)
+    v = rbf(g, B, S, H * hd)
+    nq, nk = -(-S // 128), -(-S // 64)
+    m = torch.zeros(B, H, nq, nk, dtype=torch.int8)
+    m[:, :, 0::2, 0] = 1            # first mask row of each 256-row block keeps tile 0 ...
+    m[:, :, 0::2, 5] = 1
+    m[:, :, 1::2, 3] = 1            # ... the second one starts at tile 3: dead first union tile for waves 2, 3
+    m[:, :, 1::2, 7] = 1
+    got = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=m.cuda()).cpu()
+    ref = O.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5, block_mask=m)
+    assert torch.isfinite(got.float()).all()
+    assert ref.float().abs().mean().item() > 0.05
+    torch.testing.assert_close(got, ref, rtol=0.0, atol=1.8e-2)
+
+
 @pytest.mark.parametrize("rows,d", [(8192, 5120), (2048, 10240), (7, 8)])
 def test_gelu_and_mul_shapes(K, rows, d):
     g = gen(rows + d)
