@@ -89,29 +89,64 @@ def cpu_baseline_leg(height, width, n_txt, quant_tag):
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh child processes (one per GPU, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* set) BEFORE anything in this process touches the GPU, relay rank 0's JSON line, and return
-    non-zero if any rank failed.  The parent never initialises HIP and never re-execs itself."""
-    import socket
-    import subprocess
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if out0:
-        sys.stdout.write(out0)
-        sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
-        return 1
-    return 0
+    non-zero if any rank failed.  The parent never initialises HIP and never re-execs itself; it polls ALL ranks, terminates
+    the others when one dies (a dead rank otherwise leaves its siblings in the rendezvous until the RCCL timeout) and gives up
+    after FDM_BENCH_TIMEOUT seconds (default 1500)."""
+    from fastdm_amd.launch import spawn_self
+    return spawn_self(__file__, sys.argv[1:], n, timeout=float(os.environ.get("FDM_BENCH_TIMEOUT", "1500")))
+
+
+def cpu_baseline_qwen(height, width, n_txt, quant_tag):
+    """Qwen-Image: ONE double-stream block of the oracle at full width (S = image tokens + text tokens), x 60 blocks x 2 forwards
+    (true CFG) per denoise step."""
+    from oracle import qwen as OQ
+    cfg = OQ.QwenConfig(num_layers=1)
+    quant = {"fp8": torch.float8_e4m3fn, "int8": torch.int8, "bf16": None}[quant_tag]
+    sd = {n: OQ.synth_tensor(n, sh, k, 0) for n, sh, k in OQ.param_specs(cfg) if n.startswith("transformer_blocks.0.")}
+    blk = OQ.QwenImageTransformerBlock(sd, 0, cfg, quant)
+    h, w = height // 16, width // 16
+    D = cfg.num_attention_heads * cfg.attention_head_dim
+    g = torch.Generator().manual_seed(0)
+    hidden = torch.randn(1, h * w, D, generator=g).to(torch.bfloat16)
+    enc = torch.randn(1, n_txt, D, generator=g).to(torch.bfloat16)
+    temb = torch.randn(1, D, generator=g).to(torch.bfloat16)
+    rope = OQ.qwen_rope_cache([(1, h, w)], n_txt, cfg.axes_dims_rope)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        blk(hidden, enc, temb, rope)
+        dt = time.perf_counter() - t0
+    step_s = dt * 60 * 2
+    return {"value": 1.0 / step_s, "unit": "it/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (torch-CPU restatement of the reference torch backend, {quant_tag}): 1 Qwen-Image block {dt:.1f}s at full width "
+                      f"S={h * w + n_txt}, extrapolated x60 blocks x2 CFG forwards to one denoise step ({step_s:.0f}s)"}
+
+
+def cpu_baseline_sdxl(height, width, n_txt, quant_tag):
+    """SDXL UNet (BASELINE.json configs[0] is its CPU path): ONE transformer layer of the oracle at each of the two attention
+    levels (640 / 1280 channels, CFG batch 2), x the 10 / 60 layers of the UNet; the 52 convolutions and group norms (library calls
+    on both sides) are not in the sample."""
+    from oracle import sdxl as OS
+    cfg = OS.SDXLConfig()
+    quant = {"fp8": torch.float8_e4m3fn, "int8": torch.int8, "bf16": None}[quant_tag]
+    g = torch.Generator().manual_seed(0)
+    enc = torch.randn(2 * n_txt, cfg.cross_attention_dim, generator=g).to(torch.bfloat16).reshape(2, n_txt, -1)
+    times = []
+    for c, tokens, name in ((cfg.block_out_channels[1], (height // 16) * (width // 16), "down_blocks.1.attentions.0"),
+                            (cfg.block_out_channels[2], (height // 32) * (width // 32), "down_blocks.2.attentions.0")):
+        sd = {n: OS.synth_tensor(n, sh, k, 0) for n, sh, k in OS._transformer(name, c, 1, cfg.cross_attention_dim)}
+        blk = OS.BasicTransformerBlock(sd, f"{name}.transformer_blocks.0", c, cfg.head_dim, quant)
+        x = torch.randn(2 * tokens, c, generator=g).to(torch.bfloat16)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            blk(x, enc, 2)
+            times.append(time.perf_counter() - t0)
+    n1 = cfg.transformer_layers[0] * 5                      # 2 down + 3 up attentions at level 1
+    n2 = cfg.transformer_layers[1] * 5 + cfg.mid_layers     # 2 down + 3 up at level 2, + the mid block
+    step_s = times[0] * n1 + times[1] * n2
+    return {"value": 1.0 / step_s, "unit": "it/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (torch-CPU restatement of the reference torch backend, {quant_tag}): 1 transformer layer at 640 channels "
+                      f"{times[0]:.1f}s + 1 at 1280 channels {times[1]:.1f}s, CFG batch 2, {height}x{width}, extrapolated x{n1}/x{n2} layers "
+                      f"to one UNet forward ({step_s:.0f}s; convolutions / group norms not included)"}
 
 
 _RESULT_FD = None
@@ -345,12 +380,16 @@ def main():
             one_step()
         if rec:
             rec.__exit__(None, None, None)
+        torch.cuda.synchronize()
+        t_steps = time.perf_counter() - t0          # this rank's own steps (a straggler shows here, not only in the max)
         final = gather_final()      # the job's single end-of-job collective (RCCL all-gather)
         torch.cuda.synchronize()
+        t_gather = time.perf_counter() - t0 - t_steps
         D.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, dev)
+    per_rank = D.gather_floats([t_steps / args.steps * 1e3, t_gather * 1e3], dev)     # [world][2]
     assert torch.isfinite(final.float()).all(), "non-finite latents"
 
     if rank != 0:
@@ -386,11 +425,12 @@ def main():
                     f"({'one batch-2 forward' if args.batch_cfg else '2 forwards'} per step), batch 1 per GPU, 60 double-stream blocks"
                     + (f", TeaCache ({skipped}/{nfw} forwards skipped)" if cache else ""))
     out = {
-        "metric": {"flux": "denoise it/s (sec/image = 25 / (value / n_gpus)), FLUX 1024x2048 fp8 @25 steps",
-                   "qwen": "denoise it/s (sec/image = 25 / (value / n_gpus)), Qwen-Image 1328x1328 int8 @25 steps, true CFG",
-                   "sd35": "denoise it/s (sec/image = 28 / (value / n_gpus)), SD3.5-large 1024x1024 fp8 @28 steps, CFG",
-                   "sdxl": "denoise it/s (sec/image = 30 / (value / n_gpus)), SDXL-base UNet 1024x1024 fp8 @30 steps, CFG",
-                   "wan": "denoise it/s (sec/video = 40 / (value / n_gpus)), Wan2.2-T2V-A14B 768x1280x81f fp8 @40 steps, CFG"}[args.model],
+        # value counts denoise steps of ALL images in flight (n_images = n_gpus, or n_gpus / 2 with --cfg-pair)
+        "metric": {"flux": f"denoise it/s (sec/image = 25 / (value / {n_images})), FLUX 1024x2048 fp8 @25 steps",
+                   "qwen": f"denoise it/s (sec/image = 25 / (value / {n_images})), Qwen-Image 1328x1328 int8 @25 steps, true CFG",
+                   "sd35": f"denoise it/s (sec/image = 28 / (value / {n_images})), SD3.5-large 1024x1024 fp8 @28 steps, CFG",
+                   "sdxl": f"denoise it/s (sec/image = 30 / (value / {n_images})), SDXL-base UNet 1024x1024 fp8 @30 steps, CFG",
+                   "wan": f"denoise it/s (sec/video = 40 / (value / {n_images})), Wan2.2-T2V-A14B 768x1280x81f fp8 @40 steps, CFG"}[args.model],
         "value": n_images * args.steps / elapsed,
         "unit": "it/s",
         "n_gpus": world,
@@ -400,6 +440,10 @@ def main():
         "sec_per_image": ms_per_step * IMAGE_STEPS / 1e3,
         "higher_is_better": True,
         "scaling": "strong" if (pair is not None and world == 2) else "weak",
+        "scaling_note": (f"dp{n_images} x cfg2: each image is strong-scaled over a GPU pair (cond / uncond forward), pairs are added weakly"
+                         if pair is not None else f"dp{world}: one image per GPU"),
+        "per_rank_ms_per_step": [round(r[0], 3) for r in per_rank],
+        "final_allgather_ms": round(max(r[1] for r in per_rank), 3),
         "vs_baseline": None,
         "dtype": {"fp8": "fp8_e4m3 W8A8 GEMM (fp32 accumulate) + bf16 attention", "int8": "int8 W8A8 + bf16 attention", "bf16": "bf16"}[args.quant],
         "data": f"synthetic (counter-based random weights of the {ARCH_NAME[args.model]} architecture, synthetic latents/prompt embeddings)",
@@ -424,12 +468,23 @@ def main():
                            "peak": kernels[dom]["peak_TFLOPs"], "unit": "TFLOP/s", "frac": kernels[dom]["frac"],
                            "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": kernels[dom]["avg_ms"]}
         out["kernels"] = kernels
+        # the W8A8 GEMM family as ONE entry (its instantiations are separate spans above, so the family never shows up as the
+        # "dominant kernel" although it is the largest share of the step)
+        fam = [k for k in summ if k.startswith("gemm_w8a8")]
+        if fam:
+            fdt = "int8" if "int8" in fam[0] else "fp8"
+            f_ms, f_work = sum(summ[k]["total_ms"] for k in fam), sum(summ[k]["work"] for k in fam)
+            f_tf = f_work / (f_ms * 1e-3) / 1e12
+            out["roofline_family"] = {"family": f"W8A8 {fdt} GEMM (fdm::gemm_kernel / fdm::gemm_w4_kernel, all epilogues)", "spans": fam, "bound": "mfma",
+                                      "achieved": f_tf, "peak": PEAK_TFLOPS[fdt], "unit": "TFLOP/s", "frac": f_tf / PEAK_TFLOPS[fdt],
+                                      "ms_per_step": f_ms / args.steps, "share_of_step": f_ms / args.steps / ms_per_step}
         flops_step = sum(s["work"] for s in summ.values()) / args.steps
         out["step_TFLOP"] = flops_step / 1e12
         out["step_achieved_TFLOPs"] = flops_step / (ms_per_step * 1e-3) / 1e12
-    if world == 1 and not args.no_cpu_baseline and args.model == "flux":
+    if world == 1 and not args.no_cpu_baseline and args.model in ("flux", "qwen", "sdxl"):
         try:
-            out["cpu_baseline"] = cpu_baseline_leg(args.height, args.width, args.max_seq_len, args.quant)
+            leg = {"flux": cpu_baseline_leg, "qwen": cpu_baseline_qwen, "sdxl": cpu_baseline_sdxl}[args.model]
+            out["cpu_baseline"] = leg(args.height, args.width, args.max_seq_len, args.quant)
         except Exception as e:  # noqa: BLE001  -- the baseline leg must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e}"}
     emit_result(json.dumps(out))

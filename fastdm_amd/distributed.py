@@ -96,6 +96,17 @@ def max_over_ranks(x: float, device) -> float:
     return float(t.item())
 
 
+def gather_floats(xs, device):
+    """Every rank's list of floats, as [world][len(xs)] on every rank (per-rank step time / collective time of a benchmark run:
+    the max over ranks alone hides which rank was slow)."""
+    if not dist.is_initialized():
+        return [list(map(float, xs))]
+    t = torch.tensor(list(xs), dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(v) for v in o.tolist()] for o in out]
+
+
 # ---------------------------------------------------------------------------------------------- CFG-pair split
 # Models that run a conditional AND an unconditional forward per step (the reference flags them in
 # caching/config.py:16 and loops over both in model_entry.py:782-789) leave GPUs idle when there are fewer images

@@ -9,8 +9,6 @@ differs from RCCL but the protocol (who runs which forward, what is gathered, wh
 so the bit-equality checks run on a 1-GPU box too."""
 import argparse
 import os
-import socket
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,21 +17,11 @@ if ROOT not in sys.path:
 
 
 def spawn(args):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(args.world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if args.same_device else r), WORLD_SIZE=str(args.world),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rcs = [p.wait() for p in procs]
-    if any(rcs):
-        print(f"multigpu_worker: rank exit codes {rcs}", file=sys.stderr)
-        return 1
-    print("MULTIGPU_OK")
-    return 0
+    from fastdm_amd.launch import spawn_self
+    rc = spawn_self(__file__, sys.argv[1:], args.world, timeout=float(os.environ.get("FDM_MULTIGPU_TIMEOUT", "900")), same_device=args.same_device)
+    if rc == 0:
+        print("MULTIGPU_OK")
+    return rc
 
 
 def main():
