@@ -115,8 +115,10 @@ def build(force: bool = False) -> str:
             res = subprocess.run(["bash", BUILD_SCRIPT], capture_output=True, text=True)
             if res.returncode != 0 or not os.path.exists(LIB_PATH):
                 raise NativeLibraryError(f"building libfastdm_amd.so failed:\n{res.stdout}\n{res.stderr}")
-            with open(stamp, "w") as f:
+            tmp = f"{stamp}.{os.getpid()}"
+            with open(tmp, "w") as f:
                 f.write(digest)
+            os.replace(tmp, stamp)           # atomic, like the library itself (build.sh links to a temporary name and renames)
     return LIB_PATH
 
 
@@ -193,12 +195,23 @@ _gemm_ws = {}
 
 
 def gemm_int8_workspace(device):
-    """Per-device scratch of fdm_gemm_w8a8_int8_x2_ws's split-K tail (64 MiB, allocated once).  One buffer per device is
-    enough for launches on ONE stream (the library's merge launch has consumed it before the next GEMM's parts write)."""
+    """Scratch of fdm_gemm_w8a8_int8_x2_ws's split-K tail (64 MiB), one buffer per (device, STREAM): the library's merge launch has
+    consumed it before the next GEMM's parts write only when both are on one stream, so launches on another stream get their own
+    buffer instead of silently sharing partial sums.  Allocate it before any HIP-graph capture (`warm_gemm_int8_workspace`): an
+    allocation inside a capture would land in the graph's private pool."""
     import torch
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev, int(torch.cuda.current_stream(dev).cuda_stream))
     ws = _gemm_ws.get(key)
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("fastdm_amd: the int8 split-K workspace of this stream must be allocated before graph capture "
+                               "(call fastdm_amd._native.warm_gemm_int8_workspace(device) on the capture stream first)")
         ws = torch.empty(int(lib().fdm_gemm_int8_workspace_bytes()), dtype=torch.uint8, device=device)
         _gemm_ws[key] = ws
     return ws
+
+
+def warm_gemm_int8_workspace(device):
+    """Allocate the int8 split-K workspace of the current stream eagerly (model load / warm-up path)."""
+    return gemm_int8_workspace(device)

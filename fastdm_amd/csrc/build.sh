@@ -16,5 +16,9 @@ for f in elementwise gemm attention capi; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libfastdm_amd.so" "$OUT"/elementwise.o "$OUT"/gemm.o "$OUT"/attention.o "$OUT"/capi.o
+# link under a temporary name and rename: a process that has the old library mapped (another rank, another job) keeps its inode
+# instead of seeing a truncated file
+TMP_SO="$OUT/.libfastdm_amd.so.$$"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$TMP_SO" "$OUT"/elementwise.o "$OUT"/gemm.o "$OUT"/attention.o "$OUT"/capi.o
+mv -f "$TMP_SO" "$OUT/libfastdm_amd.so"
 echo "built $OUT/libfastdm_amd.so"

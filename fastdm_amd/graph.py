@@ -22,7 +22,8 @@ class GraphedForward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        # capture on the SAME side stream the warm-up ran on: per-stream scratch (the int8 split-K workspace) then exists already
+        with torch.cuda.graph(self.graph, stream=side), torch.no_grad():
             self.static_out = fn(*self.static_in)
 
     def __call__(self, *inputs):

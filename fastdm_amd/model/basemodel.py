@@ -19,7 +19,8 @@ from fastdm_amd.layer.qlinear import QLinear
 
 def checkpoint_fingerprint(model_path) -> str:
     """Identity of a checkpoint WITHOUT reading its tensor bytes: sorted tensor names, shapes and dtypes, plus
-    * files / shard directories: every file's relative name, size and mtime (ns);
+    * files / shard directories: every weight file's base name and size, the safetensors header (names, shapes, dtypes, data offsets)
+      and the first / last 64 KiB of the file -- no mtime, no directory part, so a copied or re-mounted checkpoint keeps it;
     * in-memory state_dicts: the dict's own `fingerprint` attribute when it has one (the lazily generated synthetic
       checkpoints expose their seed that way), otherwise a hash of the first 64 KiB of every tensor.
     Stored in a pre-quantised cache file and compared on every later load that still names a checkpoint, so a cache written
@@ -45,20 +46,32 @@ def checkpoint_fingerprint(model_path) -> str:
                 h.update(flat.view(torch.uint8).numpy().tobytes())
         return h.hexdigest()
     from safetensors import safe_open
+    import json
+    import struct
+    model_path = os.path.normpath(model_path)          # 'ckpt/' and 'ckpt' are the same checkpoint
     files = []
     if os.path.isdir(model_path):
         for root, _, names in os.walk(model_path):
-            files += [os.path.join(root, n) for n in names if ".safetensors" in n]
+            files += [os.path.join(root, n) for n in names if n.endswith((".safetensors", ".bin"))]   # not *.safetensors.index.json
     else:
         files = [model_path]
-    for f in sorted(files):
-        st = os.stat(f)
-        add(os.path.relpath(f, os.path.dirname(model_path) or "."), st.st_size, st.st_mtime_ns)
-        if ".safetensors" in f:
-            with safe_open(f, framework="pt") as sf:
-                for k in sorted(sf.keys()):
-                    sl = sf.get_slice(k)
-                    add(k, tuple(sl.get_shape()), sl.get_dtype())
+    for f in sorted(files, key=os.path.basename):
+        # basename + size + (safetensors) the header itself -- tensor names, shapes, dtypes AND data offsets -- + the first and last
+        # 64 KiB of tensor bytes.  No mtime, no directory part: a copied / rsynced / re-mounted checkpoint keeps its fingerprint.
+        add(os.path.basename(f), os.path.getsize(f))
+        with open(f, "rb") as fh:
+            if f.endswith(".safetensors"):
+                n = struct.unpack("<Q", fh.read(8))[0]
+                header = fh.read(n)
+                h.update(hashlib.sha256(header).digest())
+                meta = json.loads(header)
+                for k in sorted(k for k in meta if k != "__metadata__"):
+                    add(k, tuple(meta[k]["shape"]), meta[k]["dtype"])
+            h.update(fh.read(65536))
+            size = os.path.getsize(f)
+            if size > 131072:
+                fh.seek(size - 65536)
+                h.update(fh.read(65536))
     return h.hexdigest()
 
 

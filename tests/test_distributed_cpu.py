@@ -225,3 +225,34 @@ def test_launcher_overall_timeout():
     t0 = time.time()
     rc = launch.supervise([_child("import time; time.sleep(600)")] * 2, [launch.rank_env(r, 2, port) for r in range(2)], timeout=1.5, grace=2.0)
     assert rc == 1 and time.time() - t0 < 30
+
+
+# ------------------------------------------------------------------ checkpoint fingerprint of FILES
+def test_checkpoint_fingerprint_survives_copy_and_ignores_index_json(tmp_path):
+    """The fingerprint that guards a pre-quantised cache must identify the checkpoint, not its location or file times: a copied /
+    rsynced / re-mounted checkpoint (other directory, other mtime, trailing slash) keeps it; other weights change it; the
+    *.safetensors.index.json of a sharded checkpoint is not opened as a weight file."""
+    import os
+    import shutil
+    import time
+    import torch
+    from safetensors.torch import save_file
+    from fastdm_amd.model.basemodel import checkpoint_fingerprint
+    a = tmp_path / "ckpt"
+    a.mkdir()
+    g = torch.Generator().manual_seed(0)
+    save_file({"w0": torch.randn(64, 32, generator=g).to(torch.bfloat16), "b0": torch.randn(64, generator=g)}, str(a / "model-00001-of-00002.safetensors"))
+    save_file({"w1": torch.randn(16, 8, generator=g).to(torch.bfloat16)}, str(a / "model-00002-of-00002.safetensors"))
+    (a / "model.safetensors.index.json").write_text('{"weight_map": {}}')
+    fp = checkpoint_fingerprint(str(a))
+    assert fp == checkpoint_fingerprint(str(a) + "/")
+    b = tmp_path / "elsewhere" / "copy_of_ckpt"
+    shutil.copytree(str(a), str(b))
+    future = time.time() + 1000
+    for f in os.listdir(b):
+        os.utime(b / f, (future, future))
+    assert checkpoint_fingerprint(str(b)) == fp
+    one = checkpoint_fingerprint(str(a / "model-00001-of-00002.safetensors"))
+    assert one != fp and one == checkpoint_fingerprint(str(b / "model-00001-of-00002.safetensors"))
+    save_file({"w1": torch.randn(16, 8, generator=g).to(torch.bfloat16)}, str(b / "model-00002-of-00002.safetensors"))   # other weights, same shapes
+    assert checkpoint_fingerprint(str(b)) != fp
