@@ -1077,7 +1077,7 @@ def gen_c3(n_double, n_single, quant_tags, img_h=64, img_w=128, n_txt=512, seed=
             hidden = x[:, n_txt:]
             hidden = core.norm_out.forward(hidden, temb)
             out = core.proj_out.forward(hidden)
-            if name is None:
+            if name is None or "depth" not in name:
                 d["out"] = out
             else:
                 d["out_sub"] = out[:, ::sub].clone()
@@ -1396,7 +1396,7 @@ def gen_radial_full():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3", "c3_traj", "c3_depth", "teacache_flux", "teacache_qwen", "radial_full", "c3_equal", "wan_ti2v"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c3", "c2", "c3_traj", "c3_depth", "teacache_flux", "teacache_qwen", "radial_full", "c3_equal", "wan_ti2v"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     ap.add_argument("--steps", type=int, default=4, help="c3_traj: denoise steps of the 25-step schedule")
@@ -1441,6 +1441,8 @@ def main():
         gen_sd3_full()
     if args.what == "c3":
         gen_c3(args.blocks[0], args.blocks[1], args.quant)
+    if args.what == "c2":        # BASELINE.json configs[1]: FLUX bf16 1024 x 1024 (S = 4096 + 512), full depth
+        gen_c3(19, 38, ["bf16"], img_h=64, img_w=64, name="flux_c2_{tag}_19x38.npz")
     if args.what == "c3_traj":
         for tag in args.quant:
             for att in args.attention:

@@ -402,7 +402,10 @@ ATT_SHAPES = [  # /root/reference/tests/test_attention.py:7-21  (B, Sq, Skv, H, 
 def test_attention_reference_shapes(K, B, Sq, Sk, H, hd):
     torch.manual_seed(0)
     g = gen(Sq + Sk + H)
-    q, k, v = rbf(g, B, Sq, H * hd), rbf(g, B, Sk, H * hd), rbf(g, B, Sk, H * hd)
+    # q ~ N(0, 16): logits ~ N(0, 16) make the softmax peaked, outputs are O(0.3) instead of the ~1/sqrt(Sk) of a near-uniform
+    # softmax over N(0, 1) logits -- at which the absolute tolerance below is as large as the signal and a kernel that dropped key
+    # blocks would pass.  The relative L2 bound is the discriminating assertion.
+    q, k, v = rbf(g, B, Sq, H * hd, scale=4.0), rbf(g, B, Sk, H * hd), rbf(g, B, Sk, H * hd)
     got = K.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5).cpu()
     assert torch.isfinite(got.float()).all()
     rows = sample_rows(Sq, 24)
@@ -413,6 +416,9 @@ def test_attention_reference_shapes(K, B, Sq, Sk, H, hd):
     sub = got[:, rows][:, :, hsel]
     torch.testing.assert_close(sub, ref, rtol=0.0, atol=1.8e-2)
     assert (sub.float() - ref.float()).abs().mean() < 1.5e-3
+    assert ref.float().abs().mean() > 0.1                                             # the signal is O(1): the tolerances above bite
+    rel = ((sub.float() - ref.float()).norm() / ref.float().norm()).item()
+    assert rel <= 1.0e-2, rel                                                         # bf16 P and bf16 output rounding
 
 
 @pytest.mark.parametrize("S", [8704, 8650])
@@ -453,7 +459,9 @@ def test_attention_reference_maximum_shape_wan_i2v(K):
     free, _ = torch.cuda.mem_get_info()
     if free < 40 * 2 ** 30:
         pytest.skip("needs ~35 GB of free HBM")
-    q, k, v = (fused.synth_fill(torch.empty((S, D), dtype=BF16, device="cuda"), seed, 0, 1.0 / 37837.0) for seed in (11, 12, 13))   # ~N(0,1)
+    # q ~ N(0, 16), k, v ~ N(0, 1): a peaked softmax with O(0.3) outputs (with N(0, 1) logits over 490 k keys the outputs are ~0.003,
+    # the size of the tolerance)
+    q, k, v = (fused.synth_fill(torch.empty((S, D), dtype=BF16, device="cuda"), seed, 0, sc / 37837.0) for seed, sc in ((11, 4.0), (12, 1.0), (13, 1.0)))
     rows = torch.tensor([0, 1, 127, 128, 255, 256, 70000, 244915, 489829 - 256, 489829 - 255, 489829])
     heads = [0, 17, 39]
 
@@ -472,13 +480,15 @@ def test_attention_reference_maximum_shape_wan_i2v(K):
     ref = fp32_ref(k, v)
     assert torch.isfinite(dense[::4096].float()).all()
     d = (sample(dense) - ref).abs()
-    assert d.max() <= 1.8e-2 and d.mean() <= 1e-3, ("dense", d.max().item(), d.mean().item())       # tests/test_attention.py atol
+    assert d.max() <= 1.8e-2 and d.mean() <= 1.5e-3, ("dense", d.max().item(), d.mean().item())
+    assert ref.abs().mean().item() > 0.05 and ((sample(dense) - ref).norm() / ref.norm()).item() <= 1.5e-2, ("dense", ref.abs().mean().item())
     mask = torch.ones((1, H, (S + 127) // 128, (S + 63) // 64), dtype=torch.int8, device="cuda")
     masked = torch.empty_like(dense)
     N.check(N.lib().fdm_attn_fwd(N.ptr(masked), N.ptr(q), N.ptr(k), N.ptr(v), 1, S, S, H, H, hd, D, D, D, D, hd ** -0.5, N.ptr(mask), 128, 64,
                                  None, 0, N.stream()), "masked attention")
     d = (sample(masked) - ref).abs()
-    assert d.max() <= 1.8e-2 and d.mean() <= 1e-3, ("masked", d.max().item(), d.mean().item())
+    assert d.max() <= 1.8e-2 and d.mean() <= 1.5e-3, ("masked", d.max().item(), d.mean().item())
+    assert ref.abs().mean().item() > 0.05 and ((sample(masked) - ref).norm() / ref.norm()).item() <= 1.5e-2, ("masked", ref.abs().mean().item())
     assert (masked[::997].float() - dense[::997].float()).abs().max() <= 2.0 ** -6
     del mask, masked
     # cross-attention to 512 text tokens

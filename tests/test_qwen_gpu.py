@@ -294,3 +294,87 @@ def test_batch_cfg_is_bit_identical_to_two_forwards():
             json.dump({"cache_algorithm": "fbcache", "enable_caching": True, "threshold": 0.2, "warmup_steps": 2}, f)
         with pytest.raises(ValueError, match="batch_cfg"):
             FastDMEngine("", architecture="qwen", use_int8=True, cache_config=cc, batch_cfg=True, **kw)
+
+
+# ------------------------------------------------------------------ TeaCache at the size BASELINE.json configs[3] is quoted on
+@pytest.mark.parametrize("tag", ["shipped", "scaled"])
+def test_qwen_teacache_at_size_decisions_match_reference(tag):
+    """Qwen-Image int8 at FULL width, 1328 x 1328 (6889 image + 128 text tokens), 2 blocks, the 25-step schedule with true CFG (two
+    forwards per step) through TeaCache with the shipped positive AND negative coefficients and the negative-prompt cache
+    (`oracle.make_golden teacache_qwen`: the reference's own TeaCache.apply_cache, xcaching.py:187-276).  Decisions identical,
+    rel-L1 within a bf16 ulp, keys alternate positive / negative."""
+    import os
+    from oracle.make_golden import GOLD
+    path = "teacache_at_size_qwen.npz"
+    if not os.path.exists(os.path.join(GOLD, path)):
+        pytest.skip(f"{path} not generated")
+    g = load(path)
+    from fastdm_amd.caching import AutoCache
+    from fastdm_amd.model_entry import create_model
+    from fastdm_amd.synthetic import SyntheticQwenStateDict, qwen_step_inputs
+    n_steps = int(g["meta_n_steps"])
+    state = {"step": 0}
+    cache = AutoCache.from_dict({"cache_algorithm": "teacache", "enable_caching": True, "threshold": float(g[f"{tag}_threshold"]),
+                                 "negtive_cache": True, "coefficients": g["coefficients"].tolist(),
+                                 "negtive_coefficients": g["negtive_coefficients"].tolist()})
+    cache.config.current_steps_callback = lambda: state["step"]
+    model = create_model("qwen", ckpt_path=SyntheticQwenStateDict(num_layers=2, seed=0), dtype=BF16, quant_type=torch.int8,
+                         kernel_backend="hip", cache=cache, num_layers=2).eval()
+    inp = qwen_step_inputs(1, 83, 83, 128, seed=0)
+    neg = qwen_step_inputs(1, 83, 83, 128, seed=1)["encoder_hidden_states"]
+    sig = g["sigmas"].numpy()
+    lat = inp["hidden_states"].clone()
+    for i in range(n_steps):
+        state["step"] = i
+        row = []
+        for enc in (inp["encoder_hidden_states"], neg):
+            row.append(model(hidden_states=lat, encoder_hidden_states=enc, encoder_hidden_states_mask=inp["encoder_hidden_states_mask"],
+                             timestep=torch.tensor([float(sig[i])], device="cuda"), img_shapes=inp["img_shapes"], txt_seq_lens=inp["txt_seq_lens"])[0])
+        comb = (row[1].float() + 4.0 * (row[0].float() - row[1].float()))[..., : lat.shape[-1]]
+        lat = (lat.float() + float(sig[i + 1] - sig[i]) * comb).to(BF16)
+    dec = [int(t[3]) for t in cache.trace]
+    rel = [0.0 if t[1] is None else float(t[1]) for t in cache.trace]
+    assert [t[4] for t in cache.trace] == ["positive", "negative"] * n_steps
+    ref_dec, ref_rel = g[f"{tag}_should_calc"].tolist(), g[f"{tag}_rel"].tolist()
+    lines = [f"forward {i:2d} decision {dec[i]} (ref {ref_dec[i]})  rel {rel[i]:.6f} (ref {ref_rel[i]:.6f})" for i in range(2 * n_steps)]
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/teacache_at_size_qwen_{tag}.txt", "w") as f:
+        f.write("\n".join(lines) + "\n")
+    assert dec == ref_dec, "\n".join(lines)
+    for i in range(2, 2 * n_steps):
+        assert abs(rel[i] - ref_rel[i]) <= 2.0 ** -7 * ref_rel[i] + 1e-6, lines[i]
+    d = (lat.float().cpu() - g[f"{tag}_final"].float()).abs()
+    assert torch.isfinite(lat.float()).all() and d.mean().item() < 0.08, (d.max().item(), d.mean().item())
+
+
+def test_qwen_image_full_depth_forward_at_1328():
+    """BASELINE.json configs[3] at its real size and depth: Qwen-Image int8, 1328 x 1328 (6889 image + 128 text tokens), all 60
+    double-stream blocks, synthetic weights.  No CPU oracle reaches 60 blocks in test time (the 4-block fixture pins the
+    arithmetic), so this holds the properties a full forward must have: finite, O(1) statistics in line with the 4-block fixture
+    (mean |out| 0.97), bit-identical when repeated, and the batch-2 (cond | uncond in one forward) path equal to two batch-1
+    forwards bit for bit (every quantisation is per token)."""
+    from fastdm_amd.model_entry import create_model
+    from fastdm_amd.synthetic import SyntheticQwenStateDict, qwen_step_inputs
+    model = create_model("qwen", ckpt_path=SyntheticQwenStateDict(seed=0), dtype=BF16, quant_type=torch.int8, kernel_backend="hip").eval()
+    assert len(model.core_model.transformer_blocks) == 60
+    inp = qwen_step_inputs(1, 83, 83, 128, seed=0)
+    neg = qwen_step_inputs(1, 83, 83, 128, seed=1)["encoder_hidden_states"]
+    t = torch.tensor([0.7], device="cuda")
+
+    def fwd(enc, lat=None, mask=None, shapes=None, lens=None, tt=None):
+        return model(hidden_states=inp["hidden_states"] if lat is None else lat, encoder_hidden_states=enc,
+                     encoder_hidden_states_mask=inp["encoder_hidden_states_mask"] if mask is None else mask, timestep=t if tt is None else tt,
+                     img_shapes=inp["img_shapes"] if shapes is None else shapes, txt_seq_lens=inp["txt_seq_lens"] if lens is None else lens)[0]
+
+    a = fwd(inp["encoder_hidden_states"])
+    b = fwd(inp["encoder_hidden_states"])
+    c = fwd(neg)
+    assert a.shape == (1, 6889, 64) and torch.isfinite(a.float()).all() and torch.isfinite(c.float()).all()
+    assert torch.equal(a, b)
+    m = a.float().abs().mean().item()
+    assert 0.3 < m < 3.0, m
+    assert (a.float() - c.float()).abs().mean().item() > 1e-3           # the prompt matters
+    both = fwd(torch.cat([inp["encoder_hidden_states"], neg], 0), lat=inp["hidden_states"].expand(2, -1, -1).contiguous(),
+               mask=inp["encoder_hidden_states_mask"].expand(2, -1).contiguous(), shapes=inp["img_shapes"] * 2, lens=inp["txt_seq_lens"] * 2,
+               tt=t.expand(2).contiguous())
+    assert torch.equal(both[0:1], a) and torch.equal(both[1:2], c)

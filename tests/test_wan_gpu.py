@@ -348,7 +348,8 @@ def test_radial_mask_and_sparse_attention_at_a14b_size():
     # (2) sparse attention at full size against the oracle's definition on sampled rows
     H, hd = 40, 128
     D = H * hd
-    q, k, v = (fused.synth_fill(torch.empty((S, D), dtype=BF16, device="cuda"), seed, 0, 1.0 / 37837.0) for seed in (21, 22, 23))   # ~N(0,1)
+    # q ~ N(0, 16): peaked softmax, O(0.3) outputs -- a kernel that dropped kept blocks or multiplied dropped ones would show
+    q, k, v = (fused.synth_fill(torch.empty((S, D), dtype=BF16, device="cuda"), seed, 0, sc / 37837.0) for seed, sc in ((21, 4.0), (22, 1.0), (23, 1.0)))
     mask = km[None, None].expand(1, H, -1, -1).contiguous()
     out = torch.empty_like(q)
     N.check(N.lib().fdm_attn_fwd(N.ptr(out), N.ptr(q), N.ptr(k), N.ptr(v), 1, S, S, H, H, hd, D, D, D, D, hd ** -0.5, N.ptr(mask), 128, 64,
@@ -356,7 +357,7 @@ def test_radial_mask_and_sparse_attention_at_a14b_size():
     assert torch.isfinite(out[::1024].float()).all()
     rows = torch.tensor([0, 1, 127, 128, 3839, 3840, 40320, 40321 + 128, S - 3841, S - 129, S - 1], device="cuda")
     key_keep = km[(rows // 128)].bool().repeat_interleave(64, dim=1)          # [rows, S]: keys of the kept 64-key blocks
-    worst_max, worst_mean = 0.0, 0.0
+    worst_max, worst_mean, worst_rel, sig_ = 0.0, 0.0, 0.0, 1.0
     for h in (0, 19, 39):
         sl = slice(h * hd, (h + 1) * hd)
         sc = (q[rows][:, sl].float() @ k[:, sl].float().t()) * hd ** -0.5
@@ -364,4 +365,63 @@ def test_radial_mask_and_sparse_attention_at_a14b_size():
         ref = torch.softmax(sc, dim=-1) @ v[:, sl].float()
         d = (out[rows][:, sl].float() - ref).abs()
         worst_max, worst_mean = max(worst_max, d.max().item()), max(worst_mean, d.mean().item())
-    assert worst_max <= 1.8e-2 and worst_mean <= 1e-3, (worst_max, worst_mean)
+        worst_rel = max(worst_rel, ((out[rows][:, sl].float() - ref).norm() / ref.norm()).item())
+        sig_ = min(sig_, ref.abs().mean().item())
+    assert worst_max <= 1.8e-2 and worst_mean <= 1.5e-3 and worst_rel <= 1.5e-2 and sig_ > 0.05, (worst_max, worst_mean, worst_rel, sig_)
+
+
+# ------------------------------------------------------------------ BASELINE.json configs[4]: ONE full forward at size and depth
+def test_wan_a14b_full_depth_forward_sparse_dense_and_all_ones_mask():
+    """Wan2.2-T2V-A14B fp8, 768 x 1280 x 81 frames (latents [1, 16, 21, 96, 160] -> 80 640 video tokens + 512 text tokens), all 40
+    blocks, synthetic weights: one forward on a SPARSE step of the shipped radial config (layers >= dense_layers run the
+    block-sparse kernel at density ~0.24), one dense forward, and one forward through the block-mask kernel with an all-ones mask
+    (what the reference's own sparse test feeds).  Properties at the size no CPU oracle reaches:
+      * all three finite, output statistics of a sane DiT forward (mean |out| within 3x of the 2-block fixture's 0.95);
+      * dense == all-ones mask to 2^-6 on the final latents (two kernels, same mathematics, 40 blocks of accumulated difference);
+      * the sparse forward differs from the dense one (the mask really drops 3/4 of the keys) but stays O(1)."""
+    import json
+    from fastdm_amd.model_entry import create_model
+    from fastdm_amd.sparse import SparseAttn
+    from fastdm_amd.synthetic import SyntheticWanStateDict, wan_step_inputs
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2 ** 30:
+        pytest.skip("needs ~50 GB of free HBM")
+    cfg_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "sparse", "radial_attn_wan.json")
+    sp_cfg = json.load(open(cfg_path))
+    sparse = SparseAttn.from_dict(sp_cfg)
+    step = {"i": int(sp_cfg.get("dense_steps", 11)) + 1}
+    sparse.config.current_steps_callback = lambda: step["i"]
+    model = create_model("wan", ckpt_path=SyntheticWanStateDict(seed=0), dtype=BF16, quant_type=FP8, kernel_backend="hip", sparse_attn=sparse).eval()
+    assert len(model.core_model.blocks) == 40
+    inp = wan_step_inputs(1, 21, 96, 160, 512, seed=0)
+    t = torch.tensor([700.0], device="cuda")
+
+    def fwd():
+        return model(hidden_states=inp["hidden_states"], timestep=t, encoder_hidden_states=inp["encoder_hidden_states"], return_dict=False)[0]
+
+    out_sparse = fwd()
+    step["i"] = 0                                   # a dense step of the same config
+    out_dense = fwd()
+    # all-ones mask through the block-mask kernel on every layer
+    ones_cfg = dict(sp_cfg, dense_layers=0, dense_steps=0)
+    ones = SparseAttn.from_dict(ones_cfg)
+    ones.config.current_steps_callback = lambda: 5
+    S = 21 * 48 * 80
+    ones.post_init(video_token_num=S, num_frame=21)
+    full_mask = torch.ones((S // 128, S // 64), dtype=torch.int8, device="cuda")
+    ones.kernel_mask = lambda *a, **k: full_mask
+    model.core_model.sparse_attn = ones
+    out_ones = fwd()
+    for name, o in (("sparse", out_sparse), ("dense", out_dense), ("all-ones", out_ones)):
+        assert o.shape == inp["hidden_states"].shape and torch.isfinite(o.float()).all(), name
+        m = o.float().abs().mean().item()
+        assert 0.3 < m < 3.0, (name, m)
+    d = (out_ones.float() - out_dense.float()).abs()
+    assert d.max().item() <= 2.0 ** -6 * max(1.0, out_dense.float().abs().max().item()) and d.mean().item() <= 2e-3, (d.max().item(), d.mean().item())
+    ds = (out_sparse.float() - out_dense.float()).abs().mean().item()
+    assert ds > 1e-3, ds
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/wan_a14b_full_forward.txt", "w") as f:
+        f.write(f"mean|out| sparse {out_sparse.float().abs().mean().item():.4f} dense {out_dense.float().abs().mean().item():.4f} "
+                f"all-ones {out_ones.float().abs().mean().item():.4f}; dense vs all-ones max {d.max().item():.5f} mean {d.mean().item():.6f}; "
+                f"sparse vs dense mean {ds:.5f}\n")
