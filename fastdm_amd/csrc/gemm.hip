@@ -44,6 +44,9 @@ constexpr int GEMM_THREADS = 512;
 constexpr int NSTAGE = 4;
 constexpr int STAGE_BYTES = (BM + BN) * BKB;  // 32 KiB
 constexpr int GROUP_M = 4;
+#ifndef FDM_GEMM_SPREAD_DMA
+#define FDM_GEMM_SPREAD_DMA 0
+#endif
 #ifndef FDM_GEMM_W4
 #define FDM_GEMM_W4 1
 #endif
@@ -440,6 +443,28 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
     auto step = [&](auto inner_c, Frag (&bc)[NS][2], Frag (&bn)[NS][2], int t) {
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+#if FDM_GEMM_SPREAD_DMA
+      // (experiment) one DMA behind each of the four MFMA groups instead of a burst of four behind the barrier
+      if constexpr (decltype(inner_c)::value) {
+        uint8_t* sA = smem + ((t + 3) & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024;
+        uint8_t* sB = sA + BM * BKB;
+        const uint8_t* ka = baseA + (int64_t)(t + 3) * BKB;
+        const uint8_t* kb = baseB + (int64_t)(t + 3) * BKB;
+        read_b(bn, t + 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = M::run(bc[s][j], fa[s][i], acc[i][j]);
+          read_a(t + 1, i);
+          if (i < 2) glds16(ka + oa[i], sA + i * 8192);
+          else glds16(kb + ob[i - 2], sB + (i - 2) * 8192);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+      }
+#endif
       if constexpr (decltype(inner_c)::value) stage_inner(t + 3);
       else stage(t + 3);
       read_b(bn, t + 1);
@@ -820,7 +845,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
   }
   const GemmProblem& p = grp.p[prob];
 #ifdef FDM_GEMM_STAMPS
-  unsigned long long* stamp = grp.stamps + (size_t)blockIdx.x * 4;
+  unsigned long long* stamp = grp.stamps + (size_t)blockIdx.x * 8;
   if (tid == 0) stamp[0] = __builtin_readcyclecounter();
 #endif
 
@@ -943,10 +968,17 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     };
     const int nk = (int)((Kb + 127) / 128);
     const int nk_full = (int)(Kb / 128);
-    stage_a(std::false_type{}, 0);
-    stage_b(std::false_type{}, 0);
-    stage_a(std::false_type{}, 1);
-    stage_b(std::false_type{}, 1);
+    if (nk_full >= 3) {      // stages 0..2 lie inside K: the select-free DMA form (the checked one costs ~6 VALU per DMA)
+      stage_a(std::true_type{}, 0);
+      stage_b(std::true_type{}, 0);
+      stage_a(std::true_type{}, 1);
+      stage_b(std::true_type{}, 1);
+    } else {
+      stage_a(std::false_type{}, 0);
+      stage_b(std::false_type{}, 0);
+      stage_a(std::false_type{}, 1);
+      stage_b(std::false_type{}, 1);
+    }
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // stage 0 (stage 1 lands while its B fragments are read)
     __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -954,7 +986,8 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     read_frag(fa[0], smem + a_row, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // stage 1 has landed (step 0 reads its B fragments); every wave holds B(0) in registers: its buffer takes B(2)
-    stage_b(std::false_type{}, 2);
+    if (nk_full >= 3) stage_b(std::true_type{}, 2);
+    else stage_b(std::false_type{}, 2);
 #ifdef FDM_GEMM_STAMPS
     if (tid == 0) stamp[1] = __builtin_readcyclecounter();
 #endif
@@ -1100,6 +1133,9 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: no block barrier needed
     __builtin_amdgcn_sched_barrier(0);
+#ifdef FDM_GEMM_STAMPS
+    if (tid == 0) stamp[4] = __builtin_readcyclecounter();
+#endif
     // pass 2: row-contiguous 16-byte pieces.  Instruction it (0..31): lane -> row 4 * it + lane / 16, chunk lane % 16.
     const int rsub = lane >> 4, ch = lane & 15;
     const int ncol = n0 + wn * 128 + ch * 8;
@@ -1205,6 +1241,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     else epilogue(std::integral_constant<int, FDM_EPI_NONE>{});
   }
 #ifdef FDM_GEMM_STAMPS
+  if (tid == 0) stamp[5] = __builtin_readcyclecounter();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (tid == 0) stamp[3] = __builtin_readcyclecounter();
 #endif

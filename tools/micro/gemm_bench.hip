@@ -101,8 +101,8 @@ int main(int argc, char** argv) {
     hipMemcpy(sb, s.data(), 12288 * 4, hipMemcpyHostToDevice);
   }
 #ifdef FDM_GEMM_STAMPS
-  hipMalloc(&fdm::g_gemm_stamps, 2048 * 4 * 8);
-  hipMemset(fdm::g_gemm_stamps, 0, 2048 * 4 * 8);
+  hipMalloc(&fdm::g_gemm_stamps, 2048 * 8 * 8);
+  hipMemset(fdm::g_gemm_stamps, 0, 2048 * 8 * 8);
 #endif
   const bool use_int8 = getenv("GEMM_DT") && !strcmp(getenv("GEMM_DT"), "int8");
   int32_t *azp, *azp_adj;
@@ -210,14 +210,21 @@ int main(int argc, char** argv) {
 #ifdef FDM_GEMM_STAMPS
     {
       hipDeviceSynchronize();
-      std::vector<unsigned long long> st(2048 * 4);
+      std::vector<unsigned long long> st(2048 * 8);
       hipMemcpy(st.data(), fdm::g_gemm_stamps, st.size() * 8, hipMemcpyDeviceToHost);
+#ifdef FDM_GEMM_AB
+      const int stride = fdm::g_gemm_use_w4 ? 8 : 4;
+#else
+      const int stride = 4;
+#endif
       for (int b : {0, 100, 255, 256, 700}) {
-        unsigned long long* q = &st[(size_t)b * 4];
+        unsigned long long* q = &st[(size_t)b * stride];
         if (q[3] == 0) continue;
-        printf("   block %4d: start +%llu  prologue %llu  main %llu  epilogue(+drain) %llu\n", b, q[0] - st[0], q[1] - q[0], q[2] - q[1], q[3] - q[2]);
+        printf("   block %4d: start +%llu  prologue %llu  main %llu  epilogue(+drain) %llu", b, q[0] - st[0], q[1] - q[0], q[2] - q[1], q[3] - q[2]);
+        if (stride == 8 && q[4]) printf("  [pass 1 %llu, store issue %llu, drain %llu]", q[4] - q[2], q[5] - q[4], q[3] - q[5]);
+        printf("\n");
       }
-      hipMemset(fdm::g_gemm_stamps, 0, st.size() * 8);
+      hipMemset(fdm::g_gemm_stamps, 0, 2048 * 8 * 8);
     }
 #endif
   }
