@@ -29,9 +29,11 @@ import torch  # noqa: E402
 PEAK_TFLOPS = {"fp8": 5000.0, "bf16": 2500.0, "int8": 5000.0}   # dense MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 IMAGE_STEPS = 25
 # timing-span name -> HIP kernel it launches (the name rocprofv3 reports; profiles/*_summary.txt)
-HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128, false>", "attn_sparse_bf16": "fdm::attn_fwd64_kernel<128, true>", "gemm_w8a8_fp8": "fdm::gemm_kernel<0, false>", "gemm_w8a8_fp8_res": "fdm::gemm_kernel<0, true>",
+HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128, false>", "attn_sparse_bf16": "fdm::attn_fwd64_kernel<128, true>",
+              # GEMM spans: the kernel the dispatch policy (gemm.hip use_w4) picks for the default workloads' launches of that span
+              "gemm_w8a8_fp8": "fdm::gemm_kernel<0, false>", "gemm_w8a8_fp8_res": "fdm::gemm_w4_kernel<0, true>",
               "gemm_w8a8_int8": "fdm::gemm_kernel<1, false>", "gemm_w8a8_int8_res": "fdm::gemm_kernel<1, true>",
-              "gemm_bf16": "fdm::gemm_kernel<2, false>", "gemm_bf16_res": "fdm::gemm_kernel<2, true>"}
+              "gemm_bf16": "fdm::gemm_w4_kernel<2, false>", "gemm_bf16_res": "fdm::gemm_w4_kernel<2, true>"}
 
 
 def pmc_traffic(kernel):
@@ -195,6 +197,8 @@ def main():
     ap.add_argument("--cache-threshold", type=float, default=None,
                     help="override the cache config's threshold (random synthetic weights move the TeaCache probe ~0.3 per step, far more than a "
                          "trained model: the shipped 0.2 never skips on them; reported in the workload string)")
+    ap.add_argument("--cache-negative", action="store_true", help="set the cache config's negtive_cache flag: separate cache entries for the "
+                    "conditional / unconditional forward of a true-CFG step (the shipped teacache_qwenimage.json has it off)")
     ap.add_argument("--batch-cfg", action="store_true", help="qwen: conditional + unconditional prompt as one batch-2 forward per step")
     ap.add_argument("--graph", action="store_true", help="sdxl: replay the UNet forward from a HIP graph (the step is launch-bound: ~2000 small kernels)")
     ap.add_argument("--nhwc", action="store_true", help="sdxl: keep convolution activations channels-last instead of NCHW")
@@ -237,6 +241,8 @@ def main():
     cache = AutoCache.from_json(args.cache_config) if args.cache_config else None
     if cache is not None and args.cache_threshold is not None:
         cache.config.threshold = args.cache_threshold
+    if cache is not None and args.cache_negative:
+        cache.config.negtive_cache = True
     if args.model == "flux":
         model = create_model("flux", ckpt_path=SyntheticFluxStateDict(seed=0), dtype=torch.bfloat16, quant_type=quant,
                              kernel_backend="hip", cache=cache).eval()
@@ -428,7 +434,7 @@ def main():
         nfw = 2 * args.steps
         workload = (f"Qwen-Image {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step schedule, true CFG "
                     f"({'one batch-2 forward' if args.batch_cfg else '2 forwards'} per step), batch 1 per GPU, 60 double-stream blocks"
-                    + (f", TeaCache (threshold {cache.config.threshold}{' [OVERRIDDEN]' if args.cache_threshold is not None else ''}; {skipped}/{nfw} forwards skipped)" if cache else ""))
+                    + (f", TeaCache (threshold {cache.config.threshold}{' [OVERRIDDEN]' if args.cache_threshold is not None else ''}{', negative cache' if args.cache_negative else ''}; {skipped}/{nfw} forwards skipped)" if cache else ""))
     out = {
         # value counts denoise steps of ALL images in flight (n_images = n_gpus, or n_gpus / 2 with --cfg-pair)
         "metric": {"flux": f"denoise it/s (sec/image = 25 / (value / {n_images})), FLUX 1024x2048 fp8 @25 steps",
