@@ -1,2 +1,2 @@
 cd tools/micro
-(GEMM_DATA=gauss ./gemm_bench_ab | grep -E "old vs|TOTAL"; GEMM_DATA=gauss ./gemm_bench_abst n 2>&1 | grep -v "vs exact" | grep -v "old vs" | grep -A1 -E "dbl qkv|TOTAL")
+(echo "== persistent"; GEMM_DATA=gauss ./gemm_bench_ab | grep -E "old vs|us |TOTAL"; echo "== one tile per block"; FDM_GEMM_W4_PERSIST=0 GEMM_DATA=gauss ./gemm_bench_ab n | grep -E "us |TOTAL"; echo "== old"; GEMM_OLD=1 GEMM_DATA=gauss ./gemm_bench_ab n | grep -E "us |TOTAL") 2>&1 | grep -v "vs exact"
