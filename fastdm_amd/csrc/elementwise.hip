@@ -171,6 +171,61 @@ __global__ void __launch_bounds__(256) rope_kernel(bf16_t* __restrict__ q, bf16_
   }
 }
 
+// ------------------------------------------------------------------------------------ division by a row-uniform scale
+// The quantising kernels are VALU-bound, not HBM-bound (a wave64 fp32 instruction occupies a SIMD for 4 clocks; 11 instructions per
+// IEEE division x 48 elements per lane was 40 % of ln_modulate's instruction stream).  hipcc expands a / b into
+//   b' = div_scale(b), a' = div_scale(a); y0 = rcp(b'); e = fma(-b', y0, 1); y = fma(e, y0, y0);
+//   q0 = a' * y; r0 = fma(-b', q0, a'); q1 = fma(r0, y, q0); r1 = fma(-b', q1, a'); q = div_fmas(r1, y, q1); div_fixup(q, b, a)
+// The reciprocal chain depends only on b, and div_scale / div_fmas / div_fixup are identities unless an operand or the quotient is
+// zero, denormal, infinite, NaN or within 2^-103 of underflow.  RowDiv hoists y once per row and runs the SAME five-instruction
+// residual chain per element, so the quotient is bit-identical to `a / b` whenever |a / b| >= 2^-43; below that (and for a = +-0)
+// both paths round to a zero byte, and the sign of the quotient is copied from a (b > 0).  Rows whose scale lies outside
+// [2^-60, 2^60] (or is NaN) take the compiler's division: `ok` is wave-uniform.
+struct RowDiv {
+  float b, y;
+  bool ok;
+  __device__ __forceinline__ explicit RowDiv(float scale) : b(scale) {
+#ifdef FDM_ROWDIV_OFF
+    ok = false;   // A/B builds (tools/micro/ew_bench.hip): the compiler's division everywhere
+#else
+    ok = scale >= 0x1p-60f && scale <= 0x1p60f;
+#endif
+    const float y0 = __builtin_amdgcn_rcpf(scale);
+    const float e = __builtin_fmaf(-scale, y0, 1.0f);
+    y = __builtin_fmaf(e, y0, y0);
+  }
+  __device__ __forceinline__ float fast(float a) const {
+    const float q0 = a * y;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_copysignf(__builtin_fmaf(r1, y, q1), a);
+  }
+};
+
+// eight cached values -> eight quantised bytes (FAST: RowDiv::fast, else the compiler's division)
+template <int MODE, bool SW, bool FAST>
+__device__ __forceinline__ i32x2 quant8(const Vec8& t, const RowDiv& dv, float zpf) {
+  uint32_t w[2] = {0, 0};
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const float qa = FAST ? dv.fast(t.v[j]) : t.v[j] / dv.b, qb = FAST ? dv.fast(t.v[j + 1]) : t.v[j + 1] / dv.b;
+    uint32_t two;
+    if constexpr (MODE == 1) {
+      two = cvt2_e4m3<SW>(clamp448(qa), clamp448(qb));
+    } else {
+      float ra = __builtin_rintf(qa + zpf), rb = __builtin_rintf(qb + zpf);
+      int ia = (int)fmaxf(-128.f, fminf(ra, 127.f)), ib = (int)fmaxf(-128.f, fminf(rb, 127.f));
+      two = ((uint32_t)ia & 0xffu) | (((uint32_t)ib & 0xffu) << 8);
+    }
+    w[j >> 2] |= two << (8 * (j & 3));
+  }
+  i32x2 o;
+  o[0] = (int)w[0];
+  o[1] = (int)w[1];
+  return o;
+}
+
 // ------------------------------------------------------------------------------------ row quant
 // Shared body: given this thread's cached row slice x[], emit fp8 / int8 bytes + per-row params.
 // MODE 1: fp8 (torch/quantize.py:58-67)   MODE 2: int8 asymmetric (:36-41)   MODE 3: int8 symmetric (:31-35)
@@ -206,33 +261,18 @@ __device__ __forceinline__ void quant_row_cached(const Vec8 (&x)[MAXV], int nvec
     scale_out[row] = scale;
     if constexpr (MODE == 2) azp_out[row] = (int32_t)zpf;
   }
+  const RowDiv dv(scale);
+  if (dv.ok) {
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    int v = (int)(threadIdx.x % THREADS) + i * THREADS;
-    if (v < nvec) {
-      uint32_t w[2];
+    for (int i = 0; i < MAXV; ++i) {
+      int v = (int)(threadIdx.x % THREADS) + i * THREADS;
+      if (v < nvec) *reinterpret_cast<i32x2*>(qdst + (size_t)v * 8) = quant8<MODE, SW, true>(x[i], dv, zpf);
+    }
+  } else {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j += 2) {
-          float a = x[i].v[h * 4 + j], b = x[i].v[h * 4 + j + 1];
-          uint32_t two;
-          if constexpr (MODE == 1) {
-            two = cvt2_e4m3<SW>(clamp448(a / scale), clamp448(b / scale));
-          } else {
-            float ra = __builtin_rintf(a / scale + zpf), rb = __builtin_rintf(b / scale + zpf);
-            int ia = (int)fmaxf(-128.f, fminf(ra, 127.f)), ib = (int)fmaxf(-128.f, fminf(rb, 127.f));
-            two = ((uint32_t)ia & 0xffu) | (((uint32_t)ib & 0xffu) << 8);
-          }
-          acc |= two << (8 * j);
-        }
-        w[h] = acc;
-      }
-      i32x2 o;
-      o[0] = (int)w[0];
-      o[1] = (int)w[1];
-      *reinterpret_cast<i32x2*>(qdst + (size_t)v * 8) = o;
+    for (int i = 0; i < MAXV; ++i) {
+      int v = (int)(threadIdx.x % THREADS) + i * THREADS;
+      if (v < nvec) *reinterpret_cast<i32x2*>(qdst + (size_t)v * 8) = quant8<MODE, SW, false>(x[i], dv, zpf);
     }
   }
 }
@@ -291,25 +331,13 @@ __global__ void __launch_bounds__(256) quant_rowwise_wide_kernel(uint8_t* __rest
     if constexpr (MODE == 2) azp[row] = (int32_t)zpf;
   }
   uint8_t* dst = q + row * (int64_t)hidden;
-  for (int v = threadIdx.x; v < nvec; v += 256) {
-    Vec8 t = load8(src + (size_t)v * 8);
-    uint32_t w[2] = {0, 0};
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      uint32_t two;
-      if constexpr (MODE == 1) {
-        two = cvt2_e4m3<SW>(clamp448(t.v[j] / sc), clamp448(t.v[j + 1] / sc));
-      } else {
-        float ra = __builtin_rintf(t.v[j] / sc + zpf), rb = __builtin_rintf(t.v[j + 1] / sc + zpf);
-        int ia = (int)fmaxf(-128.f, fminf(ra, 127.f)), ib = (int)fmaxf(-128.f, fminf(rb, 127.f));
-        two = ((uint32_t)ia & 0xffu) | (((uint32_t)ib & 0xffu) << 8);
-      }
-      w[j >> 2] |= two << (8 * (j & 3));
-    }
-    i32x2 o;
-    o[0] = (int)w[0];
-    o[1] = (int)w[1];
-    *reinterpret_cast<i32x2*>(dst + (size_t)v * 8) = o;
+  const RowDiv dv(sc);
+  if (dv.ok) {
+    for (int v = threadIdx.x; v < nvec; v += 256)
+      *reinterpret_cast<i32x2*>(dst + (size_t)v * 8) = quant8<MODE, SW, true>(load8(src + (size_t)v * 8), dv, zpf);
+  } else {
+    for (int v = threadIdx.x; v < nvec; v += 256)
+      *reinterpret_cast<i32x2*>(dst + (size_t)v * 8) = quant8<MODE, SW, false>(load8(src + (size_t)v * 8), dv, zpf);
   }
 }
 

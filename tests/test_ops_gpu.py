@@ -210,6 +210,43 @@ def test_quant_fp8_adversarial_rows_on_rounding_boundaries(K):
     assert torch.equal(q.cpu().view(torch.uint8), rq.view(torch.uint8))
 
 
+def test_quant_every_bf16_value_against_every_kind_of_scale(K):
+    """The quantisers divide by the row's scale with the reciprocal hoisted out of the row (`RowDiv`, elementwise.hip): the same
+    residual chain hipcc emits for `a / b`, minus its per-element rcp / div_scale / div_fixup.  Exhaustive check of the claim
+    that this is bit-identical: EVERY finite bf16 value (both signs, zeros, denormals) is divided by scales set through the row
+    maximum -- powers of two, all-ones mantissas, tiny and huge maxima (the latter two take the slow path) -- for fp8, int8
+    symmetric and int8 asymmetric, against the reference arithmetic (torch division on the CPU)."""
+    bits = torch.arange(65536, dtype=torch.int32)
+    allv = bits.to(torch.int16).view(BF16)
+    finite = allv[torch.isfinite(allv.float())]
+    g = gen(99)
+    maxima = [1.0, 448.0, 127.0, 3.0, 0.3333, 1.9921875, 255.0, 6.1e4, 1e-3, 2.0 ** -40, 2.0 ** 40, 1e-30, 1e30, 3.3895e38, 1e-38]
+    maxima += [float(v) for v in (torch.rand(17, generator=g) * 8 + 0.05)]
+    width = 8192
+    rows = []
+    for mx in maxima:
+        m = torch.tensor(mx).to(BF16)
+        keep = finite[finite.float().abs() <= m.float()]
+        for i in range(0, keep.numel(), width - 2):
+            r = torch.zeros(width, dtype=BF16)
+            part = keep[i:i + width - 2]
+            r[:part.numel()] = part
+            r[width - 2] = m
+            r[width - 1] = -m if len(rows) % 2 else m
+            rows.append(r)
+    x = torch.stack(rows)
+    q, s = K.quantize_to_fp8(x.cuda())
+    rq, rs = O.quantize_to_fp8(x)
+    assert torch.equal(s.cpu(), rs)
+    assert torch.equal(q.cpu().view(torch.uint8), rq.view(torch.uint8))
+    for sym in (True, False):
+        q, s, zp = K.quantize_to_int8(x.cuda(), symmetric=sym)
+        rq, rs, rzp = O.quantize_to_int8(x, symmetric=sym)
+        assert torch.equal(s.cpu(), rs) and torch.equal(q.cpu(), rq)
+        if not sym:
+            assert torch.equal(zp.cpu(), rzp)
+
+
 def test_quant_strided_input(K):
     g = gen(77)
     big = rbf(g, 100, 9216)
