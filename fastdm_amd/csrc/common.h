@@ -47,8 +47,7 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 struct Vec8 {
   float v[8];
 };
-__device__ __forceinline__ Vec8 load8(const bf16_t* p) {
-  i32x4 r = *reinterpret_cast<const i32x4*>(p);
+__device__ __forceinline__ Vec8 unpack8(const i32x4 r) {
   Vec8 o;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -58,6 +57,7 @@ __device__ __forceinline__ Vec8 load8(const bf16_t* p) {
   }
   return o;
 }
+__device__ __forceinline__ Vec8 load8(const bf16_t* p) { return unpack8(*reinterpret_cast<const i32x4*>(p)); }
 __device__ __forceinline__ void store8(bf16_t* p, const Vec8& x) {
   i32x4 r;
 #pragma unroll

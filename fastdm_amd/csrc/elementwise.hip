@@ -12,13 +12,29 @@ bool g_fp8_sw_cvt = false;
 
 constexpr int MAXV = 8;  // 16-byte vectors held per thread
 
+// Row loops come in two shapes.  NIT = 0: any width, MAXV guarded iterations (`v < nvec` around every load: hipcc keeps each load in
+// its own exec-masked block, reuses one register quad and waits for every load before it issues the next -- one 1 KB request in
+// flight per wave, a third of what the HBM latency x bandwidth product needs at full occupancy).  NIT = ceil(nvec / THREADS) known
+// at compile time: NIT unguarded loads issued back to back (the last one clamps its vector index into the row, so it is always a
+// legal address), and only the last iteration's arithmetic / stores are predicated.  The host picks NIT; NIT = 0 stays as the
+// fallback for the software-fp8 debug path.
+template <int NIT>
+struct RowIt {
+  static constexpr int N = NIT ? NIT : MAXV;
+  // may iteration i of this thread touch vector v?
+  static __device__ __forceinline__ bool live(int i, int v, int nvec) { return (NIT && i < NIT - 1) || v < nvec; }
+  // vector index to LOAD for iteration i (always inside the row when NIT != 0)
+  static __device__ __forceinline__ int ld(int i, int v, int nvec) { return (NIT && i == NIT - 1) ? min(v, nvec - 1) : v; }
+};
+
 // Load this thread's slice of a row: vectors t, t+THREADS, ...  (nvec = hidden/8)
-template <int THREADS>
+template <int THREADS, int NIT = 0>
 __device__ __forceinline__ void load_row(Vec8 (&x)[MAXV], const bf16_t* row, int nvec) {
+  using It = RowIt<NIT>;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < It::N; ++i) {
     int v = threadIdx.x % THREADS + i * THREADS;
-    if (v < nvec) x[i] = load8(row + (size_t)v * 8);
+    if (NIT || v < nvec) x[i] = load8(row + (size_t)It::ld(i, v, nvec) * 8);
   }
 }
 
@@ -212,7 +228,10 @@ __device__ __forceinline__ i32x2 quant8(const Vec8& t, const RowDiv& dv, float z
     const float qa = FAST ? dv.fast(t.v[j]) : t.v[j] / dv.b, qb = FAST ? dv.fast(t.v[j + 1]) : t.v[j + 1] / dv.b;
     uint32_t two;
     if constexpr (MODE == 1) {
-      two = cvt2_e4m3<SW>(clamp448(qa), clamp448(qb));
+      // FAST rows have a finite scale = RN(amax / 448) and |a| <= amax, so |a / scale| <= 448 (1 + 2^-23): the hardware conversion
+      // rounds that to 448 by itself (e4m3 overflows from 464 up) and the reference's clamp is the identity
+      if constexpr (FAST && !SW) two = cvt2_e4m3<SW>(qa, qb);
+      else two = cvt2_e4m3<SW>(clamp448(qa), clamp448(qb));
     } else {
       float ra = __builtin_rintf(qa + zpf), rb = __builtin_rintf(qb + zpf);
       int ia = (int)fmaxf(-128.f, fminf(ra, 127.f)), ib = (int)fmaxf(-128.f, fminf(rb, 127.f));
@@ -229,13 +248,14 @@ __device__ __forceinline__ i32x2 quant8(const Vec8& t, const RowDiv& dv, float z
 // ------------------------------------------------------------------------------------ row quant
 // Shared body: given this thread's cached row slice x[], emit fp8 / int8 bytes + per-row params.
 // MODE 1: fp8 (torch/quantize.py:58-67)   MODE 2: int8 asymmetric (:36-41)   MODE 3: int8 symmetric (:31-35)
-template <int THREADS, int MODE, bool SW>
+template <int THREADS, int MODE, bool SW, int NIT = 0>
 __device__ __forceinline__ void quant_row_cached(const Vec8 (&x)[MAXV], int nvec, uint8_t* qdst, float* scale_out,
                                                  int32_t* azp_out, int64_t row, float* smem) {
+  using It = RowIt<NIT>;
   float amax = 0.f, mn = 3.0e38f, mx = -3.0e38f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
-    if ((int)(threadIdx.x % THREADS) + i * THREADS < nvec) {
+  for (int i = 0; i < It::N; ++i)
+    if (It::live(i, (int)(threadIdx.x % THREADS) + i * THREADS, nvec)) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         amax = fmaxf(amax, fabsf(x[i].v[j]));
@@ -264,35 +284,41 @@ __device__ __forceinline__ void quant_row_cached(const Vec8 (&x)[MAXV], int nvec
   const RowDiv dv(scale);
   if (dv.ok) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < It::N; ++i) {
       int v = (int)(threadIdx.x % THREADS) + i * THREADS;
-      if (v < nvec) *reinterpret_cast<i32x2*>(qdst + (size_t)v * 8) = quant8<MODE, SW, true>(x[i], dv, zpf);
+      if (It::live(i, v, nvec)) *reinterpret_cast<i32x2*>(qdst + (size_t)v * 8) = quant8<MODE, SW, true>(x[i], dv, zpf);
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < It::N; ++i) {
       int v = (int)(threadIdx.x % THREADS) + i * THREADS;
-      if (v < nvec) *reinterpret_cast<i32x2*>(qdst + (size_t)v * 8) = quant8<MODE, SW, false>(x[i], dv, zpf);
+      if (It::live(i, v, nvec)) *reinterpret_cast<i32x2*>(qdst + (size_t)v * 8) = quant8<MODE, SW, false>(x[i], dv, zpf);
     }
   }
 }
 
 // Virtual concatenation of two sources so proj_out's K=15360 row never exists in bf16.
-template <int THREADS, int MODE, bool SW>
+template <int THREADS, int MODE, bool SW, int NIT = 0>
 __global__ void __launch_bounds__(THREADS) quant_rowwise_kernel(uint8_t* __restrict__ q, float* __restrict__ scale,
                                                                 int32_t* __restrict__ azp,
                                                                 const bf16_t* __restrict__ s0, int w0, int64_t st0,
                                                                 const bf16_t* __restrict__ s1, int w1, int64_t st1) {
+  using It = RowIt<NIT>;
   __shared__ float smem[THREADS / 64 + 1];
   const int64_t row = blockIdx.x;
   const int nv0 = w0 >> 3, nvec = (w0 + w1) >> 3;
   Vec8 x[MAXV];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < It::N; ++i) {
     int v = threadIdx.x + i * THREADS;
-    if (v < nvec) x[i] = (v < nv0) ? load8(s0 + row * st0 + (size_t)v * 8) : load8(s1 + row * st1 + (size_t)(v - nv0) * 8);
+    if (NIT || v < nvec) {
+      v = It::ld(i, v, nvec);
+      // one address, one load: a select between two loads would issue both
+      const bf16_t* src = (v < nv0) ? s0 + row * st0 + (size_t)v * 8 : s1 + row * st1 + (size_t)(v - nv0) * 8;
+      x[i] = load8(src);
+    }
   }
-  quant_row_cached<THREADS, MODE, SW>(x, nvec, q + row * (int64_t)(w0 + w1), scale, azp, row, smem);
+  quant_row_cached<THREADS, MODE, SW, NIT>(x, nvec, q + row * (int64_t)(w0 + w1), scale, azp, row, smem);
 }
 
 // Fallback for very wide rows (> MAXV*256*8 = 16384 elements): two passes, second read from L2.
@@ -343,41 +369,70 @@ __global__ void __launch_bounds__(256) quant_rowwise_wide_kernel(uint8_t* __rest
 
 // ------------------------------------------------------------------------------------ AdaLN modulate (+residual, +quant)
 // y = bf16(bf16(LN(x) * bf16(1+scale)) + shift); optional x := bf16(res + bf16(gate*x)) first.
-template <int THREADS, int QMODE, bool SW>
+template <int THREADS, int QMODE, bool SW, int NIT = 0>
 __global__ void __launch_bounds__(THREADS) ln_modulate_kernel(
     bf16_t* __restrict__ out_bf16, uint8_t* __restrict__ out_q, float* __restrict__ out_scale,
     int32_t* __restrict__ out_azp, const bf16_t* __restrict__ xin, const bf16_t* __restrict__ scale,
     const bf16_t* __restrict__ shift, int64_t mod_bstride, const bf16_t* __restrict__ res,
     const bf16_t* __restrict__ gate, bf16_t* __restrict__ x_out, int hidden, int64_t rows_per_batch, float eps) {
+  using It = RowIt<NIT>;
   __shared__ float smem[THREADS / 64 + 1];
   const int64_t row = blockIdx.x;
   const int64_t b = row / rows_per_batch;
   const int nvec = hidden >> 3;
   Vec8 x[MAXV];
-  load_row<THREADS>(x, xin + row * hidden, nvec);
-  if (res != nullptr) {
+  load_row<THREADS, NIT>(x, xin + row * hidden, nvec);
+  // the modulation vectors do not depend on the row statistics: request them now (16 B raw per lane and iteration), so they
+  // travel under the two reductions instead of one L2 round trip per iteration after them
+  i32x4 scr[MAXV], shr[MAXV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      int v = threadIdx.x + i * THREADS;
-      if (v < nvec) {
-        Vec8 r = load8(res + row * hidden + (size_t)v * 8), g = load8(gate + b * mod_bstride + (size_t)v * 8);
+  for (int i = 0; i < It::N; ++i) {
+    const int v = threadIdx.x + i * THREADS;
+    if (NIT || v < nvec) {
+      const size_t off = b * mod_bstride + (size_t)It::ld(i, v, nvec) * 8;
+      scr[i] = *reinterpret_cast<const i32x4*>(scale + off);
+      shr[i] = *reinterpret_cast<const i32x4*>(shift + off);
+    }
+  }
+  if (res != nullptr) {
+    i32x4 rr[MAXV], gr[MAXV];
+#pragma unroll
+    for (int i = 0; i < It::N; ++i) {
+      const int v = threadIdx.x + i * THREADS;
+      if (NIT || v < nvec) {
+        const int vl = It::ld(i, v, nvec);
+        rr[i] = *reinterpret_cast<const i32x4*>(res + row * hidden + (size_t)vl * 8);
+        gr[i] = *reinterpret_cast<const i32x4*>(gate + b * mod_bstride + (size_t)vl * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < It::N; ++i) {
+      const int v = threadIdx.x + i * THREADS;
+      if (NIT || v < nvec) {
+        const Vec8 r = unpack8(rr[i]), g = unpack8(gr[i]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[i].v[j] = rbf(r.v[j] + rbf(g.v[j] * x[i].v[j]));
-        if (x_out != nullptr) store8(x_out + row * hidden + (size_t)v * 8, x[i]);
+      }
+    }
+    if (x_out != nullptr) {
+#pragma unroll
+      for (int i = 0; i < It::N; ++i) {
+        const int v = threadIdx.x + i * THREADS;
+        if (It::live(i, v, nvec)) store8(x_out + row * hidden + (size_t)v * 8, x[i]);
       }
     }
   }
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
-    if ((int)threadIdx.x + i * THREADS < nvec)
+  for (int i = 0; i < It::N; ++i)
+    if (It::live(i, (int)threadIdx.x + i * THREADS, nvec))
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += x[i].v[j];
   const float mean = block_reduce<THREADS>(s, OpSum(), smem) / (float)hidden;
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
-    if ((int)threadIdx.x + i * THREADS < nvec)
+  for (int i = 0; i < It::N; ++i)
+    if (It::live(i, (int)threadIdx.x + i * THREADS, nvec))
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float d = x[i].v[j] - mean;
@@ -386,46 +441,53 @@ __global__ void __launch_bounds__(THREADS) ln_modulate_kernel(
   const float var = block_reduce<THREADS>(ss, OpSum(), smem) / (float)hidden;
   const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    int v = threadIdx.x + i * THREADS;
-    if (v < nvec) {
-      Vec8 sc = load8(scale + b * mod_bstride + (size_t)v * 8), sh = load8(shift + b * mod_bstride + (size_t)v * 8);
+  for (int i = 0; i < It::N; ++i) {
+    const int v = threadIdx.x + i * THREADS;
+    if (NIT || v < nvec) {
+      const Vec8 sc = unpack8(scr[i]), sh = unpack8(shr[i]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float n = rbf((x[i].v[j] - mean) * rstd);
         x[i].v[j] = rbf(rbf(n * rbf(1.0f + sc.v[j])) + sh.v[j]);
       }
-      if (out_bf16 != nullptr) store8(out_bf16 + row * hidden + (size_t)v * 8, x[i]);
+    }
+  }
+  if (out_bf16 != nullptr) {
+#pragma unroll
+    for (int i = 0; i < It::N; ++i) {
+      const int v = threadIdx.x + i * THREADS;
+      if (It::live(i, v, nvec)) store8(out_bf16 + row * hidden + (size_t)v * 8, x[i]);
     }
   }
   if constexpr (QMODE != 0) {
-    quant_row_cached<THREADS, QMODE, SW>(x, nvec, out_q + row * (int64_t)hidden, out_scale, out_azp, row, smem);
+    quant_row_cached<THREADS, QMODE, SW, NIT>(x, nvec, out_q + row * (int64_t)hidden, out_scale, out_azp, row, smem);
   }
 }
 
 // fp32 modulation (Wan): y = bf16(((x - mean) * rstd) * (1 + scale_f32) + shift_f32), one rounding.
-template <int THREADS, int QMODE, bool SW>
+template <int THREADS, int QMODE, bool SW, int NIT = 0>
 __global__ void __launch_bounds__(THREADS) ln_modulate_f32_kernel(
     bf16_t* __restrict__ out_bf16, uint8_t* __restrict__ out_q, float* __restrict__ out_scale, int32_t* __restrict__ out_azp,
     const bf16_t* __restrict__ xin, const float* __restrict__ scale, const float* __restrict__ shift, int64_t mod_bstride,
     int hidden, int64_t rows_per_batch, float eps) {
+  using It = RowIt<NIT>;
   __shared__ float smem[THREADS / 64 + 1];
   const int64_t row = blockIdx.x;
   const int64_t b = row / rows_per_batch;
   const int nvec = hidden >> 3;
   Vec8 x[MAXV];
-  load_row<THREADS>(x, xin + row * hidden, nvec);
+  load_row<THREADS, NIT>(x, xin + row * hidden, nvec);
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
-    if ((int)threadIdx.x + i * THREADS < nvec)
+  for (int i = 0; i < It::N; ++i)
+    if (It::live(i, (int)threadIdx.x + i * THREADS, nvec))
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += x[i].v[j];
   const float mean = block_reduce<THREADS>(s, OpSum(), smem) / (float)hidden;
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
-    if ((int)threadIdx.x + i * THREADS < nvec)
+  for (int i = 0; i < It::N; ++i)
+    if (It::live(i, (int)threadIdx.x + i * THREADS, nvec))
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float d = x[i].v[j] - mean;
@@ -434,11 +496,12 @@ __global__ void __launch_bounds__(THREADS) ln_modulate_f32_kernel(
   const float var = block_reduce<THREADS>(ss, OpSum(), smem) / (float)hidden;
   const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < It::N; ++i) {
     int v = threadIdx.x + i * THREADS;
-    if (v < nvec) {
-      const float* sc = scale + b * mod_bstride + (size_t)v * 8;
-      const float* sh = shift + b * mod_bstride + (size_t)v * 8;
+    if (NIT || v < nvec) {
+      const int vl = It::ld(i, v, nvec);
+      const float* sc = scale + b * mod_bstride + (size_t)vl * 8;
+      const float* sh = shift + b * mod_bstride + (size_t)vl * 8;
       const f32x4 sc0 = *reinterpret_cast<const f32x4*>(sc), sc1 = *reinterpret_cast<const f32x4*>(sc + 4);
       const f32x4 sh0 = *reinterpret_cast<const f32x4*>(sh), sh1 = *reinterpret_cast<const f32x4*>(sh + 4);
 #pragma unroll
@@ -447,11 +510,17 @@ __global__ void __launch_bounds__(THREADS) ln_modulate_f32_kernel(
         const float scj = j < 4 ? sc0[j & 3] : sc1[j & 3], shj = j < 4 ? sh0[j & 3] : sh1[j & 3];
         x[i].v[j] = rbf(n * (1.0f + scj) + shj);
       }
-      if (out_bf16 != nullptr) store8(out_bf16 + row * hidden + (size_t)v * 8, x[i]);
+    }
+  }
+  if (out_bf16 != nullptr) {   // stores after the arithmetic: a branch per iteration would pin every modulation load behind it
+#pragma unroll
+    for (int i = 0; i < It::N; ++i) {
+      const int v = threadIdx.x + i * THREADS;
+      if (It::live(i, v, nvec)) store8(out_bf16 + row * hidden + (size_t)v * 8, x[i]);
     }
   }
   if constexpr (QMODE != 0) {
-    quant_row_cached<THREADS, QMODE, SW>(x, nvec, out_q + row * (int64_t)hidden, out_scale, out_azp, row, smem);
+    quant_row_cached<THREADS, QMODE, SW, NIT>(x, nvec, out_q + row * (int64_t)hidden, out_scale, out_azp, row, smem);
   }
 }
 
@@ -662,12 +731,19 @@ static int launch_quant(void* q, float* scale, int32_t* azp, const bf16_t* s0, i
   const int hidden = w0 + w1;
   const bool sw = g_fp8_sw_cvt;   // constexpr false in the product build
   auto qq = (uint8_t*)q;
+#define FDM_QNIT(T, NITV) quant_rowwise_kernel<T, MODE, false, NITV><<<(unsigned)rows, T, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1)
+#define FDM_QROW(T)                                                                                                      \
+  if (sw) quant_rowwise_kernel<T, MODE, true><<<(unsigned)rows, T, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1);     \
+  else switch (((hidden >> 3) + T - 1) / T) {                                                                             \
+    case 1: FDM_QNIT(T, 1); break; case 2: FDM_QNIT(T, 2); break; case 3: FDM_QNIT(T, 3); break; case 4: FDM_QNIT(T, 4); break; \
+    case 5: FDM_QNIT(T, 5); break; case 6: FDM_QNIT(T, 6); break; case 7: FDM_QNIT(T, 7); break; default: FDM_QNIT(T, 8); break; \
+  }
   if (hidden <= 4096) {
-    if (sw) quant_rowwise_kernel<64, MODE, true><<<(unsigned)rows, 64, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1);
-    else quant_rowwise_kernel<64, MODE, false><<<(unsigned)rows, 64, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1);
+    FDM_QROW(64)
   } else if (hidden <= MAXV * 256 * 8) {
-    if (sw) quant_rowwise_kernel<256, MODE, true><<<(unsigned)rows, 256, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1);
-    else quant_rowwise_kernel<256, MODE, false><<<(unsigned)rows, 256, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1);
+    FDM_QROW(256)
+#undef FDM_QROW
+#undef FDM_QNIT
   } else {
     if (s1 != nullptr) return FDM_ERR_UNSUPPORTED;
     if (sw) quant_rowwise_wide_kernel<MODE, true><<<(unsigned)rows, 256, 0, s>>>(qq, scale, azp, s0, hidden, st0);
@@ -682,14 +758,22 @@ static int launch_ln(void* out_bf16, void* out_q, float* out_scale, int32_t* out
                      const void* shift, int64_t mbs, const void* res, const void* gate, void* x_out, int64_t rows, int hidden,
                      int64_t rpb, float eps, hipStream_t s) {
   const bool sw = g_fp8_sw_cvt;   // constexpr false in the product build
-#define FDM_LN(QM, SWV)                                                                                                  \
-  ln_modulate_kernel<THREADS, QM, SWV><<<(unsigned)rows, THREADS, 0, s>>>(                                               \
+#define FDM_LNK(QM, SWV, NITV)                                                                                           \
+  ln_modulate_kernel<THREADS, QM, SWV, NITV><<<(unsigned)rows, THREADS, 0, s>>>(                                         \
       (bf16_t*)out_bf16, (uint8_t*)out_q, out_scale, out_azp, (const bf16_t*)x, (const bf16_t*)scale, (const bf16_t*)shift, \
       mbs, (const bf16_t*)res, (const bf16_t*)gate, (bf16_t*)x_out, hidden, rpb, eps)
-  if (qm == 0) FDM_LN(0, false);
-  else if (qm == 1) { if (sw) FDM_LN(1, true); else FDM_LN(1, false); }
-  else if (qm == 2) FDM_LN(2, false);
+#define FDM_LN(QM, SWV)                                                                                                  \
+  if (SWV) FDM_LNK(QM, SWV, 0);                                                                                          \
+  else switch (((hidden >> 3) + THREADS - 1) / THREADS) {                                                                 \
+    case 1: FDM_LNK(QM, false, 1); break; case 2: FDM_LNK(QM, false, 2); break; case 3: FDM_LNK(QM, false, 3); break;    \
+    case 4: FDM_LNK(QM, false, 4); break; case 5: FDM_LNK(QM, false, 5); break; case 6: FDM_LNK(QM, false, 6); break;    \
+    case 7: FDM_LNK(QM, false, 7); break; default: FDM_LNK(QM, false, 8); break;                                         \
+  }
+  if (qm == 0) { FDM_LN(0, false) }
+  else if (qm == 1) { if (sw) { FDM_LN(1, true) } else { FDM_LN(1, false) } }
+  else if (qm == 2) { FDM_LN(2, false) }
   else return FDM_ERR_UNSUPPORTED;
+#undef FDM_LNK
 #undef FDM_LN
   FDM_CHECK_LAUNCH();
   return FDM_OK;
@@ -699,13 +783,21 @@ template <int THREADS>
 static int launch_ln_f32(void* out_bf16, void* out_q, float* out_scale, int32_t* out_azp, int qm, const void* x, const float* scale,
                          const float* shift, int64_t mbs, int64_t rows, int hidden, int64_t rpb, float eps, hipStream_t s) {
   const bool sw = g_fp8_sw_cvt;   // constexpr false in the product build
-#define FDM_LNF(QM, SWV)                                                                                        \
-  ln_modulate_f32_kernel<THREADS, QM, SWV><<<(unsigned)rows, THREADS, 0, s>>>(                                   \
+#define FDM_LNFK(QM, SWV, NITV)                                                                                  \
+  ln_modulate_f32_kernel<THREADS, QM, SWV, NITV><<<(unsigned)rows, THREADS, 0, s>>>(                             \
       (bf16_t*)out_bf16, (uint8_t*)out_q, out_scale, out_azp, (const bf16_t*)x, scale, shift, mbs, hidden, rpb, eps)
-  if (qm == 0) FDM_LNF(0, false);
-  else if (qm == 1) { if (sw) FDM_LNF(1, true); else FDM_LNF(1, false); }
-  else if (qm == 2) FDM_LNF(2, false);
+#define FDM_LNF(QM, SWV)                                                                                         \
+  if (SWV) FDM_LNFK(QM, SWV, 0);                                                                                 \
+  else switch (((hidden >> 3) + THREADS - 1) / THREADS) {                                                         \
+    case 1: FDM_LNFK(QM, false, 1); break; case 2: FDM_LNFK(QM, false, 2); break; case 3: FDM_LNFK(QM, false, 3); break; \
+    case 4: FDM_LNFK(QM, false, 4); break; case 5: FDM_LNFK(QM, false, 5); break; case 6: FDM_LNFK(QM, false, 6); break; \
+    case 7: FDM_LNFK(QM, false, 7); break; default: FDM_LNFK(QM, false, 8); break;                                \
+  }
+  if (qm == 0) { FDM_LNF(0, false) }
+  else if (qm == 1) { if (sw) { FDM_LNF(1, true) } else { FDM_LNF(1, false) } }
+  else if (qm == 2) { FDM_LNF(2, false) }
   else return FDM_ERR_UNSUPPORTED;
+#undef FDM_LNFK
 #undef FDM_LNF
   FDM_CHECK_LAUNCH();
   return FDM_OK;
