@@ -189,9 +189,8 @@ def test_quant_shapes_bit_exact(K, M, Kd):
 def test_quant_fp8_adversarial_rows_on_rounding_boundaries(K):
     """Rows built to sit ON the fp8 rounding boundaries -- lattice values whose quotients x / scale are exact ties, saturating
     and subnormal-range values, zeros, the scale clamp -- must be bit-identical to the reference arithmetic (a quantiser that
-    replaces the division by a reciprocal multiplication fails exactly here; r2 tried a bracketed division-free variant, which
-    passed this test but was not faster: the row quantisers are bound by their load -> reduce -> convert phase structure, not
-    by VALU throughput)."""
+    replaces the division by a plain reciprocal multiplication fails exactly here; the shipped `RowDiv` keeps the compiler's
+    residual chain and only hoists the reciprocal)."""
     g = gen(4242)
     rows, width = 24, 12288
     x = rbf(g, rows, width, scale=1.0)
