@@ -565,16 +565,14 @@ __global__ void __launch_bounds__(256) gelu_and_mul_kernel(bf16_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------ q/k norm + rope + scatter
+// x: 8 consecutive elements of one head (lane `sub` of the head's HD/8 lanes); wv: the norm weight's 8 elements; cr / sr: this
+// lane's 4 cos / 4 sin factors of the row's position (ignored without a cache)
 template <int HD>
-__device__ __forceinline__ Vec8 qk_norm_rope_apply(const Vec8& x, float rs, const bf16_t* __restrict__ w,
-                                                 const bf16_t* __restrict__ cache, int64_t pos, int sub) {
-  Vec8 wv = load8(w + sub * 8), o;
+__device__ __forceinline__ Vec8 qk_norm_rope_apply_pre(const Vec8& x, float rs, const Vec8& wv, bool rope, const i32x2 cr, const i32x2 sr) {
+  Vec8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) o.v[j] = rbf(rbf(x.v[j] * rs) * wv.v[j]);
-  if (cache != nullptr) {
-    const bf16_t* crow = cache + pos * HD;
-    const i32x2 cr = *reinterpret_cast<const i32x2*>(crow + sub * 4);
-    const i32x2 sr = *reinterpret_cast<const i32x2*>(crow + HD / 2 + sub * 4);
+  if (rope) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       uint32_t cw = (uint32_t)cr[j >> 1], sw = (uint32_t)sr[j >> 1];
@@ -586,6 +584,17 @@ __device__ __forceinline__ Vec8 qk_norm_rope_apply(const Vec8& x, float rs, cons
     }
   }
   return o;
+}
+template <int HD>
+__device__ __forceinline__ Vec8 qk_norm_rope_apply(const Vec8& x, float rs, const bf16_t* __restrict__ w,
+                                                 const bf16_t* __restrict__ cache, int64_t pos, int sub) {
+  i32x2 cr = {0, 0}, sr = {0, 0};
+  if (cache != nullptr) {
+    const bf16_t* crow = cache + pos * HD;
+    cr = *reinterpret_cast<const i32x2*>(crow + sub * 4);
+    sr = *reinterpret_cast<const i32x2*>(crow + HD / 2 + sub * 4);
+  }
+  return qk_norm_rope_apply_pre<HD>(x, rs, load8(w + sub * 8), cache != nullptr, cr, sr);
 }
 
 // One wave handles one (token, head) pair-of-8-lanes... layout: 16 lanes x 8 elements = one 128-wide head
@@ -660,6 +669,53 @@ __global__ void __launch_bounds__(256) qk_norm_rope_inplace_kernel(bf16_t* qkv, 
   if (!ok) return;
   const float rs = rsqrtf(ss / (float)HD + eps);
   store8(p, qk_norm_rope_apply<HD>(x, rs, which == 0 ? wq : wk, cache, pos_offset + r, sub));
+}
+
+// The same arithmetic with one block per row: the (q | k, head) items of a row are walked in NI = ceil(2 * heads / (256 / LPH))
+// unrolled passes, so a thread has NI 16-byte loads in flight instead of one, the norm weights and the row's cos / sin factors
+// are loaded once per thread instead of once per item, and the per-thread 64-bit divisions of the flat mapping (item -> row,
+// head, batch: two thirds of that kernel's instruction stream) become one scalar division per block.
+template <int HD, int NI>
+__global__ void __launch_bounds__(256) qk_norm_rope_inplace_row_kernel(bf16_t* qkv, const bf16_t* __restrict__ wq,
+                                                                       const bf16_t* __restrict__ wk,
+                                                                       const bf16_t* __restrict__ cache, int64_t rows_per_batch,
+                                                                       int64_t row_stride_batch, int64_t row_stride,
+                                                                       int64_t k_offset, int64_t pos_offset, int heads, float eps) {
+  constexpr int LPH = HD / 8, IPP = 256 / LPH;
+  const int64_t row = blockIdx.x;
+  const int64_t b = row / rows_per_batch, r = row - b * rows_per_batch;
+  const int sub = threadIdx.x % LPH, it0 = threadIdx.x / LPH;
+  const int items = 2 * heads;
+  bf16_t* base = qkv + (b * row_stride_batch + r) * row_stride + sub * 8;
+  i32x4 raw[NI];
+  bf16_t* ptr[NI];
+  bool isk[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int item = min(it0 + i * IPP, items - 1);   // past the end: re-read the last item (never stored)
+    isk[i] = item >= heads;
+    ptr[i] = base + (isk[i] ? k_offset + (int64_t)(item - heads) * HD : (int64_t)item * HD);
+    raw[i] = *reinterpret_cast<const i32x4*>(ptr[i]);
+  }
+  const Vec8 wqv = load8(wq + sub * 8), wkv = load8(wk + sub * 8);
+  i32x2 cr = {0, 0}, sr = {0, 0};
+  if (cache != nullptr) {
+    const bf16_t* crow = cache + (pos_offset + r) * HD;
+    cr = *reinterpret_cast<const i32x2*>(crow + sub * 4);
+    sr = *reinterpret_cast<const i32x2*>(crow + HD / 2 + sub * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const Vec8 x = unpack8(raw[i]);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += x.v[j] * x.v[j];
+#pragma unroll
+    for (int off = LPH / 2; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float rs = rsqrtf(ss / (float)HD + eps);
+    const Vec8 o = qk_norm_rope_apply_pre<HD>(x, rs, isk[i] ? wkv : wqv, cache != nullptr, cr, sr);
+    if (it0 + i * IPP < items) store8(ptr[i], o);
+  }
 }
 
 // ------------------------------------------------------------------------------------ TeaCache metric
@@ -1037,9 +1093,20 @@ int fdm_qk_norm_rope_inplace(void* qkv, const void* wq, const void* wk, const vo
   qk_norm_rope_inplace_kernel<HD><<<(unsigned)grid, 256, 0, s>>>((bf16_t*)qkv, (const bf16_t*)wq, (const bf16_t*)wk, \
                                                                  (const bf16_t*)cos_sin_cache, rows, rows_per_batch,  \
                                                                  batch_row_stride, row_stride, k_offset, pos_offset, heads, eps)
-  if (head_dim == 128) FDM_QKI(128);
-  else if (head_dim == 64) FDM_QKI(64);
-  else FDM_QKI(32);
+#define FDM_QKR(HD, NIV)                                                                                                    \
+  qk_norm_rope_inplace_row_kernel<HD, NIV><<<(unsigned)rows, 256, 0, s>>>((bf16_t*)qkv, (const bf16_t*)wq, (const bf16_t*)wk,   \
+                                                                          (const bf16_t*)cos_sin_cache, rows_per_batch,        \
+                                                                          batch_row_stride, row_stride, k_offset, pos_offset, heads, eps)
+#define FDM_QKSEL(HD)                                                                          \
+  switch ((2 * heads + (2048 / HD) - 1) / (2048 / HD)) {   /* passes of 256 / (HD / 8) items */  \
+    case 1: FDM_QKR(HD, 1); break; case 2: FDM_QKR(HD, 2); break; case 3: FDM_QKR(HD, 3); break; \
+    case 4: FDM_QKR(HD, 4); break; default: FDM_QKI(HD); break;                                  \
+  }
+  if (head_dim == 128) { FDM_QKSEL(128) }
+  else if (head_dim == 64) { FDM_QKSEL(64) }
+  else { FDM_QKSEL(32) }
+#undef FDM_QKSEL
+#undef FDM_QKR
 #undef FDM_QKI
   FDM_CHECK_LAUNCH();
   return FDM_OK;

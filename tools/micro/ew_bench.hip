@@ -62,6 +62,13 @@ int main() {
   time("quant fp8 [8704,12288]", R * 12288 * 3.0, [&] { fdm_quant_rowwise_cat2(q, s, nullptr, 1, x, 12288, W, nullptr, 0, 0, R, nullptr); });
   time("quant fp8 [8704,3072]", R * 3072 * 3.0, [&] { fdm_quant_rowwise_cat2(q, s, nullptr, 1, y, 3072, 3072, nullptr, 0, 0, R, nullptr); });
   time("quant int8 (generic) [8704,3072]", R * 3072 * 3.0, [&] { fdm_quant_rowwise_cat2(q, s, nullptr, 3, y, 3072, 3072, nullptr, 0, 0, R, nullptr); });
+  {   // q|k|v planes [3][8704][3072]; norm + rope of q and k in place
+    uint16_t *planes, *wq, *cache; hipMalloc(&planes, 3 * R * 3072 * 2); hipMalloc(&wq, 256); hipMalloc(&cache, R * 128 * 2);
+    for (int i = 0; i < 3; ++i) hipMemcpy(planes + i * R * 3072, h.data() + i * 1000, R * 3072 * 2, hipMemcpyHostToDevice);
+    hipMemcpy(wq, h.data(), 256, hipMemcpyHostToDevice); hipMemcpy(cache, h.data() + 777, R * 128 * 2, hipMemcpyHostToDevice);
+    time("qk_norm_rope_inplace flat kernel (r02)", R * 3072 * 2 * 4.0, [&] { fdm::qk_norm_rope_inplace_kernel<128><<<(unsigned)((R * 48 * 16 + 255) / 256), 256>>>(planes, wq, wq, cache, R, R, R, 3072, R * 3072, 0, 24, 1e-6f); });
+    time("qk_norm_rope_inplace [8704, 2x24x128]", R * 3072 * 2 * 4.0, [&] { fdm_qk_norm_rope_inplace(planes, wq, wq, cache, R, R, R, 3072, R * 3072, 0, 24, 128, 1e-6f, nullptr); });
+  }
   for (int g : {2048, 4096, 8704, 32768}) {
     char nm[64]; snprintf(nm, 64, "stream cvt 16B->8B grid %d", g);
     time(nm, R * W * 3.0, [&] { stream_cvt_kernel<<<g, 256>>>(q, x, R * W / 8, 0.37f); });
