@@ -67,22 +67,28 @@ __global__ void __launch_bounds__(256) rms_norm_small_kernel(bf16_t* __restrict_
   store8(out + row * hidden + sub * 8, o);
 }
 
-template <int THREADS>
+template <int THREADS, int NIT = 0>
 __global__ void __launch_bounds__(THREADS) rms_norm_row_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ in,
                                                                const bf16_t* __restrict__ w, float eps, int hidden,
                                                                int64_t in_stride, int64_t out_stride) {
+  using It = RowIt<NIT>;
   __shared__ float smem[THREADS / 64];
   const int64_t row = blockIdx.x;
   const int nvec = hidden >> 3;
   const bf16_t* src = in + row * in_stride;
   Vec8 x[MAXV];
   float ss = 0.f;
-  const bool cached = nvec <= MAXV * THREADS;
+  const bool cached = NIT || nvec <= MAXV * THREADS;
+  i32x4 wr[MAXV];
   if (cached) {
-    load_row<THREADS>(x, src, nvec);
+    load_row<THREADS, NIT>(x, src, nvec);
+    if constexpr (NIT != 0) {   // the weight vectors travel under the reduction
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-      if ((int)threadIdx.x + i * THREADS < nvec)
+      for (int i = 0; i < It::N; ++i) wr[i] = *reinterpret_cast<const i32x4*>(w + (size_t)It::ld(i, threadIdx.x + i * THREADS, nvec) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < It::N; ++i)
+      if (It::live(i, (int)threadIdx.x + i * THREADS, nvec))
 #pragma unroll
         for (int j = 0; j < 8; ++j) ss += x[i].v[j] * x[i].v[j];
   } else {
@@ -97,10 +103,12 @@ __global__ void __launch_bounds__(THREADS) rms_norm_row_kernel(bf16_t* __restric
   bf16_t* dst = out + row * out_stride;
   if (cached) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < It::N; ++i) {
       int v = threadIdx.x + i * THREADS;
-      if (v < nvec) {
-        Vec8 wv = load8(w + (size_t)v * 8), o;
+      if (It::live(i, v, nvec)) {
+        Vec8 wv, o;
+        if constexpr (NIT != 0) wv = unpack8(wr[i]);
+        else wv = load8(w + (size_t)v * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.v[j] = rbf(x[i].v[j] * rs) * wv.v[j];
         store8(dst + (size_t)v * 8, o);
@@ -114,6 +122,19 @@ __global__ void __launch_bounds__(THREADS) rms_norm_row_kernel(bf16_t* __restric
       store8(dst + (size_t)v * 8, o);
     }
   }
+}
+
+// host side: iteration count -> template instance (widths beyond MAXV iterations use the generic two-pass form)
+template <int THREADS>
+static void launch_rms_row(bf16_t* o, const bf16_t* i, const bf16_t* w, float eps, int64_t rows, int hidden, int64_t is, int64_t os,
+                           hipStream_t s) {
+#define FDM_RMS(NITV) rms_norm_row_kernel<THREADS, NITV><<<(int)rows, THREADS, 0, s>>>(o, i, w, eps, hidden, is, os)
+  switch (((hidden >> 3) + THREADS - 1) / THREADS) {
+    case 1: FDM_RMS(1); break; case 2: FDM_RMS(2); break; case 3: FDM_RMS(3); break; case 4: FDM_RMS(4); break;
+    case 5: FDM_RMS(5); break; case 6: FDM_RMS(6); break; case 7: FDM_RMS(7); break; case 8: FDM_RMS(8); break;
+    default: FDM_RMS(0); break;
+  }
+#undef FDM_RMS
 }
 
 // Any width / alignment (the reference kernel takes any last_dim, csrc/elmwise_ops.cu:56-84): one wave per row, scalar bf16
@@ -910,9 +931,9 @@ int fdm_rms_norm(void* out, const void* in, const void* weight, float eps, int64
       default: rms_norm_small_kernel<64><<<grid, 256, 0, s>>>(o, i, w, eps, rows, hidden); break;
     }
   } else if (hidden <= 4096) {
-    rms_norm_row_kernel<64><<<(int)rows, 64, 0, s>>>(o, i, w, eps, hidden, hidden, hidden);
+    launch_rms_row<64>(o, i, w, eps, rows, hidden, hidden, hidden, s);
   } else {
-    rms_norm_row_kernel<256><<<(int)rows, 256, 0, s>>>(o, i, w, eps, hidden, hidden, hidden);
+    launch_rms_row<256>(o, i, w, eps, rows, hidden, hidden, hidden, s);
   }
   FDM_CHECK_LAUNCH();
   return FDM_OK;
@@ -926,12 +947,8 @@ int fdm_rms_norm_strided(void* out, const void* in, const void* weight, float ep
       in_row_stride < hidden || out_row_stride < hidden || (in_row_stride & 7) || (out_row_stride & 7))
     return FDM_ERR_INVALID;
   hipStream_t s = to_stream(stream);
-  if (hidden <= 4096)
-    rms_norm_row_kernel<64><<<(int)rows, 64, 0, s>>>((bf16_t*)out, (const bf16_t*)in, (const bf16_t*)weight, eps, hidden, in_row_stride,
-                                                     out_row_stride);
-  else
-    rms_norm_row_kernel<256><<<(int)rows, 256, 0, s>>>((bf16_t*)out, (const bf16_t*)in, (const bf16_t*)weight, eps, hidden, in_row_stride,
-                                                       out_row_stride);
+  if (hidden <= 4096) launch_rms_row<64>((bf16_t*)out, (const bf16_t*)in, (const bf16_t*)weight, eps, rows, hidden, in_row_stride, out_row_stride, s);
+  else launch_rms_row<256>((bf16_t*)out, (const bf16_t*)in, (const bf16_t*)weight, eps, rows, hidden, in_row_stride, out_row_stride, s);
   FDM_CHECK_LAUNCH();
   return FDM_OK;
 }
