@@ -534,19 +534,40 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
         if (p.azp != nullptr) azpm[i] = p.azp[mc];
       }
     }
+    // per-column operands of all 8 column groups, requested before any of them is used (inside the loop below every load sat
+    // in front of its first use: 8 exposed L2 round trips per tile)
+    f32x4 sbv[8];
+    i32x2 biasv[8];
+    i32x4 adjv[8];
+    const bool has_bias = p.bias != nullptr;
+#pragma unroll
+    for (int jq = 0; jq < 8; ++jq) {
+      const int nc = min(n0 + wn * 64 + (jq >> 2) * 32 + 8 * (jq & 3) + 4 * g, p.N - 4);
+      sbv[jq] = f32x4{1.f, 1.f, 1.f, 1.f};
+      biasv[jq] = i32x2{0, 0};
+      adjv[jq] = i32x4{0, 0, 0, 0};
+      if constexpr (DT != DT_BF16) sbv[jq] = *reinterpret_cast<const f32x4*>(p.sb + nc);
+    }
+    if (has_bias) {
+#pragma unroll
+      for (int jq = 0; jq < 8; ++jq)
+        biasv[jq] = *reinterpret_cast<const i32x2*>(p.bias + min(n0 + wn * 64 + (jq >> 2) * 32 + 8 * (jq & 3) + 4 * g, p.N - 4));
+    }
+    if constexpr (DT == DT_INT8) {
+      if (p.azp_adj != nullptr) {
+#pragma unroll
+        for (int jq = 0; jq < 8; ++jq)
+          adjv[jq] = *reinterpret_cast<const i32x4*>(p.azp_adj + min(n0 + wn * 64 + (jq >> 2) * 32 + 8 * (jq & 3) + 4 * g, p.N - 4));
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int nc = min(n0 + wn * 64 + j * 32 + 8 * q + 4 * g, p.N - 4);
-        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-        f32x4 sbq = {1.f, 1.f, 1.f, 1.f};
-        i32x4 adjq = {0, 0, 0, 0};
-        if constexpr (DT != DT_BF16) sbq = *reinterpret_cast<const f32x4*>(p.sb + nc);
-        if (p.bias != nullptr) unpack4(*reinterpret_cast<const i32x2*>(p.bias + nc), bias4);
-        if constexpr (DT == DT_INT8) {
-          if (p.azp_adj != nullptr) adjq = *reinterpret_cast<const i32x4*>(p.azp_adj + nc);
-        }
+        float bias4[4];
+        unpack4(biasv[j * 4 + q], bias4);
+        const f32x4 sbq = sbv[j * 4 + q];
+        const i32x4 adjq = adjv[j * 4 + q];
         float y[16];   // [i][c]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -559,7 +580,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
             } else if constexpr (DT == DT_INT8) {
               const int a = acc[i][j][e] - azpm[i] * adjq[c];
               yy = (float)a * (sam[i] * sbq[c]);
-              if (p.bias != nullptr) yy = rbf(yy) + bias4[c];
+              if (has_bias) yy = rbf(yy) + bias4[c];
             } else {
               yy = acc[i][j][e] + bias4[c];
             }
@@ -640,8 +661,20 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
           }
         }
       };
-      auto pipelined = [&](auto f32_c) {
-        // loads(h0) | combine(h0) | loads(h1) | stores(h0) | combine(h1) | stores(h1): every load precedes every store
+      bool fast = full;
+#ifdef FDM_DEBUG_BUILD
+      fast = fast && !(grp.debug & 4);
+#endif
+      bf16_t* cptr = p.C + (int64_t)(m0 + wm * 128 + rsub) * p.ldc + ccol;
+      const int64_t step8 = 8 * p.ldc;
+      auto pipelined = [&](auto f32_c, auto fast_c) {
+        // loads(h0) | combine(h0) | loads(h1) | stores(h0) | combine(h1) | stores(h1): every load precedes every store.
+        // FAST (whole tile): unpredicated stores off one base pointer -- the guarded store re-reads M / ldc / C per row.
+        constexpr bool FAST = decltype(fast_c)::value;
+        auto put = [&](int it, const i32x4& v) {
+          if constexpr (FAST) *reinterpret_cast<i32x4*>(cptr + it * step8) = v;
+          else store_row(it, v);
+        };
         float g8[8];
         load_gate(m_first / p.rows_per_batch, g8);
         i32x4 r0[8], o0[8], r1[8], o1[8];
@@ -656,15 +689,20 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) store_row(it, o0[it]);
+        for (int it = 0; it < 8; ++it) put(it, o0[it]);
 #pragma unroll
         for (int it = 0; it < 8; ++it) o1[it] = combine(f32_c, lds_row(8 + it), g8, r1[it]);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) store_row(8 + it, o1[it]);
+        for (int it = 0; it < 8; ++it) put(8 + it, o1[it]);
       };
       if (one_batch) {
-        if (p.gate_f32) pipelined(std::true_type{});
-        else pipelined(std::false_type{});
+        if (p.gate_f32) {
+          if (fast) pipelined(std::true_type{}, std::true_type{});
+          else pipelined(std::true_type{}, std::false_type{});
+        } else {
+          if (fast) pipelined(std::false_type{}, std::true_type{});
+          else pipelined(std::false_type{}, std::false_type{});
+        }
       } else {
         // the wave's 128 rows straddle a batch boundary (rare): per-row gate vector, unpipelined
         for (int it = 0; it < 16; ++it) {
@@ -676,8 +714,24 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
         }
       }
     } else {
+      bool fast = full;
+#ifdef FDM_DEBUG_BUILD
+      fast = fast && !(grp.debug & 4);
+#endif
+      if (fast) {
+        // whole tile (the common case): all 16 LDS reads in flight, then 16 unpredicated stores off one base pointer.  The guarded
+        // form below re-tests `full`, re-reads M / ldc / C from the kernel arguments and waits for its LDS read in every iteration.
+        i32x4 v[16];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) store_row(it, lds_row(it));
+        for (int it = 0; it < 16; ++it) v[it] = lds_row(it);
+        bf16_t* cptr = p.C + (int64_t)(m0 + wm * 128 + rsub) * p.ldc + ccol;
+        const int64_t step8 = 8 * p.ldc;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) *reinterpret_cast<i32x4*>(cptr + it * step8) = v[it];
+      } else {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) store_row(it, lds_row(it));
+      }
     }
   };
   if constexpr (RES) {
@@ -1087,17 +1141,34 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
         if (p.azp != nullptr) azpm[mb] = p.azp[mc];
       }
     }
+    // per-column operands of all 8 column blocks, requested before any of them is used (as in gemm_kernel's epilogue)
+    f32x4 sbv[8];
+    i32x2 biasv[8];
+    i32x4 adjv[8];
+    const bool has_bias = p.bias != nullptr;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      sbv[nb] = f32x4{1.f, 1.f, 1.f, 1.f};
+      biasv[nb] = i32x2{0, 0};
+      adjv[nb] = i32x4{0, 0, 0, 0};
+      if constexpr (DT != DT_BF16) sbv[nb] = *reinterpret_cast<const f32x4*>(p.sb + min(n0 + wn * 128 + nb * 16 + fq * 4, p.N - 4));
+    }
+    if (has_bias) {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) biasv[nb] = *reinterpret_cast<const i32x2*>(p.bias + min(n0 + wn * 128 + nb * 16 + fq * 4, p.N - 4));
+    }
+    if constexpr (DT == DT_INT8) {
+      if (p.azp_adj != nullptr) {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) adjv[nb] = *reinterpret_cast<const i32x4*>(p.azp_adj + min(n0 + wn * 128 + nb * 16 + fq * 4, p.N - 4));
+      }
+    }
     static_for<8>([&](auto nbc) {
       constexpr int nb = decltype(nbc)::value;
-      const int nc = min(n0 + wn * 128 + nb * 16 + fq * 4, p.N - 4);
-      float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-      f32x4 sbq = {1.f, 1.f, 1.f, 1.f};
-      i32x4 adjq = {0, 0, 0, 0};
-      if constexpr (DT != DT_BF16) sbq = *reinterpret_cast<const f32x4*>(p.sb + nc);
-      if (p.bias != nullptr) unpack4(*reinterpret_cast<const i32x2*>(p.bias + nc), bias4);
-      if constexpr (DT == DT_INT8) {
-        if (p.azp_adj != nullptr) adjq = *reinterpret_cast<const i32x4*>(p.azp_adj + nc);
-      }
+      float bias4[4];
+      unpack4(biasv[nb], bias4);
+      const f32x4 sbq = sbv[nb];
+      const i32x4 adjq = adjv[nb];
       static_for<2>([&](auto hc) {
         constexpr int h = decltype(hc)::value;
         float y[16];   // [mm][c]
@@ -1113,7 +1184,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
             } else if constexpr (DT == DT_INT8) {
               const int a = aw[c] - azpm[mb] * adjq[c];
               yy = (float)a * (sam[mb] * sbq[c]);
-              if (p.bias != nullptr) yy = rbf(yy) + bias4[c];
+              if (has_bias) yy = rbf(yy) + bias4[c];
             } else {
               yy = __builtin_bit_cast(float, aw[c]) + bias4[c];
             }
@@ -1191,9 +1262,13 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
           }
         }
       };
-      auto pipelined = [&](auto f32_c) {
+      bf16_t* cptr = p.C + (int64_t)(m0 + wm * 128 + rsub) * p.ldc + ccol;
+      const int64_t step4 = 4 * p.ldc;
+      auto pipelined = [&](auto f32_c, auto fast_c) {
         // groups of 8 row-instructions: loads(g) run one group ahead of combine(g - 1) + stores(g - 1); every load of a
-        // group precedes the stores of the previous one in program order (vmcnt retires in order)
+        // group precedes the stores of the previous one in program order (vmcnt retires in order).
+        // FAST (whole tile): unpredicated stores off one base pointer -- the guarded store re-reads M / ldc / C per row.
+        constexpr bool FAST = decltype(fast_c)::value;
         float g8[8];
         load_gate(m_first / p.rows_per_batch, g8);
         i32x4 rr[2][8], oo[8];
@@ -1210,12 +1285,20 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
           asm volatile("" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int it = 0; it < 8; ++it) store_row(gi * 8 + it, oo[it]);
+          for (int it = 0; it < 8; ++it) {
+            if constexpr (FAST) *reinterpret_cast<i32x4*>(cptr + (gi * 8 + it) * step4) = oo[it];
+            else store_row(gi * 8 + it, oo[it]);
+          }
         }
       };
       if (one_batch) {
-        if (p.gate_f32) pipelined(std::true_type{});
-        else pipelined(std::false_type{});
+        if (p.gate_f32) {
+          if (full) pipelined(std::true_type{}, std::true_type{});
+          else pipelined(std::true_type{}, std::false_type{});
+        } else {
+          if (full) pipelined(std::false_type{}, std::true_type{});
+          else pipelined(std::false_type{}, std::false_type{});
+        }
       } else {
         for (int it = 0; it < 32; ++it) {
           const int mc = min(m0 + wm * 128 + it * 4 + rsub, p.M - 1);
@@ -1224,6 +1307,18 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
           const i32x4 rv = res_row(it);
           store_row(it, p.gate_f32 ? combine(std::true_type{}, lds_row(it), g8, rv) : combine(std::false_type{}, lds_row(it), g8, rv));
         }
+      }
+    } else if (full) {
+      // whole tile: 16 LDS reads in flight, 16 unpredicated stores off one base pointer, twice
+      bf16_t* cptr = p.C + (int64_t)(m0 + wm * 128 + rsub) * p.ldc + ccol;
+      const int64_t step4 = 4 * p.ldc;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        i32x4 v[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) v[it] = lds_row(hf * 16 + it);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) *reinterpret_cast<i32x4*>(cptr + (hf * 16 + it) * step4) = v[it];
       }
     } else {
 #pragma unroll
@@ -1249,10 +1344,10 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
 
 // Which tile kernel runs a launch.  Both compute the same 256 x 256 tiles (int8: bit-identical; fp8 / bf16: identical except for
 // the fp32 summation order inside the MFMA shapes, <= 1-2 bf16 ulp on ~1e-6 of the elements).  Measured inside whole denoise steps
-// on MI355X (rocprofv3 / bench.py A/B on one box, profiles/r03_experiments.md): gemm_w4_kernel wins where a launch is a few rounds
-// of long tiles (FLUX N = 3072 down-projections: 325 vs 350 us) and for FLUX bf16 (the 8-wave kernel is MFMA-issue-bound there);
-// many-round K = 3072 launches stay with the 8-wave kernel, whose two waves per SIMD cover each other's prologue / epilogue
-// (214 vs 218 us).
+// on MI355X (bench.py A/B on one box, profiles/r03_experiments.md): gemm_w4_kernel everywhere it applies is 102.9-103.3 ms per
+// FLUX fp8 step against 105.7-106.2 with gemm_kernel everywhere (int8: 107.7 vs 111.2 with the earlier mixed rule).  Before the
+// epilogues of both kernels were rewritten (operands requested up front, whole-tile stores off one base pointer) the many-round
+// K = 3072 launches were 2 % slower in the 4-wave kernel, whose one wave per SIMD has nothing to cover its epilogue with.
 // FDM_GEMM_KERNEL = w4 | w8 | auto (default) overrides for A/B runs; read once.
 #ifdef FDM_GEMM_AB
 int g_gemm_use_w4 = 1;   // micro-benchmark builds only: both kernels in one process
@@ -1272,16 +1367,19 @@ static bool use_w4(const GemmGroup& grp) {
 #else
   const int mode = gemm_kernel_mode();
   if (mode != 2) return mode == 1;
-  // auto: only whole tiles and an even number of 128-byte K steps (ragged problems pay gemm_w4_kernel's longer prologue /
-  // epilogue and its zero-filled padding step for nothing: Qwen-Image M = 7017 +2 %, SD3.5 N = K = 2432 +3 % per step)
-  int64_t kb = grp.p[0].Kb;
+  // auto: the 4-wave kernel for every problem of whole N tiles and an even number of 128-byte K steps; a ragged M (edge tiles:
+  // clamped source rows, masked stores) only in launches of >= 2 rounds -- 1.3-round launches go through the int8 split-K tail,
+  // whose part / merge blocks are slower with one wave per SIMD (Qwen-Image 1328^2, one forward of M = 7017: 205.1 -> 199.3 ms per
+  // step with this rule, 196.9 -> 198 without the round limit; batch-2 forward 188.4 -> 178.6; SDXL unchanged)
+  // (ragged N / K in the 4-wave kernel: SD3.5-large N = K = 2432 56.9 -> 56.6 ms per step, SDXL 45.4 -> 44.5: within noise, not taken)
+  const bool many_rounds = grp.total_tiles >= 2 * device_cu_count();
   for (int i = 0; i < grp.n; ++i) {
     const GemmProblem& q = grp.p[i];
-    if ((q.M % BM) || (q.N % BN) || (q.Kb % 256) || q.Kb < 2048) return false;
-    if (q.Kb < kb) kb = q.Kb;
+    if (q.Kb < 2048) return false;
+    if (!many_rounds && (q.M % BM)) return false;
+    if ((q.N % BN) || (q.Kb % 256)) return false;
   }
-  if (DT == DT_BF16) return true;                                         // FLUX bf16 1024^2: 88.5 vs 94.7 ms per step
-  return kb >= 8192 || grp.total_tiles <= 3 * device_cu_count();           // FLUX fp8 / int8 down-projections: -4 % / -12 % per launch
+  return true;
 #endif
 }
 #ifdef FDM_GEMM_STAMPS

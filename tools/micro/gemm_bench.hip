@@ -1,7 +1,10 @@
 // Standalone fp8 GEMM micro-benchmark: compiles gemm.hip directly so that kernel variants (-D macros) can be
 // A/B-tested in one GPU call without Python.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off
 //   tools/micro/gemm_bench.hip -o tools/micro/gemm_bench[_variant] [-DFDM_...]
-#include "../../fastdm_amd/csrc/gemm.hip"
+#ifndef GEMM_SRC
+#define GEMM_SRC "../../fastdm_amd/csrc/gemm.hip"   // A/B builds point this at another revision of the file (-DGEMM_SRC=... -I fastdm_amd/csrc)
+#endif
+#include GEMM_SRC
 #include <cstdio>
 #include <cstring>
 #include <cmath>
