@@ -31,8 +31,8 @@ IMAGE_STEPS = 25
 # timing-span name -> HIP kernel it launches (the name rocprofv3 reports; profiles/*_summary.txt)
 HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128, false>", "attn_sparse_bf16": "fdm::attn_fwd64_kernel<128, true>",
               # GEMM spans: the kernel the dispatch policy (gemm.hip use_w4) picks for the default workloads' launches of that span
-              "gemm_w8a8_fp8": "fdm::gemm_kernel<0, false>", "gemm_w8a8_fp8_res": "fdm::gemm_w4_kernel<0, true>",
-              "gemm_w8a8_int8": "fdm::gemm_kernel<1, false>", "gemm_w8a8_int8_res": "fdm::gemm_kernel<1, true>",
+              "gemm_w8a8_fp8": "fdm::gemm_w4_kernel<0, false>", "gemm_w8a8_fp8_res": "fdm::gemm_w4_kernel<0, true>",
+              "gemm_w8a8_int8": "fdm::gemm_w4_kernel<1, false>", "gemm_w8a8_int8_res": "fdm::gemm_w4_kernel<1, true>",
               "gemm_bf16": "fdm::gemm_w4_kernel<2, false>", "gemm_bf16_res": "fdm::gemm_w4_kernel<2, true>"}
 
 
