@@ -1003,11 +1003,21 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
       merged = true;
       const int32_t* src = grp.ws + ((int64_t)(blockIdx.x >> grp.spread_shift) * grp.splits) * (64 * 256 * 4) + tid * 4;
       const int n_parts = (wave >> (2 - grp.spread_shift)) == (int)(blockIdx.x & ((1 << grp.spread_shift) - 1)) ? grp.splits : 0;
-      static_for<64>([&](auto ic) {
-        constexpr int IDX = decltype(ic)::value;
-        i32x4 sum = {0, 0, 0, 0};
-        for (int sp = 0; sp < n_parts; ++sp) sum += *reinterpret_cast<const i32x4*>(src + (int64_t)sp * (64 * 256 * 4) + IDX * (256 * 4));
-        acc_set<IDX>(sum);
+      // 16 accumulator quads at a time: the parts' 16 loads are in flight together (one quad with its own runtime loop over the
+      // parts, as first written, is a chain of 64 x S dependent round trips)
+      static_for<4>([&](auto cc) {
+        constexpr int C0 = decltype(cc)::value * 16;
+        i32x4 sum[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum[j] = i32x4{0, 0, 0, 0};
+        for (int sp = 0; sp < n_parts; ++sp) {
+          i32x4 v[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const i32x4*>(src + (int64_t)sp * (64 * 256 * 4) + (C0 + j) * (256 * 4));
+#pragma unroll
+          for (int j = 0; j < 16; ++j) sum[j] += v[j];
+        }
+        static_for<16>([&](auto jc) { acc_set<C0 + decltype(jc)::value>(sum[decltype(jc)::value]); });
       });
     }
   }
@@ -1368,11 +1378,13 @@ static bool use_w4(const GemmGroup& grp) {
   const int mode = gemm_kernel_mode();
   if (mode != 2) return mode == 1;
   // auto: the 4-wave kernel for every problem of whole N tiles and an even number of 128-byte K steps; a ragged M (edge tiles:
-  // clamped source rows, masked stores) only in launches of >= 2 rounds -- 1.3-round launches go through the int8 split-K tail,
-  // whose part / merge blocks are slower with one wave per SIMD (Qwen-Image 1328^2, one forward of M = 7017: 205.1 -> 199.3 ms per
-  // step with this rule, 196.9 -> 198 without the round limit; batch-2 forward 188.4 -> 178.6; SDXL unchanged)
+  // clamped source rows, masked stores) in launches of at least one full round -- the sub-round ragged launches (SDXL's 154-row
+  // cross-attention projections) lose 1.4 % of the SDXL step there.  Measured per denoise step, one box each
+  // (profiles/r03_experiments.md): Qwen-Image 1328^2, one forward of M = 7017 per prompt: 205.1 (whole tiles only) -> 199.3
+  // (>= 2 rounds) -> 196.9 (>= 1 round, after the merge launch of the split-K tail got its loads batched); batch-2 forward
+  // 188.4 -> 178.6; SDXL unchanged.
   // (ragged N / K in the 4-wave kernel: SD3.5-large N = K = 2432 56.9 -> 56.6 ms per step, SDXL 45.4 -> 44.5: within noise, not taken)
-  const bool many_rounds = grp.total_tiles >= 2 * device_cu_count();
+  const bool many_rounds = grp.total_tiles >= device_cu_count();
   for (int i = 0; i < grp.n; ++i) {
     const GemmProblem& q = grp.p[i];
     if (q.Kb < 2048) return false;
