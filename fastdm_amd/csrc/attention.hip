@@ -585,6 +585,18 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (last ? vofs_t[I] : vofs[I])),
                                      (__attribute__((address_space(3))) void*)(smem + V_RING + slot * TILE_BYTES + wave * 1024 + I * 4096), 16, 0, 0);
   };
+  // Q first: its 16 raw loads go out back to back and in front of the 28 K / V DMAs of the prologue (loads return in order), so the
+  // conversion below waits for Q alone while the tiles are still landing.  (Loading inside the conversion loop, as first written,
+  // became 16 load -> s_waitcnt vmcnt(0) -> convert round trips per work item, the first of them behind all 28 DMAs.)
+  i32x4 qraw[2][KSTEPS];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    int64_t qrow = q0 + wave * 64 + qb * 32 + lq;
+    if (qrow > p.sq - 1) qrow = p.sq - 1;
+    const bf16_t* qp = qbase + qrow * p.q_ts + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) qraw[qb][ks] = *reinterpret_cast<const i32x4*>(qp + 16 * ks);
+  }
   static_for<4>([&](auto s_) {
     bool last;
     auto& le_ = le;
@@ -602,12 +614,9 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
   i32x4 qa[2][KSTEPS];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
-    int64_t qrow = q0 + wave * 64 + qb * 32 + lq;
-    if (qrow > p.sq - 1) qrow = p.sq - 1;
-    const bf16_t* qp = qbase + qrow * p.q_ts + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      i32x4 v = *reinterpret_cast<const i32x4*>(qp + 16 * ks);
+      i32x4 v = qraw[qb][ks];
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         const uint32_t u = (uint32_t)v[w];
