@@ -271,7 +271,11 @@ def sample_rows(M, n=48):
     return torch.tensor(rows)
 
 
-@pytest.mark.parametrize("M,Kd,Nn", MM_SHAPES)
+# Qwen-Image's ragged token counts (one forward: 7017 rows, batch-2 forward: 14034): edge tiles of gemm_w4_kernel in launches of >= 1 round
+RAGGED_M_SHAPES = [[7017, 3072, 9216], [14034, 3072, 3072], [7017, 12288, 3072]]
+
+
+@pytest.mark.parametrize("M,Kd,Nn", MM_SHAPES + RAGGED_M_SHAPES)
 def test_fp8_matmul_reference_shapes(K, M, Kd, Nn):
     g = gen(M * 31 + Kd * 7 + Nn)
     a = torch.randn(M, Kd, generator=g).to(FP8)
@@ -285,7 +289,7 @@ def test_fp8_matmul_reference_shapes(K, M, Kd, Nn):
     assert torch.isfinite(got.float()).all()
 
 
-@pytest.mark.parametrize("M,Kd,Nn", MM_SHAPES[::3] + [[130, 16, 16], [257, 48, 272]])
+@pytest.mark.parametrize("M,Kd,Nn", MM_SHAPES[::3] + [[130, 16, 16], [257, 48, 272]] + RAGGED_M_SHAPES)
 def test_int8_matmul_reference_shapes(K, M, Kd, Nn):
     g = gen(M * 13 + Kd * 5 + Nn)
     a = torch.randint(-128, 128, (M, Kd), generator=g).to(torch.int8)
