@@ -1173,6 +1173,11 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
         for (int nb = 0; nb < 8; ++nb) adjv[nb] = *reinterpret_cast<const i32x4*>(p.azp_adj + min(n0 + wn * 128 + nb * 16 + fq * 4, p.N - 4));
       }
     }
+    // int8 rounds to bf16 before the bias is added (as the reference's two ops do), fp8 / bf16 do not: with `has_bias` tested per
+    // element hipcc emitted both forms and a select for each of the 256 values per lane (pass 1: 13.5 k cycles per tile against 6.4 k for
+    // fp8), so the flag is a compile-time parameter of the pass and tested once per tile.
+    auto pass1 = [&](auto hb_c) {
+    constexpr bool HB = decltype(hb_c)::value;
     static_for<8>([&](auto nbc) {
       constexpr int nb = decltype(nbc)::value;
       float bias4[4];
@@ -1194,7 +1199,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
             } else if constexpr (DT == DT_INT8) {
               const int a = aw[c] - azpm[mb] * adjq[c];
               yy = (float)a * (sam[mb] * sbq[c]);
-              if (has_bias) yy = rbf(yy) + bias4[c];
+              if constexpr (HB) yy = rbf(yy) + bias4[c];
             } else {
               yy = __builtin_bit_cast(float, aw[c]) + bias4[c];
             }
@@ -1212,6 +1217,13 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
         }
       });
     });
+    };
+    if constexpr (DT == DT_INT8) {
+      if (has_bias) pass1(std::true_type{});
+      else pass1(std::false_type{});
+    } else {
+      pass1(std::false_type{});
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: no block barrier needed
     __builtin_amdgcn_sched_barrier(0);
 #ifdef FDM_GEMM_STAMPS
