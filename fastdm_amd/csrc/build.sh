@@ -9,13 +9,20 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-
 pids=()
 # attention.hip: the hand-placed MFMA gaps of attn_fwd64_kernel must not be re-packed by the SLP vectoriser (it merges the
 # two q-blocks' row-sum chains into v_pk_add_f32 and sinks them below the tile)
+# gemm.hip / attention.hip: keep the device assembly of exactly this build beside the objects (-save-temps=obj costs nothing extra);
+# tools/micro/audit_{gemm,attn}_asm.sh check it for compiler-made AGPR / scratch / call instructions inside the hand-scheduled kernels
 for f in elementwise gemm attention capi; do
   extra=""
-  [ "$f" = attention ] && extra="-fno-slp-vectorize"
+  [ "$f" = attention ] && extra="-fno-slp-vectorize -save-temps=obj"
+  [ "$f" = gemm ] && extra="-save-temps=obj"
   "$HIPCC" $FLAGS $extra -c "$HERE/$f.hip" -o "$OUT/$f.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
+for f in gemm attention; do
+  mv -f "$OUT/$f-hip-amdgcn-amd-amdhsa-gfx950.s" "$OUT/$f.gfx950.s"
+  rm -f "$OUT/$f"-hip-amdgcn-amd-amdhsa-gfx950.* "$OUT/$f"-host-x86_64-unknown-linux-gnu.* "$OUT/$f".hip-hip-amdgcn-amd-amdhsa.hipfb
+done
 # link under a temporary name and rename: a process that has the old library mapped (another rank, another job) keeps its inode
 # instead of seeing a truncated file
 TMP_SO="$OUT/.libfastdm_amd.so.$$"

@@ -1176,8 +1176,9 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     // int8 rounds to bf16 before the bias is added (as the reference's two ops do), fp8 / bf16 do not: with `has_bias` tested per
     // element hipcc emitted both forms and a select for each of the 256 values per lane (pass 1: 13.5 k cycles per tile against 6.4 k for
     // fp8), so the flag is a compile-time parameter of the pass and tested once per tile.
-    auto pass1 = [&](auto hb_c) {
+    auto pass1 = [&](auto hb_c, auto half_c) {
     constexpr bool HB = decltype(hb_c)::value;
+    constexpr int HALF = decltype(half_c)::value;   // 0 / 1: rows [64 HALF, 64 HALF + 64) of the wave tile only; -1: all 128 rows
     static_for<8>([&](auto nbc) {
       constexpr int nb = decltype(nbc)::value;
       float bias4[4];
@@ -1186,6 +1187,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
       const i32x4 adjq = adjv[nb];
       static_for<2>([&](auto hc) {
         constexpr int h = decltype(hc)::value;
+        if constexpr (HALF == -1 || HALF == h) {
         float y[16];   // [mm][c]
         static_for<4>([&](auto mmc) {
           constexpr int mm = decltype(mmc)::value, mb = h * 4 + mm;
@@ -1215,20 +1217,20 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
           const int r = (h * 4 + mm) * 16 + fi;          // r & 15 == fi
           *reinterpret_cast<i32x2*>(wt + r * 256 + (((nb * 2 + (fq >> 1)) ^ fi) << 4) + (fq & 1) * 8) = o;
         }
+        }
       });
     });
     };
-    if constexpr (DT == DT_INT8) {
-      if (has_bias) pass1(std::true_type{});
-      else pass1(std::false_type{});
-    } else {
-      pass1(std::false_type{});
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: no block barrier needed
-    __builtin_amdgcn_sched_barrier(0);
-#ifdef FDM_GEMM_STAMPS
-    if (tid == 0) stamp[4] = __builtin_readcyclecounter();
-#endif
+    auto run_pass1 = [&](auto half_c) {
+      if constexpr (DT == DT_INT8) {
+        if (has_bias) pass1(std::true_type{}, half_c);
+        else pass1(std::false_type{}, half_c);
+      } else {
+        pass1(std::false_type{}, half_c);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private tile: no block barrier needed
+      __builtin_amdgcn_sched_barrier(0);
+    };
     // pass 2: row-contiguous 16-byte pieces.  Instruction it (0..31): lane -> row 4 * it + lane / 16, chunk lane % 16.
     const int rsub = lane >> 4, ch = lane & 15;
     const int ncol = n0 + wn * 128 + ch * 8;
@@ -1239,6 +1241,32 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
       const int r = it * 4 + rsub;
       return *reinterpret_cast<const i32x4*>(wt + r * 256 + ((ch ^ (r & 15)) << 4));
     };
+    if constexpr (EPI != FDM_EPI_GATE_RESIDUAL) {
+      if (full) {
+        // whole tile, no residual: the two 64-row halves go out one after the other -- the row stores of the first half (queued,
+        // asynchronous) drain through the CU's store path while the VALU scales and packs the second half (epilogue of a K = 3072
+        // tile 12.6 k -> 11.8 k cycles)
+        bf16_t* cptr = p.C + (int64_t)(m0 + wm * 128 + rsub) * p.ldc + ccol;
+        const int64_t step4 = 4 * p.ldc;
+        static_for<2>([&](auto hfc) {
+          constexpr int hf = decltype(hfc)::value;
+          run_pass1(std::integral_constant<int, hf>{});
+#ifdef FDM_GEMM_STAMPS
+          if (hf == 1 && tid == 0) stamp[4] = __builtin_readcyclecounter();
+#endif
+          i32x4 v[16];
+#pragma unroll
+          for (int it = 0; it < 16; ++it) v[it] = lds_row(hf * 16 + it);
+#pragma unroll
+          for (int it = 0; it < 16; ++it) *reinterpret_cast<i32x4*>(cptr + (hf * 16 + it) * step4) = v[it];
+        });
+        return;
+      }
+    }
+    run_pass1(std::integral_constant<int, -1>{});
+#ifdef FDM_GEMM_STAMPS
+    if (tid == 0) stamp[4] = __builtin_readcyclecounter();
+#endif
     auto store_row = [&](int it, const i32x4& v) {
       const int m = m0 + wm * 128 + it * 4 + rsub;
       if (n_ok && (full || m < p.M)) *reinterpret_cast<i32x4*>(p.C + (int64_t)m * p.ldc + ccol) = v;
@@ -1290,7 +1318,6 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
         // groups of 8 row-instructions: loads(g) run one group ahead of combine(g - 1) + stores(g - 1); every load of a
         // group precedes the stores of the previous one in program order (vmcnt retires in order).
         // FAST (whole tile): unpredicated stores off one base pointer -- the guarded store re-reads M / ldc / C per row.
-        constexpr bool FAST = decltype(fast_c)::value;
         float g8[8];
         load_gate(m_first / p.rows_per_batch, g8);
         i32x4 rr[2][8], oo[8];
@@ -1308,20 +1335,16 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int it = 0; it < 8; ++it) {
-            if constexpr (FAST) *reinterpret_cast<i32x4*>(cptr + (gi * 8 + it) * step4) = oo[it];
-            else store_row(gi * 8 + it, oo[it]);
+            *reinterpret_cast<i32x4*>(cptr + (gi * 8 + it) * step4) = oo[it];
           }
         }
       };
-      if (one_batch) {
-        if (p.gate_f32) {
-          if (full) pipelined(std::true_type{}, std::true_type{});
-          else pipelined(std::true_type{}, std::false_type{});
-        } else {
-          if (full) pipelined(std::false_type{}, std::true_type{});
-          else pipelined(std::false_type{}, std::false_type{});
-        }
+      if (one_batch && full) {
+        if (p.gate_f32) pipelined(std::true_type{}, std::true_type{});
+        else pipelined(std::false_type{}, std::true_type{});
       } else {
+        // edge tiles and waves whose rows straddle a batch boundary (rare): per-row gate vector, guarded stores, unpipelined
+        // (the double-buffered form with guarded stores ran out of registers: hipcc parked three of them in a0..a2)
         for (int it = 0; it < 32; ++it) {
           const int mc = min(m0 + wm * 128 + it * 4 + rsub, p.M - 1);
           float g8[8];
@@ -1329,18 +1352,6 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
           const i32x4 rv = res_row(it);
           store_row(it, p.gate_f32 ? combine(std::true_type{}, lds_row(it), g8, rv) : combine(std::false_type{}, lds_row(it), g8, rv));
         }
-      }
-    } else if (full) {
-      // whole tile: 16 LDS reads in flight, 16 unpredicated stores off one base pointer, twice
-      bf16_t* cptr = p.C + (int64_t)(m0 + wm * 128 + rsub) * p.ldc + ccol;
-      const int64_t step4 = 4 * p.ldc;
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        i32x4 v[16];
-#pragma unroll
-        for (int it = 0; it < 16; ++it) v[it] = lds_row(hf * 16 + it);
-#pragma unroll
-        for (int it = 0; it < 16; ++it) *reinterpret_cast<i32x4*>(cptr + (hf * 16 + it) * step4) = v[it];
       }
     } else {
 #pragma unroll

@@ -1,5 +1,6 @@
 """CPU-only: the C-ABI library loads and exports every symbol include/fastdm_amd.h declares,
 and the ctypes table mirrors the header.  No compute calls (no GPU here)."""
+import pytest
 import os
 import re
 
@@ -73,3 +74,23 @@ def test_ops_reject_cpu_tensors_loudly():
         ops.rms_norm(x, torch.ones(128, dtype=torch.bfloat16), 1e-6)
     with pytest.raises(RuntimeError):
         ops.quantize_to_fp8(x)
+
+
+@pytest.mark.parametrize("script", ["audit_gemm_asm.sh", "audit_attn_asm.sh"])
+def test_hand_scheduled_kernels_pass_their_asm_audit(script):
+    """gemm_w4_kernel and attn_fwd64_kernel keep accumulators in registers only their inline asm touches.  The audits compile the
+    kernels to assembly (hipcc cross-compiles without a GPU) and fail on any compiler-generated AGPR reference, scratch access
+    or real call in them -- a spill into a[..] corrupts accumulators silently, and did once reach a commit in a rarely taken edge
+    path before this test existed."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tools", "micro", script)
+    N.lib()                                           # (re)builds if the sources changed: build.sh leaves this build's device assembly
+    asm = os.path.join(root, "fastdm_amd", "_lib", ("gemm" if "gemm" in script else "attention") + ".gfx950.s")
+    env = dict(os.environ, FDM_AUDIT_ASM=asm) if os.path.exists(asm) else dict(os.environ)   # else the audit compiles (minutes)
+    r = subprocess.run(["bash", path], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

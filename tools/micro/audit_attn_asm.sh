@@ -7,9 +7,14 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 TMP=$(mktemp -d)
 cd "$TMP"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wno-unused-result -save-temps \
-    -c "$HERE/../../fastdm_amd/csrc/attention.hip" -o a.o 2> err.txt || { tail -20 err.txt; exit 1; }
-S=attention-hip-amdgcn-amd-amdhsa-gfx950.s
+# FDM_AUDIT_ASM=<file>: audit that assembly (build.sh leaves the library's own at fastdm_amd/_lib/attention.gfx950.s) instead of compiling
+if [ -n "$FDM_AUDIT_ASM" ]; then
+  S="$FDM_AUDIT_ASM"
+else
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wno-unused-result -save-temps \
+      -c "$HERE/../../fastdm_amd/csrc/attention.hip" -o a.o 2> err.txt || { tail -20 err.txt; exit 1; }
+  S=attention-hip-amdgcn-amd-amdhsa-gfx950.s
+fi
 # MASKED=1 audits the block-mask instantiation, HD=64 the head_dim-64 one
 K="_ZN3fdm17attn_fwd64_kernelILi${HD:-128}ELb${MASKED:-0}EEEvNS_10AttnParamsE"
 awk -v k="^$K:" '$0 ~ k {on=1} on {print} on && /^\.Lfunc_end/ {exit}' $S > k.s

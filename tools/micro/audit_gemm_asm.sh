@@ -4,9 +4,14 @@
 # into a[..] would silently corrupt accumulators).  Usage: tools/micro/audit_gemm_asm.sh [extra hipcc flags]
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
-OUT="${TMPDIR:-/tmp}/fdm_gemm_audit.s"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result "$@" -S --cuda-device-only \
-  "$HERE/../../fastdm_amd/csrc/gemm.hip" -o "$OUT" 2>/dev/null
+# FDM_AUDIT_ASM=<file>: audit that assembly (build.sh leaves the library's own at fastdm_amd/_lib/gemm.gfx950.s) instead of compiling
+if [ -n "$FDM_AUDIT_ASM" ]; then
+  OUT="$FDM_AUDIT_ASM"
+else
+  OUT="${TMPDIR:-/tmp}/fdm_gemm_audit.s"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result "$@" -S --cuda-device-only \
+    "$HERE/../../fastdm_amd/csrc/gemm.hip" -o "$OUT" 2>/dev/null
+fi
 python3 - "$OUT" <<'PY'
 import re, sys
 s = open(sys.argv[1]).read()
@@ -19,7 +24,7 @@ for kern in kerns:
     for l in body.split('\n'):
         if '#ASMSTART' in l: inasm = True; continue
         if '#ASMEND' in l: inasm = False; continue
-        if not inasm and (re.search(r'\ba\[?\d+', l) or 'accvgpr' in l or 'scratch_' in l): bad.append(l.strip())
+        if not inasm and (re.search(r'\ba\[?\d+', l) or 'accvgpr' in l or 'scratch_' in l or 's_swappc' in l): bad.append(l.strip())   # a real call (an un-inlined lambda) clobbers by ABI and brings scratch
     # hipcc's own LDS-DMAs must load M0 themselves (the asm DMAs leave their value in it)
     code, flags = [], []
     inasm = False
