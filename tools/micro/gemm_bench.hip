@@ -108,6 +108,7 @@ int main(int argc, char** argv) {
   hipMemset(fdm::g_gemm_stamps, 0, 2048 * 8 * 8);
 #endif
   const bool use_int8 = getenv("GEMM_DT") && !strcmp(getenv("GEMM_DT"), "int8");
+  const bool use_bf16 = getenv("GEMM_DT") && !strcmp(getenv("GEMM_DT"), "bf16");   // K counts bf16 elements (2 K bytes per row); the byte patterns of A / B are reinterpreted: cycle counts only
   int32_t *azp, *azp_adj;
   hipMalloc(&azp, 8704 * 4); hipMalloc(&azp_adj, 12288 * 4);
   hipMemset(azp, 0, 8704 * 4); hipMemset(azp_adj, 1, 12288 * 4);
@@ -115,6 +116,7 @@ int main(int argc, char** argv) {
   double tot = 0;
   for (auto& s : shapes) {
     auto run = [&]() {
+      if (use_bf16) return fdm_gemm_bf16(C, A, B, bias, s.M, s.N, s.K, s.K, s.K, s.N, s.epi, G, s.N, R, s.M, nullptr);
       if (use_int8) return fdm_gemm_w8a8_int8(C, A, B, sa, sb, azp_adj, azp, bias, s.M, s.N, s.K, s.K, s.K, s.N, s.epi, G, s.N, R, s.M, nullptr);
       return fdm_gemm_w8a8_fp8(C, A, B, sa, sb, bias, s.M, s.N, s.K, s.K, s.K, s.N, s.epi, G, s.N, R, s.M, nullptr);
     };
