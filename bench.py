@@ -52,6 +52,62 @@ def pmc_traffic(kernel):
         return None, f"no PMC record for this kernel ({type(e).__name__})"
 
 
+
+class _reference_cpu_ops:
+    """While the CPU baseline is timed the oracle's attention op is the reference torch backend's own call --
+    ``F.scaled_dot_product_attention`` on bf16 [B, H, S, D] views (/root/reference/fastdm/kernel/torch/attention.py:34-43) --
+    and its fp32 int8 accumulate instead of the oracle's per-head fp32 softmax loop and float64 int8 sums (oracle/ops.py, which exists to pin the arithmetic, not to be fast:
+    it is >= 5x slower and made the round-3 baseline pessimistic).  With this substitution the oracle is bit-exact against
+    the reference's fixtures (tests/test_oracle_golden.py::test_sdxl_tiny_unet_matches_reference)."""
+
+    def __enter__(self):
+        from oracle import ops as OPS
+        import torch.nn.functional as F
+
+        def torch_sdpa(query, key, value, hq, hk, hd, is_causal=False, scale=None, **_):
+            b, s, c = query.shape
+            q, k, v = (x.view(b, x.size(1), h, hd).transpose(1, 2) for x, h in ((query, hq), (key, hk), (value, hk)))
+            return F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=is_causal, scale=scale).transpose(1, 2).contiguous().view(b, s, c)
+
+        def int8_matmul_f32(a, b, scale_a, scale_b, out_dtype, azp_adj, azp, bias=None):
+            # the reference's own accumulate (/root/reference/fastdm/kernel/torch/matrixmul.py:67-74): fp32 products, where the
+            # oracle's checker form takes an exact float64 sum (about twice the CPU time)
+            acc = a.float() @ b.float() - azp.float() @ azp_adj.float()
+            out = (acc * (scale_a.float() * scale_b.reshape(1, -1).float())).to(out_dtype)
+            return out + bias if bias is not None else out
+        self._ops, self._saved = OPS, (OPS.scaled_dot_product_attention, OPS.int8_matmul)
+        OPS.scaled_dot_product_attention = torch_sdpa
+        OPS.int8_matmul = int8_matmul_f32
+        return self
+
+    def __exit__(self, *exc):
+        self._ops.scaled_dot_product_attention, self._ops.int8_matmul = self._saved
+        return False
+
+
+def _best_of(fn, reps=2):
+    """One untimed warm-up call (page-in, thread pool, oneDNN primitive caches), then the best of `reps` timed calls -- at the default
+    thread count and, on hosts with more than 32 threads, once more at 32 (a 128-thread oneDNN matmul of these sizes ran SLOWER than
+    8 threads of the build container: 7.4 s against 3.9 s for the same double block); the faster setting is kept and reported."""
+    best, out, best_threads = None, None, torch.get_num_threads()
+    default = torch.get_num_threads()
+    for threads in ([default, 32] if default > 32 else [default]):
+        torch.set_num_threads(threads)
+        fn()
+        for _ in range(reps if threads == default else 1):
+            t0 = time.perf_counter()
+            out = fn()
+            dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best, best_threads = dt, threads
+    torch.set_num_threads(best_threads)      # later legs start from the better setting
+    return best, out
+
+
+def _cpu_desc():
+    return {"cores": torch.get_num_threads(), "nproc": os.cpu_count()}
+
+
 def cpu_baseline_leg(height, width, n_txt, quant_tag):
     """The oracle (CPU restatement of the reference's torch backend) timed on this box's host cores
     on a bounded sample: ONE double-stream + ONE single-stream FLUX block at full width (S = 8704),
@@ -75,17 +131,15 @@ def cpu_baseline_leg(height, width, n_txt, quant_tag):
     ids = torch.zeros(n_img, 3)
     rope = OL.flux_rope_cache(torch.zeros(n_txt, 3), ids, cfg.axes_dims_rope)
     del inp
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        enc2, hid2 = dbl(hidden, enc, temb, rope)
-        t1 = time.perf_counter()
-        sgl(torch.cat([enc2, hid2], dim=1), temb, rope)
-        t2 = time.perf_counter()
-    step_s = 19 * (t1 - t0) + 38 * (t2 - t1)
-    return {"value": 1.0 / step_s, "unit": "it/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (torch-CPU restatement of the reference torch backend, {quant_tag}): 1 double block "
-                      f"{t1 - t0:.1f}s + 1 single block {t2 - t1:.1f}s at full width S={n_img + n_txt}, extrapolated x19/x38 "
-                      f"to one denoise step ({step_s:.0f}s)"}
+    with torch.no_grad(), _reference_cpu_ops():
+        t_dbl, (enc2, hid2) = _best_of(lambda: dbl(hidden, enc, temb, rope))
+        joint = torch.cat([enc2, hid2], dim=1)
+        t_sgl, _ = _best_of(lambda: sgl(joint, temb, rope))
+    step_s = 19 * t_dbl + 38 * t_sgl
+    return {"value": 1.0 / step_s, "unit": "it/s", **_cpu_desc(), "kind": "port",
+            "sample": f"oracle blocks with the reference torch backend's attention call (bf16 F.scaled_dot_product_attention), {quant_tag}: "
+                      f"1 double block {t_dbl:.2f}s + 1 single block {t_sgl:.2f}s at full width S={n_img + n_txt} (one warm-up, best of 2, "
+                      f"{torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs), extrapolated x19/x38 to one denoise step ({step_s:.0f}s)"}
 
 
 def spawn_ranks(n: int) -> int:
@@ -113,14 +167,13 @@ def cpu_baseline_qwen(height, width, n_txt, quant_tag):
     enc = torch.randn(1, n_txt, D, generator=g).to(torch.bfloat16)
     temb = torch.randn(1, D, generator=g).to(torch.bfloat16)
     rope = OQ.qwen_rope_cache([(1, h, w)], n_txt, cfg.axes_dims_rope)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        blk(hidden, enc, temb, rope)
-        dt = time.perf_counter() - t0
+    with torch.no_grad(), _reference_cpu_ops():
+        dt, _ = _best_of(lambda: blk(hidden, enc, temb, rope))
     step_s = dt * 60 * 2
-    return {"value": 1.0 / step_s, "unit": "it/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (torch-CPU restatement of the reference torch backend, {quant_tag}): 1 Qwen-Image block {dt:.1f}s at full width "
-                      f"S={h * w + n_txt}, extrapolated x60 blocks x2 CFG forwards to one denoise step ({step_s:.0f}s)"}
+    return {"value": 1.0 / step_s, "unit": "it/s", **_cpu_desc(), "kind": "port",
+            "sample": f"oracle block with the reference torch backend's attention call (bf16 F.scaled_dot_product_attention), {quant_tag}: "
+                      f"1 Qwen-Image block {dt:.2f}s at full width S={h * w + n_txt} (one warm-up, best of 2, {torch.get_num_threads()} threads of "
+                      f"{os.cpu_count()} logical CPUs), extrapolated x60 blocks x2 CFG forwards to one denoise step ({step_s:.0f}s)"}
 
 
 def cpu_baseline_sdxl(height, width, n_txt, quant_tag):
@@ -138,17 +191,16 @@ def cpu_baseline_sdxl(height, width, n_txt, quant_tag):
         sd = {n: OS.synth_tensor(n, sh, k, 0) for n, sh, k in OS._transformer(name, c, 1, cfg.cross_attention_dim)}
         blk = OS.BasicTransformerBlock(sd, f"{name}.transformer_blocks.0", c, cfg.head_dim, quant)
         x = torch.randn(2 * tokens, c, generator=g).to(torch.bfloat16)
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            blk(x, enc, 2)
-            times.append(time.perf_counter() - t0)
+        with torch.no_grad(), _reference_cpu_ops():
+            times.append(_best_of(lambda: blk(x, enc, 2))[0])
     n1 = cfg.transformer_layers[0] * 5                      # 2 down + 3 up attentions at level 1
     n2 = cfg.transformer_layers[1] * 5 + cfg.mid_layers     # 2 down + 3 up at level 2, + the mid block
     step_s = times[0] * n1 + times[1] * n2
-    return {"value": 1.0 / step_s, "unit": "it/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (torch-CPU restatement of the reference torch backend, {quant_tag}): 1 transformer layer at 640 channels "
-                      f"{times[0]:.1f}s + 1 at 1280 channels {times[1]:.1f}s, CFG batch 2, {height}x{width}, extrapolated x{n1}/x{n2} layers "
-                      f"to one UNet forward ({step_s:.0f}s; convolutions / group norms not included)"}
+    return {"value": 1.0 / step_s, "unit": "it/s", **_cpu_desc(), "kind": "port",
+            "sample": f"oracle layers with the reference torch backend's attention call (bf16 F.scaled_dot_product_attention), {quant_tag}: "
+                      f"1 transformer layer at 640 channels {times[0]:.2f}s + 1 at 1280 channels {times[1]:.2f}s, CFG batch 2, {height}x{width} "
+                      f"(one warm-up, best of 2, {torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs), extrapolated x{n1}/x{n2} layers "
+                      f"to one UNet forward ({step_s:.1f}s; convolutions / group norms not included)"}
 
 
 _RESULT_FD = None

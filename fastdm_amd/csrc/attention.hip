@@ -39,11 +39,14 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #ifndef FDM_ATT_V2
 #define FDM_ATT_V2 1
 #endif
-// A/B build (tools/micro, tests): Q is pre-scaled by a power of two only (exact in bf16) and the rest of scale * log2(e) is
-// applied in fp32 to the scores -- the reference's arithmetic -- at one extra VALU per score.  Prices the bf16 rounding of the
-// pre-scaled Q that the shipped kernel takes.
+// 1 (default since round 4): Q is pre-scaled by a power of two only (exact in bf16) and the rest of scale * log2(e) (1.0202 at
+// head_dim 128) is applied in fp32 to the scores in front of every exp2 -- the reference's arithmetic (scale on fp32 scores,
+// fastdm/kernel/torch/attention.py:34-43) -- at one extra v_mul_f32 per score: +3.9 % kernel time (843.5 -> 876.5 us at C3, one
+// process, profiles/r04_experiments.md; the same factor as v_pk_mul_f32 on register pairs: +10.5 %, packed fp32 beside MFMAs is
+// an anti-lever).  0: Q * scale * log2(e) rounded to bf16 once more (rounds 2-3): the first FLUX block then sits at 1.67 x (fp8) /
+// 1.42 x (bf16) of the two-implementation envelope instead of 1.32 x / 1.08 x.
 #ifndef FDM_ATT_EXACT_Q
-#define FDM_ATT_EXACT_Q 0
+#define FDM_ATT_EXACT_Q 1
 #endif
 #ifndef FDM_ATT_THREADS
 #define FDM_ATT_THREADS 512
@@ -66,7 +69,7 @@ struct AttnParams {
   int mask_bq, mask_bk, mask_nq, mask_nk;
   float scale_log2e;
   float q_prescale;   // what Q is multiplied by before its bf16 rounding (= scale_log2e; FDM_ATT_EXACT_Q: the nearest power of two)
-  float exp_r;        // FDM_ATT_EXACT_Q: scale_log2e / q_prescale, applied in fp32 in front of every exp2 (A/B build only)
+  float exp_r;        // FDM_ATT_EXACT_Q: scale_log2e / q_prescale, applied in fp32 in front of every exp2
   // split-KV tail balancing: block ids >= n_full are parts of tail q-blocks (S parts each, consecutive KV ranges)
   int n_full, split;
   float* ws_o;   // [tail part][256 rows][D] unnormalised fp32 O
@@ -421,9 +424,11 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
 //   schedule  hipcc left alone moves whole tiles between the two register classes (2300 v_accvgpr moves), so the MFMAs
 //             are inline asm with fixed classes and the issue order is pinned with sched_barrier(0) per MFMA gap:
 //             gap = 1 MFMA + <= 1 v_exp_f32 + a few plain VALU + <= 2 LDS reads (or one LDS-DMA).
-//   softmax   Q is pre-scaled by scale*log2(e) once per block and the S^T accumulators START at -m_ref[q] (the C operand
-//             of the first MFMA of a tile is a register tile holding the row reference), so P = exp2(S') needs no
-//             per-element FMA.  m_ref = (row max at the last fix-up) + 7: P <= 2 between fix-ups.  The row max of tile
+//   softmax   Q is pre-scaled once per block -- by the power of two nearest to scale*log2(e), exact in bf16; the remaining factor
+//             r (1.0202 at head_dim 128) multiplies the fp32 scores in front of exp2 (FDM_ATT_EXACT_Q; rounds 2-3 rounded
+//             Q*scale*log2(e) to bf16 instead and saved that multiply) -- and the S^T accumulators START at -m_ref[q] (the C
+//             operand of the first MFMA of a tile is a register tile holding the row reference), so P = exp2(r S') needs no
+//             per-element subtraction.  m_ref = (row max at the last fix-up) + 7: P <= 2 between fix-ups.  The row max of tile
 //             t+1 is taken under the P.V MFMAs of tile t; only if some row's S' reaches 1 (its scores grew by 2^8 since
 //             the last fix-up), on the first tile and on a masked tail tile does the wave take the fix-up path
 //             (integer shift delta: S' -= delta, O and l scaled by 2^-delta -- exact -- and the reference tile rewritten).
@@ -610,7 +615,8 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
     static_for<4>([&](auto i) { dma_v(src, last, decltype(s_)::value, i); });
   });
 
-  // ---- Q fragments, pre-scaled by scale * log2(e) (one extra bf16 rounding of q), parked in accumulation registers
+  // ---- Q fragments, pre-scaled by p.q_prescale (a power of two: exact in bf16; FDM_ATT_EXACT_Q = 0: scale * log2(e), one extra
+  //      bf16 rounding of q), parked in accumulation registers
   i32x4 qa[2][KSTEPS];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {

@@ -23,6 +23,11 @@ for f in gemm attention; do   # (best effort: the audit falls back to compiling 
   [ -f "$OUT/$f-hip-amdgcn-amd-amdhsa-gfx950.s" ] && mv -f "$OUT/$f-hip-amdgcn-amd-amdhsa-gfx950.s" "$OUT/$f.gfx950.s" || rm -f "$OUT/$f.gfx950.s"
   rm -f "$OUT/$f"-hip-amdgcn-amd-amdhsa-gfx950.* "$OUT/$f"-host-x86_64-unknown-linux-gnu.* "$OUT/$f".hip-hip-amdgcn-amd-amdhsa.hipfb
 done
+# the hand-scheduled kernels' register audits run on exactly this build's assembly; a failing audit fails the build
+if [ -z "$FDM_SKIP_AUDIT" ]; then
+  FDM_AUDIT_ASM="$OUT/gemm.gfx950.s" bash "$HERE/../../tools/micro/audit_gemm_asm.sh" > "$OUT/audit_gemm.log" 2>&1 || { cat "$OUT/audit_gemm.log"; echo "audit_gemm_asm.sh FAILED (FDM_SKIP_AUDIT=1 builds anyway)"; exit 1; }
+  FDM_AUDIT_ASM="$OUT/attention.gfx950.s" bash "$HERE/../../tools/micro/audit_attn_asm.sh" > "$OUT/audit_attn.log" 2>&1 || { cat "$OUT/audit_attn.log"; echo "audit_attn_asm.sh FAILED (FDM_SKIP_AUDIT=1 builds anyway)"; exit 1; }
+fi
 # link under a temporary name and rename: a process that has the old library mapped (another rank, another job) keeps its inode
 # instead of seeing a truncated file
 TMP_SO="$OUT/.libfastdm_amd.so.$$"

@@ -152,7 +152,9 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, uint8_t* lds_wave_ba
 // pointer, keeps a VGPR PAIR per DMA alive.
 __device__ __forceinline__ void glds16_sv(const uint8_t* sbase, uint32_t voff, uint32_t lds_addr) {
   // M0 is written and read inside this statement and NOT restored: hipcc's own LDS-DMAs (the builtin, tail path) set M0
-  // themselves right before each use (tools/micro/audit_gemm_asm.sh checks that), nothing else in these kernels reads it.
+  // themselves right before each use, nothing else in these kernels reads it.  (An "m0" clobber -- ADVICE r3 -- is not honoured by
+  // hipcc 7.2: "reserved registers on the clobber list may not be preserved", one warning per statement; what holds the property
+  // is tools/micro/audit_gemm_asm.sh, which build.sh now runs on every build's own assembly and which fails the build.)
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" : : "s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const uint8_t* p) {
@@ -534,34 +536,40 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
         if (p.azp != nullptr) azpm[i] = p.azp[mc];
       }
     }
-    // per-column operands of all 8 column groups, requested before any of them is used (inside the loop below every load sat
-    // in front of its first use: 8 exposed L2 round trips per tile)
+    // per-column operands, requested before any of them is used (inside the loop below every load sat in front of its first use:
+    // 8 exposed L2 round trips per tile).  Kernels without a residual epilogue request all 8 column groups up front; the RES
+    // instantiations (whose gate / residual state is live too) request them one 32-column half at a time -- with all 8 live beside
+    // the 128 accumulator registers hipcc spilled 111 VGPRs (236 B of scratch per lane) in the fp8 kernel, 13 / 12 in int8 / bf16.
     f32x4 sbv[8];
     i32x2 biasv[8];
     i32x4 adjv[8];
     const bool has_bias = p.bias != nullptr;
+    auto load_cols = [&](int jq0, int jq1) {
 #pragma unroll
-    for (int jq = 0; jq < 8; ++jq) {
-      const int nc = min(n0 + wn * 64 + (jq >> 2) * 32 + 8 * (jq & 3) + 4 * g, p.N - 4);
-      sbv[jq] = f32x4{1.f, 1.f, 1.f, 1.f};
-      biasv[jq] = i32x2{0, 0};
-      adjv[jq] = i32x4{0, 0, 0, 0};
-      if constexpr (DT != DT_BF16) sbv[jq] = *reinterpret_cast<const f32x4*>(p.sb + nc);
-    }
-    if (has_bias) {
-#pragma unroll
-      for (int jq = 0; jq < 8; ++jq)
-        biasv[jq] = *reinterpret_cast<const i32x2*>(p.bias + min(n0 + wn * 64 + (jq >> 2) * 32 + 8 * (jq & 3) + 4 * g, p.N - 4));
-    }
-    if constexpr (DT == DT_INT8) {
-      if (p.azp_adj != nullptr) {
-#pragma unroll
-        for (int jq = 0; jq < 8; ++jq)
-          adjv[jq] = *reinterpret_cast<const i32x4*>(p.azp_adj + min(n0 + wn * 64 + (jq >> 2) * 32 + 8 * (jq & 3) + 4 * g, p.N - 4));
+      for (int jq = jq0; jq < jq1; ++jq) {
+        const int nc = min(n0 + wn * 64 + (jq >> 2) * 32 + 8 * (jq & 3) + 4 * g, p.N - 4);
+        sbv[jq] = f32x4{1.f, 1.f, 1.f, 1.f};
+        biasv[jq] = i32x2{0, 0};
+        adjv[jq] = i32x4{0, 0, 0, 0};
+        if constexpr (DT != DT_BF16) sbv[jq] = *reinterpret_cast<const f32x4*>(p.sb + nc);
       }
-    }
+      if (has_bias) {
+#pragma unroll
+        for (int jq = jq0; jq < jq1; ++jq)
+          biasv[jq] = *reinterpret_cast<const i32x2*>(p.bias + min(n0 + wn * 64 + (jq >> 2) * 32 + 8 * (jq & 3) + 4 * g, p.N - 4));
+      }
+      if constexpr (DT == DT_INT8) {
+        if (p.azp_adj != nullptr) {
+#pragma unroll
+          for (int jq = jq0; jq < jq1; ++jq)
+            adjv[jq] = *reinterpret_cast<const i32x4*>(p.azp_adj + min(n0 + wn * 64 + (jq >> 2) * 32 + 8 * (jq & 3) + 4 * g, p.N - 4));
+        }
+      }
+    };
+    if constexpr (!RES) load_cols(0, 8);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      if constexpr (RES) load_cols(j * 4, j * 4 + 4);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float bias4[4];
@@ -667,44 +675,37 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
 #endif
       bf16_t* cptr = p.C + (int64_t)(m0 + wm * 128 + rsub) * p.ldc + ccol;
       const int64_t step8 = 8 * p.ldc;
-      auto pipelined = [&](auto f32_c, auto fast_c) {
-        // loads(h0) | combine(h0) | loads(h1) | stores(h0) | combine(h1) | stores(h1): every load precedes every store.
-        // FAST (whole tile): unpredicated stores off one base pointer -- the guarded store re-reads M / ldc / C per row.
-        constexpr bool FAST = decltype(fast_c)::value;
-        auto put = [&](int it, const i32x4& v) {
-          if constexpr (FAST) *reinterpret_cast<i32x4*>(cptr + it * step8) = v;
-          else store_row(it, v);
-        };
+      const bf16_t* rptr = p.res + (int64_t)(m0 + wm * 128 + rsub) * p.ldc + ncc;
+      auto pipelined = [&](auto f32_c) {
+        // whole tiles only (unpredicated loads / stores off two base pointers).  Groups of 4 row-instructions: loads(g + 1) run one
+        // group ahead of combine(g) + stores(g); every load of a group precedes the stores of the previous one in program order
+        // (vmcnt retires in order).  The earlier two-halves form (8 + 8 rows, four 8-quad arrays and a 64-bit address per row live
+        // beside them) is what hipcc spilled in this kernel: 111 VGPRs, 236 B of scratch per lane.
         float g8[8];
         load_gate(m_first / p.rows_per_batch, g8);
-        i32x4 r0[8], o0[8], r1[8], o1[8];
+        i32x4 rr[2][4], oo[4];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) r0[it] = res_row(it);
+        for (int it = 0; it < 4; ++it) rr[0][it] = *reinterpret_cast<const i32x4*>(rptr + it * step8);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) o0[it] = combine(f32_c, lds_row(it), g8, r0[it]);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        for (int gi = 0; gi < 4; ++gi) {
+          if (gi < 3) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) r1[it] = res_row(8 + it);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+            for (int it = 0; it < 4; ++it) rr[(gi + 1) & 1][it] = *reinterpret_cast<const i32x4*>(rptr + ((gi + 1) * 4 + it) * step8);
+          }
 #pragma unroll
-        for (int it = 0; it < 8; ++it) put(it, o0[it]);
+          for (int it = 0; it < 4; ++it) oo[it] = combine(f32_c, lds_row(gi * 4 + it), g8, rr[gi & 1][it]);
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) o1[it] = combine(f32_c, lds_row(8 + it), g8, r1[it]);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) put(8 + it, o1[it]);
-      };
-      if (one_batch) {
-        if (p.gate_f32) {
-          if (fast) pipelined(std::true_type{}, std::true_type{});
-          else pipelined(std::true_type{}, std::false_type{});
-        } else {
-          if (fast) pipelined(std::false_type{}, std::true_type{});
-          else pipelined(std::false_type{}, std::false_type{});
+          for (int it = 0; it < 4; ++it) *reinterpret_cast<i32x4*>(cptr + (gi * 4 + it) * step8) = oo[it];
         }
+      };
+      if (one_batch && fast) {
+        if (p.gate_f32) pipelined(std::true_type{});
+        else pipelined(std::false_type{});
       } else {
-        // the wave's 128 rows straddle a batch boundary (rare): per-row gate vector, unpipelined
+        // edge tiles and waves whose 128 rows straddle a batch boundary: per-row gate vector, guarded stores, unpipelined
+        // (every kernel of this file has a zero private segment: tests/test_abi.py)
         for (int it = 0; it < 16; ++it) {
           const int mc = min(m0 + wm * 128 + it * 8 + rsub, p.M - 1);
           float g8[8];
@@ -797,11 +798,15 @@ struct Mma16<DT_FP8> {
   using Acc = f32x4;
   static constexpr int KS = 128;  // bytes of K per MFMA
   using Frag = i32x8;
-  template <int IDX>
+  template <int IDX, bool ZERO = false>
   static __device__ __forceinline__ void run(const Frag& a, const Frag& b) {   // unit E8M0 scales (0x7f = 2^0) for both operands
     const int one = 0x7f7f7f7f;
-    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 a[%c2:%c3], %0, %1, a[%c2:%c3], %4, %4 op_sel_hi:[0,0,0]" ::"v"(a), "v"(b),
-                 "n"(4 * IDX), "n"(4 * IDX + 3), "v"(one));
+    if constexpr (ZERO)   // a tile's first K step: C = 0 as an inline constant (the 256 accumulator registers are never zeroed)
+      asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 a[%c2:%c3], %0, %1, 0, %4, %4 op_sel_hi:[0,0,0]" ::"v"(a), "v"(b),
+                   "n"(4 * IDX), "n"(4 * IDX + 3), "v"(one));
+    else
+      asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 a[%c2:%c3], %0, %1, a[%c2:%c3], %4, %4 op_sel_hi:[0,0,0]" ::"v"(a), "v"(b),
+                   "n"(4 * IDX), "n"(4 * IDX + 3), "v"(one));
   }
 };
 template <>
@@ -809,9 +814,10 @@ struct Mma16<DT_INT8> {
   using Acc = i32x4;
   static constexpr int KS = 64;
   using Frag = i32x4;
-  template <int IDX>
+  template <int IDX, bool ZERO = false>
   static __device__ __forceinline__ void run(const Frag& a, const Frag& b) {
-    asm volatile("v_mfma_i32_16x16x64_i8 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(4 * IDX), "n"(4 * IDX + 3));
+    if constexpr (ZERO) asm volatile("v_mfma_i32_16x16x64_i8 a[%c2:%c3], %0, %1, 0" ::"v"(a), "v"(b), "n"(4 * IDX), "n"(4 * IDX + 3));
+    else asm volatile("v_mfma_i32_16x16x64_i8 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(4 * IDX), "n"(4 * IDX + 3));
   }
 };
 template <>
@@ -819,9 +825,10 @@ struct Mma16<DT_BF16> {
   using Acc = f32x4;
   static constexpr int KS = 64;
   using Frag = i32x4;
-  template <int IDX>
+  template <int IDX, bool ZERO = false>
   static __device__ __forceinline__ void run(const Frag& a, const Frag& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(4 * IDX), "n"(4 * IDX + 3));
+    if constexpr (ZERO) asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0" ::"v"(a), "v"(b), "n"(4 * IDX), "n"(4 * IDX + 3));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(4 * IDX), "n"(4 * IDX + 3));
   }
 };
 // accumulator block IDX as raw 32-bit words (float bits for fp8 / bf16, int32 for int8)
@@ -991,10 +998,10 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
   };
 
   // accumulator block [mb][nb] = a[4 (8 mb + nb) ..]: lane (fi, fq) holds C[m = mb * 16 + fi][n = nb * 16 + fq * 4 + 0..3].
-  // This statement (clobbering every AGPR) is also what makes the kernel descriptor allocate a[0:255].
-  asm volatile(
-      ".set fdm_i, 0\n\t.rept 256\n\tv_accvgpr_write_b32 a[fdm_i], 0\n\t.set fdm_i, fdm_i + 1\n\t.endr" ::
-          : FDM_ACLOB_ALL);
+  // The accumulators are never zeroed: the MFMAs of a tile's first K step take C = 0 as an inline constant (256 v_accvgpr_write
+  // in front of the first DMA were ~1 k cycles of every tile's prologue).  This empty statement, clobbering every AGPR, is what
+  // makes the kernel descriptor allocate a[0:255].
+  asm volatile("" ::: FDM_ACLOB_ALL);
 
   // int8 split-K tail, merge launch: accumulators = sum of the parts' int32 partials (exact), no K loop
   bool merged = false;
@@ -1089,7 +1096,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
         __builtin_amdgcn_sched_barrier(0);
         static_for<NS * 8>([&](auto jc) {
           constexpr int s = decltype(jc)::value / 8, nb = decltype(jc)::value % 8;
-          M::template run<g * 8 + nb>(bc[s][nb], fa[g & 1][s]);   // swapped operands: MFMA rows = n, columns = m
+          M::template run<g * 8 + nb, decltype(first_c)::value && s == 0>(bc[s][nb], fa[g & 1][s]);   // swapped operands: MFMA rows = n, columns = m
           // The 16 DMAs that follow step t's barrier are spread thinly: a burst from all four waves queues on the CU's one
           // load path and the waves then meet skewed at the next barrier (21 % of the loop, measured).  4 in group 7 of step t,
           // 3 in each of groups 0..3 of step t + 1 -- all land well before that step's barrier.
@@ -1375,6 +1382,64 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
 #endif
 }
 
+// =====================================================================================================================
+// gemm_p4_kernel: the PERSISTENT form of gemm_w4_kernel for fp8 launches of whole tiles and more than one round -- one block per CU
+// walks its tiles; one continuous K-step stream across tile seams (no per-tile prologue); tile i's accumulators are read out,
+// scaled, rounded and stored under the first K step of tile i + 1.  The body is hand-written gfx950 assembly, generated by
+// gen_gemm_p4.py (read its header): every one of the 512 vector registers is assigned by hand, which is what the C++ attempt of
+// round 3 could not get from hipcc.  Same MFMAs in the same order and the same epilogue arithmetic as gemm_w4_kernel: outputs are
+// bit-identical to it.
+struct P4Prob {
+  const void* A;
+  const void* B;
+  void* C;
+  const float* sa;
+  const float* sb;
+  const void* bias;
+  const void* gate;
+  const void* res;
+};
+struct P4Args {           // offsets are part of the assembly's contract (gen_gemm_p4.py ARG_*)
+  P4Prob p[2];            //   0, 64
+  uint32_t tiles_m0, tiles_m1, tiles_n, t0_tiles;              // 128
+  uint32_t total_tiles, nk, lda, ldb;                          // 144
+  uint32_t ldc_bytes, plane_cols, plane_stride_bytes, blocks_per_xcd;  // 160 (grid = 8 * blocks_per_xcd)
+  uint32_t pad[4];
+};
+static_assert(sizeof(P4Args) == 192, "P4Args layout is read by offset in gemm_p4_body_*.inc");
+__device__ __attribute__((aligned(256))) uint8_t g_zero_bias[65536] = {0};   // bias == nullptr: 32 K columns of bf16 zeros
+static const void* g_zero_bias_ptr() {      // device address of g_zero_bias, per device (looked up once per device)
+  static const void* ptr[64] = {nullptr};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev = dev < 0 || dev > 63 ? 0 : dev;
+  if (!ptr[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_bias)) != hipSuccess) return nullptr;
+    ptr[dev] = p;
+  }
+  return ptr[dev];
+}
+
+#ifndef FDM_P4_BODY_NONE
+#define FDM_P4_BODY_NONE "gemm_p4_body_none.inc"     // (bring-up builds point this at a generator variant)
+#endif
+template <int EPI>
+__global__ void __launch_bounds__(W4_THREADS, 1) gemm_p4_kernel(const P4Args args) {
+  __shared__ __attribute__((aligned(1024))) uint8_t smem[160 * 1024];   // 128 KiB ring + 4 x 8 KiB epilogue strips
+  const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+  const uint32_t lds0 = lds_addr_of(smem);
+  if constexpr (EPI == FDM_EPI_NONE) {
+    asm volatile(
+#include FDM_P4_BODY_NONE
+        :
+        : "s"(ka), "s"(blockIdx.x), "v"(threadIdx.x), "s"(lds0)
+        :
+#include "gemm_p4_clobbers.inc"
+    );
+  }
+}
+
 // Which tile kernel runs a launch.  Both compute the same 256 x 256 tiles (int8: bit-identical; fp8 / bf16: identical except for
 // the fp32 summation order inside the MFMA shapes, <= 1-2 bf16 ulp on ~1e-6 of the elements).  Measured inside whole denoise steps
 // on MI355X (bench.py A/B on one box, profiles/r03_experiments.md): gemm_w4_kernel everywhere it applies is 102.9-103.3 ms per
@@ -1420,6 +1485,65 @@ static bool use_w4(const GemmGroup& grp) {
 #ifdef FDM_GEMM_STAMPS
 unsigned long long* g_gemm_stamps = nullptr;  // >= 4 * grid words, set by the micro-benchmark
 #endif
+
+// Does the persistent assembly kernel run this launch?  fp8, every problem made of whole 256 x 256 tiles and an even number (>= 6)
+// of 128-byte K steps, more tiles than CUs (a one-round launch has no next tile to hide anything under), the epilogues the
+// assembly implements, and -- for two problems in one launch -- the same shape parameters except M and the pointers (the FLUX
+// image + text pairs are like that).  FDM_GEMM_KERNEL = p4 | w4 | w8 | auto; FDM_GEMM_P4 = 0 switches the persistent kernel off.
+#ifdef FDM_GEMM_AB
+int g_gemm_use_p4 = 0;   // micro-benchmark builds: 0 / 1
+#endif
+static bool use_p4(const GemmGroup& grp, P4Args& pa) {
+#ifdef FDM_GEMM_AB
+  if (!g_gemm_use_p4) return false;
+#else
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("FDM_GEMM_P4");
+    const char* k = getenv("FDM_GEMM_KERNEL");
+    on = (e && e[0] == '1') || (k && !strcmp(k, "p4")) ? 1 : 0;      // (bring-up: opt-in until the parity tests are green)
+  }
+  if (!on) return false;
+#endif
+#ifdef FDM_GEMM_AB
+  if (grp.total_tiles < device_cu_count() || grp.splits > 1 || grp.mode != 0) return false;   // (bring-up: also the one-tile-per-block case)
+#else
+  if (grp.total_tiles <= device_cu_count() || grp.splits > 1 || grp.mode != 0) return false;
+#endif
+  const GemmProblem& a = grp.p[0];
+  for (int i = 0; i < grp.n; ++i) {
+    const GemmProblem& q = grp.p[i];
+    if (q.epi != FDM_EPI_NONE) return false;
+    if ((q.M % BM) || (q.N % BN) || (q.Kb % 256) || q.Kb < 768) return false;
+    if (q.N != a.N || q.Kb != a.Kb || q.lda != a.lda || q.ldb != a.ldb || q.ldc != a.ldc || q.plane_cols != a.plane_cols ||
+        q.plane_stride != a.plane_stride)
+      return false;
+    if ((int64_t)q.M * q.lda >= (1ll << 32) || (int64_t)q.N * q.ldb >= (1ll << 32) || q.ldc * 2 >= (1ll << 31) || q.N > 32768) return false;
+    if (q.plane_cols > 0 && (q.plane_cols % BN)) return false;       // a tile never straddles two planes
+    if (!q.sa || !q.sb) return false;
+  }
+  memset(&pa, 0, sizeof(pa));
+  for (int i = 0; i < 2; ++i) {
+    const GemmProblem& q = grp.p[i < grp.n ? i : 0];
+    pa.p[i] = P4Prob{q.A, q.B, q.C, q.sa, q.sb, q.bias ? (const void*)q.bias : g_zero_bias_ptr(), q.gate, q.res};
+    if (!pa.p[i].bias) return false;
+  }
+  pa.tiles_m0 = a.tiles_m;
+  pa.tiles_m1 = grp.n > 1 ? grp.p[1].tiles_m : 0;
+  pa.tiles_n = a.tiles_n;
+  pa.t0_tiles = a.tiles_m * a.tiles_n;
+  pa.total_tiles = grp.total_tiles;
+  pa.nk = (uint32_t)(a.Kb / 128);
+  pa.lda = (uint32_t)a.lda;
+  pa.ldb = (uint32_t)a.ldb;
+  pa.ldc_bytes = (uint32_t)(a.ldc * 2);
+  pa.plane_cols = (uint32_t)a.plane_cols;
+  if ((uint64_t)a.plane_stride * 2 >= (1ull << 32)) return false;
+  pa.plane_stride_bytes = (uint32_t)(a.plane_stride * 2);
+  pa.blocks_per_xcd = (uint32_t)(device_cu_count() / 8);
+  if (pa.blocks_per_xcd == 0 || grp.total_tiles < (int)(8 * pa.blocks_per_xcd)) return false;
+  return true;
+}
 
 constexpr int64_t SPLIT_PART_BYTES = (int64_t)BM * BN * 4;   // one K part of one tile: 256 x 256 int32
 
@@ -1482,6 +1606,14 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, 
         if (res) gemm_kernel<DT, true><<<rem << g2.spread_shift, GEMM_THREADS, 0, s>>>(g2);
         else gemm_kernel<DT, false><<<rem << g2.spread_shift, GEMM_THREADS, 0, s>>>(g2);
       }
+      FDM_CHECK_LAUNCH();
+      return FDM_OK;
+    }
+  }
+  if constexpr (DT == DT_FP8) {
+    P4Args pa;
+    if (use_p4(grp, pa)) {
+      gemm_p4_kernel<FDM_EPI_NONE><<<8 * pa.blocks_per_xcd, W4_THREADS, 0, s>>>(pa);
       FDM_CHECK_LAUNCH();
       return FDM_OK;
     }

@@ -18,9 +18,13 @@ from fastdm_amd.layer.qlinear import QLinear
 
 
 def checkpoint_fingerprint(model_path) -> str:
-    """Identity of a checkpoint WITHOUT reading its tensor bytes: sorted tensor names, shapes and dtypes, plus
-    * files / shard directories: every weight file's base name and size, the safetensors header (names, shapes, dtypes, data offsets)
-      and the first / last 64 KiB of the file -- no mtime, no directory part, so a copied or re-mounted checkpoint keeps it;
+    """Identity of a checkpoint WITHOUT reading all of its tensor bytes: sorted tensor names, shapes and dtypes, plus
+    * files / shard directories: every weight file's path RELATIVE to the checkpoint root and its size, the safetensors header
+      (names, shapes, dtypes, data offsets) and 4 KiB samples from the head, middle and tail of EVERY tensor's bytes at its header
+      offsets (a partial fine-tune or a merged LoRA keeps layout, header and size but rewrites whole matrices: sampling only the
+      ends of the file missed it); .bin files: 64 KiB every 16 MiB.  No mtime and no absolute directory, so a copied
+      or re-mounted checkpoint keeps its fingerprint; files are ordered by relative path, so same-named shards in different
+      sub-directories (transformer/ and vae/) have a defined order on every filesystem;
     * in-memory state_dicts: the dict's own `fingerprint` attribute when it has one (the lazily generated synthetic
       checkpoints expose their seed that way), otherwise a hash of the first 64 KiB of every tensor.
     Stored in a pre-quantised cache file and compared on every later load that still names a checkpoint, so a cache written
@@ -45,7 +49,6 @@ def checkpoint_fingerprint(model_path) -> str:
                 flat = t.detach().reshape(-1)[:32768].contiguous().cpu()
                 h.update(flat.view(torch.uint8).numpy().tobytes())
         return h.hexdigest()
-    from safetensors import safe_open
     import json
     import struct
     model_path = os.path.normpath(model_path)          # 'ckpt/' and 'ckpt' are the same checkpoint
@@ -53,25 +56,34 @@ def checkpoint_fingerprint(model_path) -> str:
     if os.path.isdir(model_path):
         for root, _, names in os.walk(model_path):
             files += [os.path.join(root, n) for n in names if n.endswith((".safetensors", ".bin"))]   # not *.safetensors.index.json
+        rel = {f: os.path.relpath(f, model_path).replace(os.sep, "/") for f in files}
     else:
         files = [model_path]
-    for f in sorted(files, key=os.path.basename):
-        # basename + size + (safetensors) the header itself -- tensor names, shapes, dtypes AND data offsets -- + the first and last
-        # 64 KiB of tensor bytes.  No mtime, no directory part: a copied / rsynced / re-mounted checkpoint keeps its fingerprint.
-        add(os.path.basename(f), os.path.getsize(f))
+        rel = {model_path: os.path.basename(model_path)}
+    SAMPLE = 4096
+    for f in sorted(files, key=rel.get):
+        size = os.path.getsize(f)
+        add(rel[f], size)
         with open(f, "rb") as fh:
             if f.endswith(".safetensors"):
                 n = struct.unpack("<Q", fh.read(8))[0]
                 header = fh.read(n)
                 h.update(hashlib.sha256(header).digest())
                 meta = json.loads(header)
+                base = 8 + n
                 for k in sorted(k for k in meta if k != "__metadata__"):
                     add(k, tuple(meta[k]["shape"]), meta[k]["dtype"])
-            h.update(fh.read(65536))
-            size = os.path.getsize(f)
-            if size > 131072:
-                fh.seek(size - 65536)
-                h.update(fh.read(65536))
+                    lo, hi = meta[k]["data_offsets"]
+                    for off in sorted({lo, max(lo, (lo + hi) // 2 - SAMPLE // 2), max(lo, hi - SAMPLE)}):
+                        fh.seek(base + off)
+                        h.update(fh.read(min(SAMPLE, hi - off)))
+            else:
+                for off in range(0, size, 16 << 20):
+                    fh.seek(off)
+                    h.update(fh.read(65536))
+                if size > 65536:
+                    fh.seek(size - 65536)
+                    h.update(fh.read(65536))
     return h.hexdigest()
 
 
@@ -153,7 +165,7 @@ class BaseModelCore:
     _qc_in = None
     _qc_out = None
     _qc_keys = frozenset()
-    QC_FORMAT = "fastdm_amd-quantized-v2"      # v2: + checkpoint fingerprint and activation dtype in the metadata
+    QC_FORMAT = "fastdm_amd-quantized-v3"      # v2: + checkpoint fingerprint and activation dtype in the metadata; v3: the fingerprint samples every tensor
 
     def weight_loading(self, model_path, data_type=torch.bfloat16, device_type="cuda", quantized_cache=None, verify_against=None):
         """basemodel.py:88-143, plus the pre-quantised cache described in the module docstring.  With an existing cache file
@@ -167,7 +179,11 @@ class BaseModelCore:
             from safetensors import safe_open
             self._qc_in = safe_open(quantized_cache, framework="pt")
             meta = self._qc_in.metadata() or {}
-            if meta.get("format") != self.QC_FORMAT or meta.get("model") != type(self).__name__:
+            fmt = str(meta.get("format"))
+            if fmt != self.QC_FORMAT and fmt.startswith("fastdm_amd-quantized-"):
+                raise ValueError(f"{quantized_cache}: stale cache format {fmt} (this build writes {self.QC_FORMAT}): delete the file and "
+                                 "re-quantise from the checkpoint")
+            if fmt != self.QC_FORMAT or meta.get("model") != type(self).__name__:
                 raise ValueError(f"{quantized_cache}: not a {self.QC_FORMAT} file for {type(self).__name__} ({meta})")
             if meta.get("dtype") != str(data_type):
                 raise ValueError(f"{quantized_cache} was written for {meta.get('dtype')} activations, the model runs in {data_type}")

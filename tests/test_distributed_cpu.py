@@ -256,3 +256,51 @@ def test_checkpoint_fingerprint_survives_copy_and_ignores_index_json(tmp_path):
     assert one != fp and one == checkpoint_fingerprint(str(b / "model-00001-of-00002.safetensors"))
     save_file({"w1": torch.randn(16, 8, generator=g).to(torch.bfloat16)}, str(b / "model-00002-of-00002.safetensors"))   # other weights, same shapes
     assert checkpoint_fingerprint(str(b)) != fp
+
+
+def test_checkpoint_fingerprint_sees_an_interior_tensor_and_orders_subdirectories(tmp_path):
+    """a partial fine-tune / merged LoRA keeps names, shapes, offsets and file size and may leave the first and the last
+    tensor of the file alone -- every tensor is sampled at its header offsets, so rewriting only a middle one changes the
+    fingerprint; same-named shards in different sub-directories are ordered by their path relative to the checkpoint root."""
+    import shutil
+    import torch
+    from safetensors.torch import save_file
+    from fastdm_amd.model.basemodel import checkpoint_fingerprint
+    g = torch.Generator().manual_seed(1)
+    tensors = {f"layer{i}.weight": torch.randn(512, 512, generator=g).to(torch.bfloat16) for i in range(5)}   # 512 KiB each
+    a = tmp_path / "a"
+    (a / "transformer").mkdir(parents=True)
+    (a / "vae").mkdir()
+    save_file(tensors, str(a / "transformer" / "diffusion_pytorch_model.safetensors"))
+    save_file({"v": torch.randn(8, 8, generator=g)}, str(a / "vae" / "diffusion_pytorch_model.safetensors"))
+    fp = checkpoint_fingerprint(str(a))
+    b = tmp_path / "b"
+    shutil.copytree(str(a), str(b))
+    assert checkpoint_fingerprint(str(b)) == fp
+    tuned = dict(tensors)
+    mid = tuned["layer2.weight"].clone()
+    mid[200:300] += 0.5                                   # rows in the middle of a middle tensor; head / tail tensors untouched
+    tuned["layer2.weight"] = mid
+    save_file(tuned, str(b / "transformer" / "diffusion_pytorch_model.safetensors"))
+    assert (b / "transformer" / "diffusion_pytorch_model.safetensors").stat().st_size == (a / "transformer" / "diffusion_pytorch_model.safetensors").stat().st_size
+    assert checkpoint_fingerprint(str(b)) != fp
+    # swapping the two same-named files between the sub-directories is another checkpoint
+    c = tmp_path / "c"
+    shutil.copytree(str(a), str(c))
+    shutil.move(str(c / "vae" / "diffusion_pytorch_model.safetensors"), str(c / "tmp.safetensors"))
+    shutil.move(str(c / "transformer" / "diffusion_pytorch_model.safetensors"), str(c / "vae" / "diffusion_pytorch_model.safetensors"))
+    shutil.move(str(c / "tmp.safetensors"), str(c / "transformer" / "diffusion_pytorch_model.safetensors"))
+    assert checkpoint_fingerprint(str(c)) != fp
+
+
+def test_quantized_cache_of_an_older_format_is_reported_as_stale(tmp_path):
+    """A cache file written by an earlier build (format v2) must say so, not 'written from another checkpoint'."""
+    import pytest
+    import torch
+    from safetensors.torch import save_file
+    from fastdm_amd.model.basemodel import BaseModelCore
+    f = tmp_path / "old.safetensors"
+    save_file({"t:x": torch.zeros(4)}, str(f), metadata={"format": "fastdm_amd-quantized-v2", "model": "BaseModelCore", "dtype": "torch.bfloat16", "checkpoint": "0" * 64})
+    core = BaseModelCore()
+    with pytest.raises(ValueError, match="stale cache format"):
+        core.weight_loading(None, quantized_cache=str(f))

@@ -15,6 +15,8 @@ else
       -c "$HERE/../../fastdm_amd/csrc/attention.hip" -o a.o 2> err.txt || { tail -20 err.txt; exit 1; }
   S=attention-hip-amdgcn-amd-amdhsa-gfx950.s
 fi
+case "$S" in /*) ;; *) S="$TMP/$S" ;; esac
+python3 "$HERE/audit_no_scratch.py" "$S"     # every fdm:: kernel of the file: zero private segment
 # MASKED=1 audits the block-mask instantiation, HD=64 the head_dim-64 one
 K="_ZN3fdm17attn_fwd64_kernelILi${HD:-128}ELb${MASKED:-0}EEEvNS_10AttnParamsE"
 awk -v k="^$K:" '$0 ~ k {on=1} on {print} on && /^\.Lfunc_end/ {exit}' $S > k.s

@@ -12,6 +12,7 @@ else
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result "$@" -S --cuda-device-only \
     "$HERE/../../fastdm_amd/csrc/gemm.hip" -o "$OUT" 2>/dev/null
 fi
+python3 "$HERE/audit_no_scratch.py" "$OUT"     # every fdm:: kernel of the file: zero private segment
 python3 - "$OUT" <<'PY'
 import re, sys
 s = open(sys.argv[1]).read()

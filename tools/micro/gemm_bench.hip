@@ -10,7 +10,7 @@
 #include <cmath>
 namespace fdm { thread_local int g_last_hip_error = 0; int device_cu_count() { return 256; } }
 #ifdef FDM_GEMM_AB
-namespace fdm { extern int g_gemm_use_w4; }
+namespace fdm { extern int g_gemm_use_w4; extern int g_gemm_use_p4; }
 #endif
 #include <vector>
 
@@ -103,6 +103,9 @@ int main(int argc, char** argv) {
     hipMemcpy(sa, s.data(), 8704 * 4, hipMemcpyHostToDevice);
     hipMemcpy(sb, s.data(), 12288 * 4, hipMemcpyHostToDevice);
   }
+  printf("buffers: A %p (+%ld) B %p (+%ld) C %p (+%ld) R %p G %p bias %p sa %p sb %p\n", (void*)A, (long)maxA, (void*)B, (long)maxB, (void*)C, (long)maxC * 2,
+         (void*)R, (void*)G, (void*)bias, (void*)sa, (void*)sb);
+  fflush(stdout);
 #ifdef FDM_GEMM_STAMPS
   hipMalloc(&fdm::g_gemm_stamps, 2048 * 8 * 8);
   hipMemset(fdm::g_gemm_stamps, 0, 2048 * 8 * 8);
@@ -191,6 +194,43 @@ int main(int argc, char** argv) {
           e0 += d0; e1 += d1; if (d0 > m0) m0 = d0; if (d1 > m1) m1 = d1; ++cnt;
         }
         printf("   vs exact (2000 samples, units of 2^-7 |ref|): old mean %.4f max %.3f | w4 mean %.4f max %.3f\n", e0 / cnt, m0, e1 / cnt, m1);
+      }
+      {   // the persistent assembly kernel against gemm_w4_kernel: same MFMAs, same order, same epilogue arithmetic -> every bit
+        std::vector<uint16_t> h2((size_t)s.M * s.N);
+        hipMemset(C, 0xee, h2.size() * 2);
+        fdm::g_gemm_use_w4 = 1; fdm::g_gemm_use_p4 = 1;
+        const int rc = run();
+        const hipError_t er = hipDeviceSynchronize();
+        hipMemcpy(h2.data(), C, h2.size() * 2, hipMemcpyDeviceToHost);
+        size_t nd = 0, first = (size_t)-1;
+        for (size_t i = 0; i < h2.size(); ++i) if (h2[i] != h1[i]) { if (first == (size_t)-1) first = i; ++nd; }
+        if (getenv("GEMM_DUMP_P4")) {   // P4_DEBUG=8 builds: [block * 4 + wave][slot][64 lanes] dwords at C
+          const int nslots = atoi(getenv("GEMM_DUMP_P4"));
+          const uint32_t* w = reinterpret_cast<const uint32_t*>(h2.data());
+          for (int bw : {0, 1, 2, 3, 4, 37 * 4 + 2, 255 * 4 + 3}) {
+            printf("   block %d wave %d:\n", bw / 4, bw % 4);
+            for (int k = 0; k < nslots; ++k) {
+              const uint32_t* q = w + ((size_t)bw * nslots + k) * 64;
+              printf("     slot %2d: lane0 %08x lane1 %08x lane17 %08x lane63 %08x\n", k, q[0], q[1], q[17], q[63]);
+            }
+          }
+        }
+        printf("   w4 vs p4 (persistent asm): rc %d sync %d, %zu of %zu elements differ", rc, (int)er, nd, h2.size());
+        if (nd) {
+          printf(" (first at m=%zu n=%zu: w4 %04x p4 %04x)", first / s.N, first % s.N, h1[first], h2[first]);
+          // which tiles / rows / columns are wrong
+          long tiles_bad = 0; std::vector<char> tb((s.M / 256) * (s.N / 256), 0);
+          std::vector<long> by_m16(16, 0), by_n16(16, 0), by_mb(16, 0), by_nb(16, 0);
+          for (size_t i = 0; i < h2.size(); ++i) if (h2[i] != h1[i]) { const size_t m = i / s.N, n = i % s.N; tb[(m / 256) * (s.N / 256) + n / 256] = 1; ++by_m16[m & 15]; ++by_n16[n & 15]; ++by_mb[(m >> 4) & 15]; ++by_nb[(n >> 4) & 15]; }
+          for (char c : tb) tiles_bad += c;
+          printf("\n      wrong tiles %ld of %zu; by m%%16:", tiles_bad, tb.size()); for (long x : by_m16) printf(" %ld", x);
+          printf("\n      by n%%16:"); for (long x : by_n16) printf(" %ld", x);
+          printf("\n      by (m/16)%%16:"); for (long x : by_mb) printf(" %ld", x);
+          printf("\n      by (n/16)%%16:"); for (long x : by_nb) printf(" %ld", x);
+          printf("\n      first bad tiles:"); int shown = 0; for (size_t t = 0; t < tb.size() && shown < 24; ++t) if (tb[t]) { printf(" (%zu,%zu)", t / (s.N / 256), t % (s.N / 256)); ++shown; }
+        }
+        printf("\n");
+        fdm::g_gemm_use_p4 = getenv("GEMM_P4") ? 1 : 0;
       }
       fdm::g_gemm_use_w4 = getenv("GEMM_OLD") ? 0 : 1;
     }
