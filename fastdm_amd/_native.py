@@ -31,6 +31,7 @@ SIGNATURES = {
     "fdm_gemm_w8a8_int8_x2": (I32, [P, P, P]),
     "fdm_gemm_w8a8_int8_x2_ws": (I32, [P, P, P, I64, P]),
     "fdm_gemm_int8_workspace_bytes": (I64, []),
+    "fdm_gemm_last_kernel": (I32, []),
     "fdm_gemm_w8a8_int8": (I32, [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_gemm_bf16": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_attn_fwd": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I32, I32, P, I64, P]),
@@ -48,7 +49,7 @@ SIGNATURES = {
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
 }
 
-ABI_VERSION = 9          # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
+ABI_VERSION = 10         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL, EPI_GATE_RESIDUAL_F32 = 0, 1, 2, 3, 4
 
 
@@ -90,7 +91,7 @@ def _source_digest(srcs) -> str:
 def current_source_digest() -> str:
     """Content digest of everything libfastdm_amd.so is built from (kernel sources, build script, the C-ABI header)."""
     srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))
-            if f.endswith((".hip", ".h", ".sh"))]
+            if f.endswith((".hip", ".h", ".sh", ".inc", ".py"))]      # .inc: the generated assembly bodies of gemm_p4_kernel, .py: their generator
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "fastdm_amd.h"))
     return _source_digest(srcs)
 

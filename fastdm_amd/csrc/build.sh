@@ -6,6 +6,8 @@ OUT="$HERE/../_lib"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result $*"
+# gemm_p4_kernel's body is generated assembly; the committed gemm_p4_body_*.inc are regenerated when python3 is there (same bytes)
+if command -v python3 > /dev/null 2>&1; then python3 "$HERE/gen_gemm_p4.py" > /dev/null; fi
 pids=()
 # attention.hip: the hand-placed MFMA gaps of attn_fwd64_kernel must not be re-packed by the SLP vectoriser (it merges the
 # two q-blocks' row-sum chains into v_pk_add_f32 and sinks them below the tile)

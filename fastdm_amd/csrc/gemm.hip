@@ -1437,6 +1437,23 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_p4_kernel(const P4Args arg
         :
 #include "gemm_p4_clobbers.inc"
     );
+  } else if constexpr (EPI == FDM_EPI_GELU_TANH) {
+    asm volatile(
+#include "gemm_p4_body_gelu_tanh.inc"
+        :
+        : "s"(ka), "s"(blockIdx.x), "v"(threadIdx.x), "s"(lds0)
+        :
+#include "gemm_p4_clobbers.inc"
+    );
+  } else {
+    static_assert(EPI == FDM_EPI_GELU_ERF, "gemm_p4_kernel: plain, tanh-GELU and erf-GELU epilogues");
+    asm volatile(
+#include "gemm_p4_body_gelu_erf.inc"
+        :
+        : "s"(ka), "s"(blockIdx.x), "v"(threadIdx.x), "s"(lds0)
+        :
+#include "gemm_p4_clobbers.inc"
+    );
   }
 }
 
@@ -1497,13 +1514,18 @@ static bool use_p4(const GemmGroup& grp, P4Args& pa) {
 #ifdef FDM_GEMM_AB
   if (!g_gemm_use_p4) return false;
 #else
+  // FDM_GEMM_P4 = 0: never; 1 (default): the epilogues it measured faster with (plain, tanh-GELU); 2: every epilogue it implements.
+  // FDM_GEMM_KERNEL = w4 | w8 also switches it off (those select a kernel for every launch), = p4 means 2.
   static int on = -1;
   if (on < 0) {
     const char* e = getenv("FDM_GEMM_P4");
     const char* k = getenv("FDM_GEMM_KERNEL");
-    on = (e && e[0] == '1') || (k && !strcmp(k, "p4")) ? 1 : 0;      // (bring-up: opt-in until the parity tests are green)
+    on = e ? atoi(e) : 1;
+    if (k && (!strcmp(k, "w4") || !strcmp(k, "w8"))) on = 0;
+    if (k && !strcmp(k, "p4")) on = 2;
   }
   if (!on) return false;
+  if (on == 1 && grp.p[0].epi == FDM_EPI_GELU_ERF) return false;   // erf-GELU drain is VALU-bound either way: 373-378 vs 366-372 us (profiles/r04_experiments.md)
 #endif
 #ifdef FDM_GEMM_AB
   if (grp.total_tiles < device_cu_count() || grp.splits > 1 || grp.mode != 0) return false;   // (bring-up: also the one-tile-per-block case)
@@ -1513,7 +1535,7 @@ static bool use_p4(const GemmGroup& grp, P4Args& pa) {
   const GemmProblem& a = grp.p[0];
   for (int i = 0; i < grp.n; ++i) {
     const GemmProblem& q = grp.p[i];
-    if (q.epi != FDM_EPI_NONE) return false;
+    if ((q.epi != FDM_EPI_NONE && q.epi != FDM_EPI_GELU_TANH && q.epi != FDM_EPI_GELU_ERF) || q.epi != a.epi) return false;
     if ((q.M % BM) || (q.N % BN) || (q.Kb % 256) || q.Kb < 768) return false;
     if (q.N != a.N || q.Kb != a.Kb || q.lda != a.lda || q.ldb != a.ldb || q.ldc != a.ldc || q.plane_cols != a.plane_cols ||
         q.plane_stride != a.plane_stride)
@@ -1546,6 +1568,7 @@ static bool use_p4(const GemmGroup& grp, P4Args& pa) {
 }
 
 constexpr int64_t SPLIT_PART_BYTES = (int64_t)BM * BN * 4;   // one K part of one tile: 256 x 256 int32
+static thread_local int g_last_gemm_kernel = -1;              // fdm_gemm_last_kernel()
 
 template <int DT>
 static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, int64_t ws_bytes = 0) {
@@ -1597,6 +1620,7 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, 
         else gemm_kernel<DT, false><<<g2.n_blocks, GEMM_THREADS, 0, s>>>(g2);
       }
       FDM_CHECK_LAUNCH();
+      g_last_gemm_kernel = use_w4<DT>(grp) ? FDM_GEMM_KERNEL_W4 : FDM_GEMM_KERNEL_W8;
       g2.mode = 1;
       g2.spread_shift = rem * 4 <= cu ? 2 : (rem * 2 <= cu ? 1 : 0);   // as many merge blocks per tile as fit ONE round
       if (use_w4<DT>(grp)) {
@@ -1613,7 +1637,11 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, 
   if constexpr (DT == DT_FP8) {
     P4Args pa;
     if (use_p4(grp, pa)) {
-      gemm_p4_kernel<FDM_EPI_NONE><<<8 * pa.blocks_per_xcd, W4_THREADS, 0, s>>>(pa);
+      const unsigned pgrid = 8 * pa.blocks_per_xcd;
+      if (grp.p[0].epi == FDM_EPI_GELU_TANH) gemm_p4_kernel<FDM_EPI_GELU_TANH><<<pgrid, W4_THREADS, 0, s>>>(pa);
+      else if (grp.p[0].epi == FDM_EPI_GELU_ERF) gemm_p4_kernel<FDM_EPI_GELU_ERF><<<pgrid, W4_THREADS, 0, s>>>(pa);
+      else gemm_p4_kernel<FDM_EPI_NONE><<<pgrid, W4_THREADS, 0, s>>>(pa);
+      g_last_gemm_kernel = FDM_GEMM_KERNEL_P4;
       FDM_CHECK_LAUNCH();
       return FDM_OK;
     }
@@ -1621,9 +1649,11 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, 
   if (use_w4<DT>(grp)) {
     if (res) gemm_w4_kernel<DT, true><<<grid, W4_THREADS, 0, s>>>(grp);
     else gemm_w4_kernel<DT, false><<<grid, W4_THREADS, 0, s>>>(grp);
+    g_last_gemm_kernel = FDM_GEMM_KERNEL_W4;
   } else {
     if (res) gemm_kernel<DT, true><<<grid, GEMM_THREADS, 0, s>>>(grp);
     else gemm_kernel<DT, false><<<grid, GEMM_THREADS, 0, s>>>(grp);
+    g_last_gemm_kernel = FDM_GEMM_KERNEL_W8;
   }
   FDM_CHECK_LAUNCH();
   return FDM_OK;
@@ -1788,11 +1818,14 @@ static int launch_gemv(void* out, const void* a, const void* b, const void* bias
   else if (MR == 4) FDM_GEMV(4);
   else FDM_GEMV(8);
 #undef FDM_GEMV
+  g_last_gemm_kernel = FDM_GEMM_KERNEL_GEMV;
   FDM_CHECK_LAUNCH();
   return FDM_OK;
 }
 
 extern "C" {
+
+int fdm_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 
 int fdm_gemm_w8a8_fp8(void* out, const void* a, const void* b, const float* scale_a, const float* scale_b, const void* bias,
                       int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int epilogue,

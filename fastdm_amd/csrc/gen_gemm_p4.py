@@ -402,19 +402,40 @@ def build(epi):
         return [V_BIAS + nb * 4 + k for k in range(4)] if not g.packed_bias else None
 
     def act(regs, tmps):
-        """activation on 4 fp32 values in `regs` (already rounded to bf16 precision), in place; tmps: >= 8 temporaries"""
+        """activation on 4 fp32 values in `regs` (already rounded to bf16 precision), in place -- the op order of gemm.hip's gelu16<EPI>
+        (bit-identical results).  tmps: 12 temporaries.  No instruction consumes a transcendental's result in the slot right behind it
+        (gfx950: 1 wait state)."""
         o = []
         if g.epi == EPI_GELU_TANH:
-            # 0.5 x (1 + tanh(u)) = x - x / (exp2(x (c0 + c1 x^2)) + 1): gemm.hip gelu16<EPI_GELU_TANH>, same op order
-            c0 = 0.79788456080286535588 * 2.885390081777927
+            # 0.5 x (1 + tanh(u)) = x - x / (exp2(x (c0 + c1 x^2)) + 1)
             ec = tmps[:4]
             o += [f"v_mul_f32 v{ec[k]}, v{regs[k]}, v{regs[k]}" for k in range(4)]
-            o += [f"v_fma_f32 v{ec[k]}, v{ec[k]}, {S_C1}, {S_C0}" for k in range(4)]
+            o += [f"v_fma_f32 v{ec[k]}, v{ec[k]}, {K['c1']}, v{KV['c0']}" for k in range(4)]
             o += [f"v_mul_f32 v{ec[k]}, v{regs[k]}, v{ec[k]}" for k in range(4)]
             o += [f"v_exp_f32 v{ec[k]}, v{ec[k]}" for k in range(4)]
             o += [f"v_add_f32 v{ec[k]}, 1.0, v{ec[k]}" for k in range(4)]
             o += [f"v_rcp_f32 v{ec[k]}, v{ec[k]}" for k in range(4)]
             o += [f"v_fma_f32 v{regs[k]}, -v{regs[k]}, v{ec[k]}, v{regs[k]}" for k in range(4)]
+        elif g.epi == EPI_GELU_ERF:
+            # Abramowitz-Stegun 7.1.26: erf(z) = 1 - poly(t) exp(-z^2), t = 1 / (1 + p z)
+            z, t, pl = tmps[0:4], tmps[4:8], tmps[8:12]
+            o += [f"v_mul_f32 v{z[k]}, |v{regs[k]}|, {K['sqrt1_2']}" for k in range(4)]
+            o += [f"v_fma_f32 v{t[k]}, {K['p']}, v{z[k]}, 1.0" for k in range(4)]
+            o += [f"v_rcp_f32 v{t[k]}, v{t[k]}" for k in range(4)]
+            o += [f"v_fma_f32 v{pl[k]}, v{t[k]}, {K['a1']}, v{KV['a2']}" for k in range(4)]
+            o += [f"v_fma_f32 v{pl[k]}, v{t[k]}, v{pl[k]}, {K['a3']}" for k in range(4)]
+            o += [f"v_fma_f32 v{pl[k]}, v{t[k]}, v{pl[k]}, v{KV['a4']}" for k in range(4)]
+            o += [f"v_fma_f32 v{pl[k]}, v{t[k]}, v{pl[k]}, v{KV['a5']}" for k in range(4)]
+            o += [f"v_mul_f32 v{pl[k]}, v{pl[k]}, v{t[k]}" for k in range(4)]
+            o += [f"v_mul_f32 v{z[k]}, -v{z[k]}, v{z[k]}" for k in range(4)]
+            o += [f"v_mul_f32 v{z[k]}, {K['log2e']}, v{z[k]}" for k in range(4)]
+            o += [f"v_exp_f32 v{z[k]}, v{z[k]}" for k in range(4)]
+            o += [f"v_and_b32 v{t[k]}, 0x80000000, v{regs[k]}" for k in range(4)]          # sign of x (t is dead)
+            o += [f"v_fma_f32 v{pl[k]}, -v{pl[k]}, v{z[k]}, 1.0" for k in range(4)]      # er
+            o += [f"v_xor_b32 v{pl[k]}, v{pl[k]}, v{t[k]}" for k in range(4)]             # x < 0 ? -er : er
+            o += [f"v_add_f32 v{pl[k]}, 1.0, v{pl[k]}" for k in range(4)]
+            o += [f"v_mul_f32 v{regs[k]}, 0.5, v{regs[k]}" for k in range(4)]
+            o += [f"v_mul_f32 v{regs[k]}, v{regs[k]}, v{pl[k]}" for k in range(4)]
         return o
 
     def drain(mb):
@@ -573,17 +594,30 @@ def build(epi):
             for ln in trail_stores():
                 e(ln)
 
-    S_C0, S_C1 = None, None
+    # activation constants: float32 values exactly as hipcc folds them in gemm.hip; one SGPR operand per VALU instruction on gfx9,
+    # so a second constant of an instruction sits in a VGPR.  The SGPRs are setup registers that are dead from here on.
+    import struct
+    f32 = lambda x: struct.unpack("<f", struct.pack("<f", x))[0]
+    bits = lambda x: struct.unpack("<I", struct.pack("<f", x))[0]
+    K, KV = {}, {}
+    dead_s = [g.s1("karg", 0), g.s1("karg", 1), BID, LDS0, WAVE]
     if epi == EPI_GELU_TANH:
-        import struct
-        c0 = 0.79788456080286535588 * 2.885390081777927
-        f32 = lambda x: struct.unpack("<I", struct.pack("<f", x))[0]
-        c0f = struct.unpack("<f", struct.pack("<f", c0))[0]
-        S_C0, S_C1 = s("gc0"), s("gc1")
-        e(f"s_mov_b32 {S_C0}, 0x{f32(c0f):08x}")
-        e(f"s_mov_b32 {S_C1}, 0x{f32(c0f * struct.unpack('<f', struct.pack('<f', 0.044715))[0]):08x}")
+        c0 = f32(f32(0.79788456080286535588) * f32(2.885390081777927))
+        c1 = f32(c0 * f32(0.044715))
+        K["c1"] = dead_s[0]
+        KV["c0"] = XT[15]
+        e(f"s_mov_b32 {K['c1']}, 0x{bits(c1):08x}")
+        e(f"v_mov_b32 v{KV['c0']}, 0x{bits(c0):08x}")
+    elif epi == EPI_GELU_ERF:
+        vals = {"sqrt1_2": 0.70710678118654752440, "p": 0.3275911, "a1": 1.061405429, "log2e": 1.4426950408889634, "a3": 1.421413741}
+        for (nm, v), r in zip(vals.items(), dead_s):
+            K[nm] = r
+            e(f"s_mov_b32 {r}, 0x{bits(f32(v)):08x}")
+        for nm, v, r in (("a2", -1.453152027, XT[12]), ("a4", -0.284496736, XT[13]), ("a5", 0.254829592, XT[14])):
+            KV[nm] = r
+            e(f"v_mov_b32 v{r}, 0x{bits(f32(v)):08x}")
 
-    if int(os.environ.get("P4_DEBUG", "0")) & 8:
+    if os.environ.get("P4_OUT") and int(os.environ.get("P4_DEBUG", "0")) & 8:
         # bring-up: dump the setup state of every wave to p0.C ([block * 4 + wave][slot][64 lanes] dwords) and stop
         names = ["karg", "bid", "wave", "wm", "wn", "ldsw", "lds0", "p0", "p1", "cfg", "a32", "b32", "ldc4", "tcur", "tend", "prob", "mt", "nt",
                  "ptra", "ptrb", "sap", "sbp", "biasp", "cwave"]
@@ -717,7 +751,8 @@ def build(epi):
 
 def render(g):
     lines = []
-    dbg = int(os.environ.get("P4_DEBUG", "0"))      # bring-up only: 1 drop global stores, 2 drop operand loads, 4 drop LDS-DMAs
+    # bring-up only, and only when writing to another directory (P4_OUT): 1 drop global stores, 2 drop operand loads, 4 drop LDS-DMAs
+    dbg = int(os.environ.get("P4_DEBUG", "0")) if os.environ.get("P4_OUT") else 0
     for ln in g.out:
         if ln.startswith(";"):
             continue
@@ -733,7 +768,7 @@ def render(g):
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
-    for epi, name in ((EPI_NONE, "none"),):
+    for epi, name in ((EPI_NONE, "none"), (EPI_GELU_TANH, "gelu_tanh"), (EPI_GELU_ERF, "gelu_erf")):
         g = build(epi)
         text = "// generated by gen_gemm_p4.py -- do not edit\n" + render(g)
         with open(os.path.join(os.environ.get("P4_OUT", here), f"gemm_p4_body_{name}.inc"), "w") as f:

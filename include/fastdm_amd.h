@@ -44,7 +44,7 @@ const char* fdm_last_hip_error_string(void);
 
 /* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
  * refuse to run instead of passing arguments at the wrong positions. */
-#define FDM_ABI_VERSION 9
+#define FDM_ABI_VERSION 10
 int fdm_abi_version(void);
 
 /* ---- replaces cuda_ops.rms_norm_ (ops.h:17-20; csrc/elmwise_ops.cu:56-84,433-449) -------------
@@ -161,6 +161,16 @@ int fdm_gemm_w8a8_int8_x2(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_desc
 int64_t fdm_gemm_int8_workspace_bytes(void);
 int fdm_gemm_w8a8_int8_x2_ws(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_desc* d1, void* workspace,
                              int64_t workspace_bytes, fdm_stream_t stream);
+
+/* Diagnostic: which kernel the LAST GEMM entry point called on this host thread launched (the dispatch policy of gemm.hip picks
+ * per launch): 0 fdm::gemm_kernel (8 waves), 1 fdm::gemm_w4_kernel (4 waves), 2 fdm::gemm_p4_kernel (persistent, hand-written
+ * assembly), 3 fdm::gemv_bf16_kernel, -1 nothing launched yet.  bench.py names the kernel of a timing span with it; the parity
+ * tests use it to prove which kernel they compared.  No reference counterpart.                                                  */
+#define FDM_GEMM_KERNEL_W8 0
+#define FDM_GEMM_KERNEL_W4 1
+#define FDM_GEMM_KERNEL_P4 2
+#define FDM_GEMM_KERNEL_GEMV 3
+int fdm_gemm_last_kernel(void);
 
 /* ---- bf16 GEMM (QLinear's un-quantised branch: torch.addmm, layer/qlinear.py:76) --------------
  * out[M,N] = bf16(acc_f32(A[M,K] bf16 row-major x B[K,N] bf16 column-major) + bias[N])          */

@@ -1,5 +1,7 @@
 """GPU parity: every operator of the HIP path (through the C ABI) against the CPU oracle and the
 committed golden vectors.  Shapes follow /root/reference/tests/test_*.py (model-derived tables)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -391,6 +393,32 @@ def test_plane_split_projection_equals_plain_output(K, quant, C):
     planes1 = torch.empty((3, m_img, C), dtype=BF16, device="cuda")
     QLinear.forward_q_planes([(lins[0], qi, 0)], planes1)
     assert torch.equal(planes1.permute(1, 0, 2).reshape(m_img, 3 * C), plain_i)
+
+
+def test_gemm_p4_persistent_assembly_is_bit_identical_to_gemm_w4():
+    """fdm::gemm_p4_kernel (the persistent fp8 tile loop in hand-written gfx950 assembly, fastdm_amd/csrc/gen_gemm_p4.py) issues the same
+    MFMAs in the same K order and applies the same epilogue arithmetic as fdm::gemm_w4_kernel, so every output bit must agree: plain
+    / tanh-GELU / erf-GELU epilogues, with and without a bias, a 2-row last raster group, the shortest K it accepts, an image + text
+    pair in one launch with and without plane-split outputs.  The kernel policy is read once per process, so each policy runs in its
+    own process (tests/gemm_policy_worker.py); fdm_gemm_last_kernel() proves which kernel produced each hash."""
+    import json
+    import subprocess
+    import sys
+    from fastdm_amd import _native as N
+    N.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, p4 in (("w4", "0"), ("p4", "2")):
+        env = dict(os.environ, FDM_GEMM_P4=p4)
+        env.pop("FDM_GEMM_KERNEL", None)
+        if tag == "w4":
+            env["FDM_GEMM_KERNEL"] = "w4"        # (the auto policy sends K < 2048 bytes to the 8-wave kernel, whose fp32 summation order differs)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "gemm_policy_worker.py")], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    for name in out["w4"]:
+        assert out["w4"][name][0] == 1 and out["p4"][name][0] == 2, (name, out["w4"][name][0], out["p4"][name][0])   # gemm_w4_kernel vs gemm_p4_kernel
+        assert out["w4"][name][1] == out["p4"][name][1], f"{name}: gemm_p4_kernel differs from gemm_w4_kernel"
 
 
 def test_bf16_gemm_and_epilogues():
