@@ -28,7 +28,8 @@ import torch  # noqa: E402
 
 PEAK_TFLOPS = {"fp8": 5000.0, "bf16": 2500.0, "int8": 5000.0}   # dense MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 IMAGE_STEPS = 25
-# timing-span name -> HIP kernel it launches (the name rocprofv3 reports; profiles/*_summary.txt)
+# timing-span name -> HIP kernel it launches (the name rocprofv3 reports; profiles/*_summary.txt).  For the GEMM spans this is only the
+# name used for the `roofline` entry when a GEMM span dominates; what each launch really ran is recorded per span ("hip_kernels")
 HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128, false>", "attn_sparse_bf16": "fdm::attn_fwd64_kernel<128, true>",
               # GEMM spans: the kernel the dispatch policy (gemm.hip use_w4) picks for the default workloads' launches of that span
               "gemm_w8a8_fp8": "fdm::gemm_w4_kernel<0, false>", "gemm_w8a8_fp8_res": "fdm::gemm_w4_kernel<0, true>",
@@ -149,7 +150,7 @@ def spawn_ranks(n: int) -> int:
     the others when one dies (a dead rank otherwise leaves its siblings in the rendezvous until the RCCL timeout) and gives up
     after FDM_BENCH_TIMEOUT seconds (default 1500)."""
     from fastdm_amd.launch import spawn_self
-    return spawn_self(__file__, sys.argv[1:], n, timeout=float(os.environ.get("FDM_BENCH_TIMEOUT", "1500")))
+    return spawn_self(__file__, sys.argv[1:], n, timeout=float(os.environ.get("FDM_BENCH_TIMEOUT", "1500")), same_device="--same-device" in sys.argv[1:])
 
 
 def cpu_baseline_qwen(height, width, n_txt, quant_tag):
@@ -240,7 +241,7 @@ def main():
     ap.add_argument("--frames", type=int, default=81, help="wan: video frames")
     ap.add_argument("--sparse-config", default=None, help="wan: radial block-sparse attention JSON (examples/sparse/radial_attn_wan.json)")
     ap.add_argument("--start-step", type=int, default=0, help="schedule index of the first timed step (wan: >= dense_steps exercises the sparse steps)")
-    ap.add_argument("--layers", type=int, default=None, help="wan: number of blocks (default 40; a reduced depth is reported in the workload string)")
+    ap.add_argument("--layers", type=int, default=None, help="wan / qwen: number of blocks (default 40 / 60; a reduced depth is reported in the workload string)")
     ap.add_argument("--height", type=int, default=None, help="default 1024 (flux) / 1328 (qwen)")
     ap.add_argument("--width", type=int, default=None, help="default 2048 (flux) / 1328 (qwen)")
     ap.add_argument("--max-seq-len", type=int, default=None, help="text tokens: default 512 (flux) / 128 (qwen)")
@@ -256,6 +257,8 @@ def main():
     ap.add_argument("--nhwc", action="store_true", help="sdxl: keep convolution activations channels-last instead of NCHW")
     ap.add_argument("--cfg-pair", action="store_true", help="qwen / wan / sd35 / sdxl with --gpus 2k: ranks (2i, 2i+1) share image i -- one runs the "
                     "conditional, the other the unconditional forward, one all-gather of the noise predictions per step (strong scaling of a step)")
+    ap.add_argument("--same-device", action="store_true", help="PROTOCOL TEST ONLY: every rank on cuda:0 over gloo (a 1-GPU box exercising the N-rank "
+                    "sharding / CFG-pair exchange / final gather with real HIP forwards); the line says so and is not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event spans")
     args = ap.parse_args()
@@ -277,7 +280,7 @@ def main():
 
     claim_stdout()
     from fastdm_amd import distributed as D
-    rank, world, local_rank = D.init_from_env()
+    rank, world, local_rank = D.init_from_env(backend="gloo" if args.same_device else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run or let bench.py spawn the ranks"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
@@ -300,8 +303,9 @@ def main():
                              kernel_backend="hip", cache=cache).eval()
         pipe = SyntheticFluxPipeline(model, seed=0)
     elif args.model == "qwen":
-        model = create_model("qwen", ckpt_path=SyntheticQwenStateDict(seed=0), dtype=torch.bfloat16, quant_type=quant,
-                             kernel_backend="hip", cache=cache, out_channels=16).eval()
+        mc = {"num_layers": args.layers} if args.layers else {}
+        model = create_model("qwen", ckpt_path=SyntheticQwenStateDict(seed=0, **mc), dtype=torch.bfloat16, quant_type=quant,
+                             kernel_backend="hip", cache=cache, out_channels=16, **mc).eval()
         pipe = SyntheticQwenPipeline(model, seed=0, batch_cfg=args.batch_cfg)
     elif args.model == "sd35":
         from fastdm_amd.synthetic import SyntheticSD3StateDict, sd3_step_inputs
@@ -485,7 +489,8 @@ def main():
     else:
         nfw = 2 * args.steps
         workload = (f"Qwen-Image {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step schedule, true CFG "
-                    f"({'one batch-2 forward' if args.batch_cfg else '2 forwards'} per step), batch 1 per GPU, 60 double-stream blocks"
+                    f"({'one batch-2 forward' if args.batch_cfg else '2 forwards'} per step), batch 1 per GPU, {args.layers or 60} double-stream blocks"
+                    + (" [REDUCED DEPTH]" if args.layers and args.layers != 60 else "")
                     + (f", TeaCache (threshold {cache.config.threshold}{' [OVERRIDDEN]' if args.cache_threshold is not None else ''}{', negative cache' if args.cache_negative else ''}; {skipped}/{nfw} forwards skipped)" if cache else ""))
     out = {
         # value counts denoise steps of ALL images in flight (n_images = n_gpus, or n_gpus / 2 with --cfg-pair)
@@ -516,6 +521,9 @@ def main():
                                    f"dp{world} (image-sharded, one all-gather of final latents)"),
                    "ranks_in_process_group": D.group_size()},
     }
+    if args.same_device:
+        out["scaling_note"] = "PROTOCOL TEST: all ranks share cuda:0 over gloo (--same-device); `value` is not a scaling measurement. " + out["scaling_note"]
+        out["config"]["transport"] = "gloo, every rank on cuda:0 (--same-device)"
     if rec:
         summ = rec.summary()
         kernels = {}
@@ -524,6 +532,9 @@ def main():
             tf = s["work"] / (s["total_ms"] * 1e-3) / 1e12
             kernels[name] = {"launches_per_step": s["launches"] / args.steps, "avg_ms": s["avg_ms"], "ms_per_step": s["total_ms"] / args.steps,
                              "achieved_TFLOPs": tf, "peak_TFLOPs": PEAK_TFLOPS[dt], "frac": tf / PEAK_TFLOPS[dt]}
+            if "by_kernel" in s:      # the tile kernel each launch of the span actually ran (fdm_gemm_last_kernel; one span can mix kernels)
+                kernels[name]["hip_kernels"] = {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["total_ms"] / args.steps,
+                                                    "achieved_TFLOPs": v["work"] / (v["total_ms"] * 1e-3) / 1e12} for k, v in s["by_kernel"].items()}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         default_workload = (args.model, args.height, args.width, args.max_seq_len, args.quant, args.cache_config) == ("flux", 1024, 2048, 512, "fp8", None)
         traffic, traffic_src = pmc_traffic(HIP_KERNEL.get(dom, dom)) if default_workload else (None, "not the default workload")
@@ -538,7 +549,8 @@ def main():
             fdt = "int8" if "int8" in fam[0] else "fp8"
             f_ms, f_work = sum(summ[k]["total_ms"] for k in fam), sum(summ[k]["work"] for k in fam)
             f_tf = f_work / (f_ms * 1e-3) / 1e12
-            out["roofline_family"] = {"family": f"W8A8 {fdt} GEMM (fdm::gemm_kernel / fdm::gemm_w4_kernel, all epilogues)", "spans": fam, "bound": "mfma",
+            ran = sorted({k for f in fam for k in summ[f].get("by_kernel", {})})
+            out["roofline_family"] = {"family": f"W8A8 {fdt} GEMM, all epilogues; kernels launched: {', '.join(ran) if ran else 'n/a'}", "spans": fam, "bound": "mfma",
                                       "achieved": f_tf, "peak": PEAK_TFLOPS[fdt], "unit": "TFLOP/s", "frac": f_tf / PEAK_TFLOPS[fdt],
                                       "ms_per_step": f_ms / args.steps, "share_of_step": f_ms / args.steps / ms_per_step}
         flops_step = sum(s["work"] for s in summ.values()) / args.steps

@@ -7,7 +7,7 @@
     python examples/demo/gen.py --model-path /path/to/FLUX.1-dev --use-fp8 --output-path flux-fp8.png   # needs diffusers
 
 Without --model-path (no checkpoints / diffusers in this image) the engine denoises with synthetic weights of the chosen
-architecture (flux, qwen, wan, sd35, sdxl) and synthetic prompt embeddings; the output is then the final packed latent tensor, saved with torch.save.
+architecture (flux, qwen, wan, sd35, sdxl; wan-i2v needs a checkpoint) and synthetic prompt embeddings; the output is then the final packed latent tensor, saved with torch.save.
 """
 import os
 import sys
@@ -32,10 +32,13 @@ if __name__ == "__main__":
     print(f"Model loading latency: {time.time() - t0:.4f} seconds")
 
     def run():
-        return engine.generate(prompt=args.prompts, negative_prompt=args.negative_prompts, steps=args.steps,
+        # the reference's call, argument for argument (/root/reference/examples/demo/gen.py:79-103)
+        return engine.generate(prompt=args.prompts, negative_prompt=args.negative_prompts,
+                               num_frames=args.num_frames if args.task in ("t2v", "i2v") else None, steps=args.steps,
                                guidance_scale=args.guidance_scale, gen_seed=args.seed, gen_width=args.width,
                                gen_height=args.height, max_seq_len=args.max_seq_len,
-                               true_cfg_scale=args.true_cfg_scale if args.architecture == "qwen" else None)
+                               true_cfg_scale=args.true_cfg_scale if args.architecture == "qwen" else None,
+                               src_image=args.image_path if args.task == "i2v" else None)
 
     for i in range(args.num_warmup_runs):
         print(f"warmup {i + 1}/{args.num_warmup_runs}")
@@ -46,7 +49,10 @@ if __name__ == "__main__":
     torch.cuda.synchronize()
     dt = time.time() - t0
     print(f"Generation latency: {dt:.4f} seconds ({args.steps / dt:.2f} it/s)")
-    if hasattr(output, "save"):
+    if args.task in ("t2v", "i2v") and not torch.is_tensor(output):
+        from diffusers.utils import export_to_video
+        export_to_video(output, args.output_path, fps=args.fps)
+    elif hasattr(output, "save"):
         output.save(args.output_path)
     else:
         path = os.path.splitext(args.output_path)[0] + ".latents.pt"

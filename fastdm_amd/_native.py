@@ -192,7 +192,10 @@ def attn_workspace(device, head_dim):
     return ws
 
 
-_gemm_ws = {}
+import collections
+
+_gemm_ws = collections.OrderedDict()      # (device, stream handle) -> buffer, least recently used first
+_GEMM_WS_MAX = 8                           # 8 x 64 MiB: more streams than that in flight at once is not a denoise loop
 
 
 def gemm_int8_workspace(device):
@@ -210,6 +213,13 @@ def gemm_int8_workspace(device):
                                "(call fastdm_amd._native.warm_gemm_int8_workspace(device) on the capture stream first)")
         ws = torch.empty(int(lib().fdm_gemm_int8_workspace_bytes()), dtype=torch.uint8, device=device)
         _gemm_ws[key] = ws
+        # bounded: a stream handle is not an identity (a destroyed stream's handle can come back), and every stream that ever ran an
+        # int8 GEMM used to keep its 64 MiB for good.  The least recently used entry goes; torch's caching allocator keeps the block
+        # alive until the work queued on it has run.
+        while len(_gemm_ws) > _GEMM_WS_MAX:
+            _gemm_ws.popitem(last=False)
+    else:
+        _gemm_ws.move_to_end(key)
     return ws
 
 

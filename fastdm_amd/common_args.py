@@ -10,7 +10,7 @@ _COMMON = [
     ("--oom-resolve", "flag", None, "accepted for compatibility; unnecessary with 288 GB of HBM"),
     ("--model-path", str, "", "diffusion model directory ('' = synthetic weights)"),
     ("--data-type", str, "bfloat16", "activation data type: bfloat16"),
-    ("--architecture", str, "flux", "model architecture: flux | qwen | wan | sd35 | sdxl"),
+    ("--architecture", str, "flux", "model architecture: flux | qwen | wan | wan-i2v | sd35 | sdxl"),
     ("--cache-config", str, None, "step-cache JSON (examples/xcaching/configs/)"),
     ("--steps", int, 25, "denoise steps"),
     ("--guidance-scale", float, 3.5, "guidance scale"),

@@ -8,11 +8,12 @@ from collections import defaultdict
 import torch
 
 _active = None
+GEMM_KERNEL_NAMES = {0: "fdm::gemm_kernel", 1: "fdm::gemm_w4_kernel", 2: "fdm::gemm_p4_kernel", 3: "fdm::gemv_bf16_kernel"}   # fdm_gemm_last_kernel()
 
 
 class Recorder:
     def __init__(self):
-        self.events = defaultdict(list)   # name -> [(start, stop, work)]
+        self.events = defaultdict(list)   # name -> [(start, stop, work, gemm kernel id or None)]
 
     def __enter__(self):
         global _active
@@ -27,8 +28,17 @@ class Recorder:
         torch.cuda.synchronize()
         out = {}
         for name, evs in self.events.items():
-            ms = [a.elapsed_time(b) for a, b, _ in evs]
-            out[name] = {"launches": len(evs), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms), "work": sum(w for _, _, w in evs)}
+            ms = [a.elapsed_time(b) for a, b, _, _ in evs]
+            out[name] = {"launches": len(evs), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms), "work": sum(e[2] for e in evs)}
+            by_kernel = {}
+            for t, e in zip(ms, evs):
+                if e[3] is not None:
+                    k = by_kernel.setdefault(GEMM_KERNEL_NAMES.get(e[3], str(e[3])), {"launches": 0, "total_ms": 0.0, "work": 0.0})
+                    k["launches"] += 1
+                    k["total_ms"] += t
+                    k["work"] += e[2]
+            if by_kernel:
+                out[name]["by_kernel"] = by_kernel
         return out
 
 
@@ -48,7 +58,11 @@ class _Span:
         if _active is not None:
             stop = torch.cuda.Event(enable_timing=True)
             stop.record()
-            _active.events[self.name].append((self.start, stop, self.work))
+            kern = None
+            if self.name.startswith("gemm"):      # which tile kernel the dispatch policy picked for THIS launch (one span, several kernels)
+                from fastdm_amd import _native as N
+                kern = int(N.lib().fdm_gemm_last_kernel())
+            _active.events[self.name].append((self.start, stop, self.work, kern))
 
 
 def span(name: str, work: float = 0.0):

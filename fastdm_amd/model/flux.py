@@ -230,8 +230,14 @@ class FluxTransformer2DModelCore(BaseModelCore):
 
     # ------------------------------------------------------------------ forward (flux.py:334-494)
     def _rope_cache(self, txt_ids, img_ids, dtype):
-        key = (txt_ids.data_ptr(), img_ids.data_ptr(), tuple(txt_ids.shape), tuple(img_ids.shape), txt_ids._version, img_ids._version)
-        if key != self._rope_key:
+        # tensors made under torch.inference_mode() -- how the reference's engine calls its pipelines, model_entry.py:787 -- carry no
+        # version counter (reading `_version` raises): their table is rebuilt every forward (a few small launches) instead of cached
+        # on an identity that cannot see in-place updates.  Found by tests/test_engine_checkpoint_gpu.py.
+        if txt_ids.is_inference() or img_ids.is_inference():
+            key = None
+        else:
+            key = (txt_ids.data_ptr(), img_ids.data_ptr(), tuple(txt_ids.shape), tuple(img_ids.shape), txt_ids._version, img_ids._version)
+        if key is None or key != self._rope_key:
             ids = torch.cat((txt_ids, img_ids), dim=0)
             cos, sin = self.pos_embed.forward(ids)
             self._rope_val = torch.cat((cos[:, 0::2], sin[:, 1::2]), dim=-1).to(dtype).contiguous()

@@ -123,10 +123,12 @@ class SD35TransformerWrapper(BaseModelWrapper):
     """model_entry.py:192-240."""
 
     def __init__(self, ckpt_path=None, in_channels: int = 16, out_channels: int = 16, dtype: torch.dtype = torch.bfloat16,
-                 quant_type: Optional[torch.dtype] = None, kernel_backend: str = "hip", cache: AutoCache = None, **kwargs):
+                 quant_type: Optional[torch.dtype] = None, kernel_backend: str = "hip", cache: AutoCache = None, need_resolve_oom=False,
+                 **kwargs):
         super().__init__(kernel_backend)
         quantized_cache = kwargs.pop("quantized_cache", None)
         self.dtype = dtype
+        self.need_resolve_oom = need_resolve_oom        # accepted as in the reference (model_entry.py:206); no tiled VAE is needed here
         self.core_model = SD3TransformerModelCore(in_channels=in_channels, out_channels=out_channels, data_type=dtype, quant_dtype=quant_type,
                                                   cache=cache, **kwargs)
         c = self.core_model.config
@@ -231,46 +233,42 @@ def list_available_models() -> List[str]:
 
 
 class FastDMEngine:
-    """model_entry.py:529-793 for architecture='flux'.
+    """model_entry.py:529-834.
 
-    With diffusers + a checkpoint: `DiffusionPipeline.from_pretrained(model_path)`, swap
-    `pipe.transformer` for our wrapper (model_entry.py:656-667), `generate()` calls the pipeline.
-    Without (model_path == '' or diffusers missing): synthetic weights + `SyntheticFluxPipeline`, whose
+    With diffusers + a checkpoint directory (`_init_checkpoint_pipeline`): the architecture's pipeline class is loaded from `model_path`
+    and its denoiser -- `unet` (sdxl), `transformer` (flux / sd35 / qwen), `transformer` + `transformer_2` with one step cache each
+    (wan, wan-i2v: Wan2.2-A14B's two experts) -- is replaced by ours built from the pipeline's own state_dict; `generate()` calls the
+    pipeline with the reference's kwargs.  diffusers is not in this image: tests/test_engine_checkpoint_gpu.py drives this branch with
+    a test double of the pipeline classes fed from synthetic safetensors directories.
+    Without (model_path == '' or no such directory): synthetic weights + the `Synthetic*Pipeline` of the architecture, whose
     `generate()` returns the final packed latents instead of a decoded image."""
 
     def __init__(self, model_path, architecture="flux", device=0, data_type="bfloat16", use_fp8=False, use_int8=False,
                  kernel_backend="hip", cache_config=None, oom_resolve=False, use_diffusers=True, task="t2i",
                  sparse_attn_config=None, synthetic_seed=0, **model_kwargs):
-        if architecture not in ("flux", "qwen", "wan", "sd35", "sdxl"):
+        if architecture not in ("flux", "qwen", "wan", "wan-i2v", "sd35", "sdxl"):
             raise NotImplementedError(f"architecture '{architecture}' is not built yet (SURVEY.md §8f)")
         if data_type != "bfloat16":
-            raise NotImplementedError("bfloat16 activations only in this build")
-        if sparse_attn_config and architecture != "wan":
+            raise NotImplementedError("bfloat16 activations only: the HIP kernels of this path are written for bf16 (the reference's float16 "
+                                      "column is its RTX-8000 one, /root/reference/fastdm/model_entry.py:572)")
+        if sparse_attn_config and architecture not in ("wan", "wan-i2v"):
             raise ValueError("Sparse attention is only supported for Wan models")
         self.architecture, self.device, self.task = architecture, device, task
+        self.oom_resolve, self.use_diffusers = oom_resolve, use_diffusers
         torch.cuda.set_device(device)
         self.dtype = torch.bfloat16
         self.quant_type = torch.float8_e4m3fn if use_fp8 else (torch.int8 if use_int8 else None)
         self.cache = AutoCache.from_json(cache_config) if cache_config else None
+        # Wan2.2-A14B is two experts (transformer: high noise, transformer_2: low noise) with a step cache each (model_entry.py:586-590)
+        self.cache_2 = AutoCache.from_json(cache_config) if cache_config and architecture in ("wan", "wan-i2v") else None
+        self.sparse_attn = None
         self.pipe = None
         have_ckpt = bool(model_path) and os.path.exists(model_path)
         if have_ckpt:
-            try:
-                from diffusers import DiffusionPipeline
-            except ImportError as e:
-                raise ImportError("a checkpoint path was given but diffusers is not installed; use model_path='' for the "
-                                  "synthetic pipeline") from e
-            self.pipe = DiffusionPipeline.from_pretrained(model_path, torch_dtype=self.dtype, use_safetensors=True)
-            if self.cache:
-                self.cache.config.current_steps_callback = lambda: self.pipe.scheduler.step_index
-                self.cache.config.total_steps_callback = lambda: self.pipe.scheduler.timesteps.shape[0]
-            if architecture == "sdxl":    # model_entry.py:640-655: the UNet is the swapped module and has no step cache
-                self.pipe.unet = create_model("sdxl", ckpt_path=self.pipe.unet.state_dict(), dtype=self.dtype, quant_type=self.quant_type,
-                                              kernel_backend=kernel_backend).eval()
-            else:
-                self.pipe.transformer = create_model(architecture, ckpt_path=self.pipe.transformer.state_dict(), dtype=self.dtype,
-                                                     quant_type=self.quant_type, kernel_backend=kernel_backend, cache=self.cache).eval()
-            self.pipe.to("cuda")
+            self._init_checkpoint_pipeline(model_path, kernel_backend, sparse_attn_config)
+        elif architecture == "wan-i2v":
+            raise NotImplementedError("the synthetic pipeline has no image-to-video loop; 'wan-i2v' needs a checkpoint directory and diffusers "
+                                      "(the I2V transformer cores themselves are built and tested: tests/test_wan_gpu.py)")
         elif architecture == "wan":
             from fastdm_amd.pipeline import SyntheticWanPipeline
             from fastdm_amd.sparse import SparseAttn
@@ -331,6 +329,80 @@ class FastDMEngine:
                 self.cache.config.current_steps_callback = lambda: self.pipe.scheduler_step_index
                 self.cache.config.total_steps_callback = lambda: self.pipe.num_steps
 
+    def _init_checkpoint_pipeline(self, model_path, kernel_backend, sparse_attn_config):
+        """model_entry.py:606-700: load the diffusers pipeline of `model_path`, then (unless use_diffusers asks for the stock modules)
+        swap its denoiser(s) for ours built from the pipeline's own state_dict, wire the step-cache / radial-attention callbacks to the
+        pipeline's scheduler, and move the pipeline to the GPU."""
+        try:
+            import diffusers
+        except ImportError as e:
+            raise ImportError("a checkpoint path was given but diffusers is not installed; use model_path='' for the synthetic pipeline") from e
+        arch = self.architecture
+        if sparse_attn_config:
+            from fastdm_amd.sparse import SparseAttn
+            self.sparse_attn = SparseAttn.from_json(sparse_attn_config)
+        if arch == "wan":          # model_entry.py:608-618: the Wan VAE is loaded in fp32
+            vae = diffusers.AutoencoderKLWan.from_pretrained(model_path, subfolder="vae", torch_dtype=torch.float32)
+            self.pipe = diffusers.WanPipeline.from_pretrained(model_path, vae=vae, torch_dtype=torch.bfloat16)
+        elif arch == "wan-i2v":
+            self.pipe = diffusers.WanImageToVideoPipeline.from_pretrained(model_path, torch_dtype=torch.bfloat16, use_safetensors=True)
+        else:
+            self.pipe = diffusers.DiffusionPipeline.from_pretrained(model_path, torch_dtype=self.dtype, use_safetensors=True)
+        if self.use_diffusers:      # the stock pipeline, untouched (model_entry.py:631-632)
+            self.pipe.to("cuda")
+            return
+        self.model_path = model_path
+        for cache in (self.cache, self.cache_2):
+            if cache is not None:
+                cache.config.current_steps_callback = lambda: self.pipe.scheduler.step_index
+                cache.config.total_steps_callback = lambda: self.pipe.scheduler.timesteps.shape[0]
+        if self.sparse_attn is not None and self.sparse_attn.config.sparse_algorithm == "radial":
+            self.sparse_attn.config.current_steps_callback = lambda: self.pipe.scheduler.step_index
+        common = dict(dtype=self.dtype, quant_type=self.quant_type, kernel_backend=kernel_backend)
+        if arch == "sdxl":          # the UNet is the swapped module and has no step cache
+            self.pipe.unet = create_model("sdxl", ckpt_path=self.pipe.unet.state_dict(), **common).eval()
+        elif arch in ("flux", "sd35", "qwen"):
+            self.pipe.transformer = create_model(arch, ckpt_path=self.pipe.transformer.state_dict(), cache=self.cache,
+                                                 need_resolve_oom=self.oom_resolve, **common).eval()
+            # (the reference's oom_resolve also swaps tiled VAE decoders in, fastdm/utils/{qwen,flux}_vae.py: with 288 GB of HBM the
+            # stock decoders fit, so the flag is accepted and changes nothing here)
+        else:                       # wan / wan-i2v: one or two experts, each with its config.json and its own cache
+            self.pipe.transformer = create_model("wan", ckpt_path=self.pipe.transformer.state_dict(), cache=self.cache, sparse_attn=self.sparse_attn,
+                                                 config_json=f"{model_path}/transformer/config.json", **common).eval()
+            if getattr(self.pipe, "transformer_2", None) is not None:
+                self.pipe.transformer_2 = create_model("wan", ckpt_path=self.pipe.transformer_2.state_dict(), cache=self.cache_2,
+                                                       sparse_attn=self.sparse_attn, config_json=f"{model_path}/transformer_2/config.json",
+                                                       **common).eval()
+        self.pipe.to("cuda")
+        torch.cuda.empty_cache()
+
+    def i2v_image_processor(self, input_image, width=832, height=480):
+        """model_entry.py:796-810: resize the source image to the requested AREA at its own aspect ratio, on the VAE x patch grid."""
+        import numpy as np
+        if isinstance(input_image, str):
+            if not os.path.isfile(input_image):
+                raise FileNotFoundError(f"Input image file does not exist: {input_image}")
+            from diffusers.utils import load_image
+            input_image = load_image(input_image)
+        aspect = input_image.height / input_image.width
+        mod = self.pipe.vae_scale_factor_spatial * self.pipe.transformer.config.patch_size[1]
+        h = round(np.sqrt(height * width * aspect)) // mod * mod
+        w = round(np.sqrt(height * width / aspect)) // mod * mod
+        return input_image.resize((w, h)), h, w
+
+    def i2i_image_processor(self, input_image, width=832, height=480):
+        """model_entry.py:812-834: one image (path or already loaded) or a list of them; the generation takes their largest size."""
+        def load(x):
+            if isinstance(x, str) and os.path.isfile(x):
+                from diffusers.utils import load_image
+                return load_image(x)
+            return x
+        if isinstance(input_image, list):
+            images = [load(x) for x in input_image]
+            return images, max(i.height for i in images), max(i.width for i in images)
+        image = load(input_image)
+        return image, image.height, image.width
+
     def generate(self, prompt=None, negative_prompt=None, src_image=None, num_frames=None, steps=50, guidance_scale=3.5,
                  true_cfg_scale=None, gen_seed=42, gen_width=512, gen_height=512, max_seq_len=512):
         from fastdm_amd.pipeline import (SyntheticFluxPipeline, SyntheticQwenPipeline, SyntheticSD3Pipeline, SyntheticSDXLPipeline,
@@ -347,10 +419,24 @@ class FastDMEngine:
         if isinstance(self.pipe, SyntheticFluxPipeline):
             return self.pipe(num_inference_steps=steps, guidance_scale=guidance_scale, width=gen_width, height=gen_height,
                              max_sequence_length=max_seq_len, seed=gen_seed)
+        # checkpoint pipelines: the reference's kwargs (model_entry.py:748-793)
         gen = torch.Generator().manual_seed(gen_seed)
         kwargs = {"prompt": prompt, "negative_prompt": negative_prompt, "num_inference_steps": steps, "generator": gen,
-                  "max_sequence_length": max_seq_len, "width": gen_width, "height": gen_height, "guidance_scale": guidance_scale}
-        if true_cfg_scale is not None and self.architecture == "qwen":
+                  "max_sequence_length": max_seq_len}
+        if src_image is not None and self.task == "i2v":
+            kwargs["image"], gen_height, gen_width = self.i2v_image_processor(src_image, width=gen_width, height=gen_height)
+        elif src_image is not None and self.task == "i2i":
+            kwargs["image"], gen_height, gen_width = self.i2i_image_processor(src_image, width=gen_width, height=gen_height)
+        if self.sparse_attn is not None:      # sizes rounded up to the sparse block
+            bs = self.sparse_attn.config.block_size
+            gen_height, gen_width = (gen_height + bs - 1) // bs * bs, (gen_width + bs - 1) // bs * bs
+        kwargs["width"], kwargs["height"] = gen_width, gen_height
+        if num_frames is not None:
+            kwargs["num_frames"] = num_frames
+        if true_cfg_scale is not None:        # Qwen-Image
             kwargs["true_cfg_scale"] = true_cfg_scale
+        else:
+            kwargs["guidance_scale"] = guidance_scale
         with torch.inference_mode():
-            return self.pipe(**kwargs).images[0]
+            output = self.pipe(**kwargs)
+        return output.frames[0] if num_frames is not None else output.images[0]

@@ -55,7 +55,7 @@ def main():
         torch.cuda.synchronize()
         res[name] = [kern, hashlib.sha256(out.cpu().view(torch.int16).numpy().tobytes()).hexdigest()]
     # image + text pair in one launch, fused q|k|v written as three planes (the FLUX double-block projection)
-    hd3, s_txt, s_img, kk = 1024, 512, 3584, 1024
+    hd3, s_txt, s_img, kk = 1024, 512, 7168, 1024      # 28 x 12 + 2 x 12 = 360 tiles
     p_img, p_txt = problem(g, s_img, kk, 3 * hd3), problem(g, s_txt, kk, 3 * hd3)
     planes = torch.full((3, s_txt + s_img, hd3), 5.0, dtype=BF16, device="cuda")
     d_txt = desc(p_txt, planes[0, :s_txt], N.EPI_NONE, hd3, hd3, (s_txt + s_img) * hd3)
@@ -66,7 +66,7 @@ def main():
     torch.cuda.synchronize()
     res["pair_planes"] = [kern, hashlib.sha256(planes.cpu().view(torch.int16).numpy().tobytes()).hexdigest()]
     # pair with a GELU epilogue, no planes
-    p0, p1 = problem(g, 3840, 1024, 4096), problem(g, 256, 1024, 4096)
+    p0, p1 = problem(g, 4096, 1024, 4096), problem(g, 256, 1024, 4096)      # 256 + 16 tiles
     o0, o1 = (torch.full((p["m"], 4096), 1.0, dtype=BF16, device="cuda") for p in (p0, p1))
     rc = N.lib().fdm_gemm_w8a8_fp8_x2(ctypes.byref(desc(p0, o0, N.EPI_GELU_TANH, 4096)), ctypes.byref(desc(p1, o1, N.EPI_GELU_TANH, 4096)), s)
     assert rc == 0, rc

@@ -54,6 +54,19 @@ def test_shard_and_gather_ragged():
     _run(2, 3)
 
 
+def test_shard_and_gather_world8_ragged_nine_images():
+    """BASELINE.json's 8-GPU layout on the host side: dp8 over a 9-image batch (rank 0 owns images 0 and 8, the others one each);
+    every rank must end with all nine images in order after the job's single all-gather (reference pattern: one process per GPU over
+    the prompts, /root/reference/examples/evaluation/clip_score.py:346-365)."""
+    from fastdm_amd import distributed as D
+    assert [D.shard_indices(9, r, 8) for r in range(8)] == [[0, 8], [1], [2], [3], [4], [5], [6], [7]]
+    _run(8, 9)
+
+
+def test_shard_and_gather_world8_fewer_images_than_ranks():
+    _run(8, 5)
+
+
 def test_single_process_is_identity():
     from fastdm_amd import distributed as D
     x = torch.randn(2, 5, 3)
@@ -143,6 +156,13 @@ def test_cfg_pair_matches_two_forward_loop_world2():
 
 def test_two_cfg_pairs_world4():
     _run_pairs(4)
+
+
+def test_four_cfg_pairs_world8():
+    """BASELINE.json configs[3]'s layout (Qwen-Image, CFG pairs over 8 GPUs): ranks (2i, 2i + 1) own image i; each member runs one
+    branch, the pair exchanges its two noise predictions once per step, the job ends with one gather over the pair leaders --
+    latents equal the single-process two-forward loop bit for bit for all four images."""
+    _run_pairs(8)
 
 
 def test_cfg_pair_guards():

@@ -31,6 +31,27 @@ def test_two_ranks_one_device_gloo(mode):
     _run(mode, "--world", "2", "--backend", "gloo", "--same-device")
 
 
+@pytest.mark.parametrize("mode", ["flux_shard", "qwen_pair"])
+def test_eight_ranks_one_device_gloo(mode):
+    """BASELINE.json's 8-GPU layouts with REAL HIP forwards on one device: dp8 over 9 images (rank 0 owns two), and four CFG
+    pairs; every rank's gathered latents equal the single-process loop bit for bit."""
+    _run(mode, "--world", "8", "--backend", "gloo", "--same-device")
+
+
+def test_bench_qwen_four_cfg_pairs_eight_ranks_one_device():
+    """`bench.py --model qwen --gpus 8 --cfg-pair` -- the launch line of BASELINE.json configs[3] -- as a plain command on a 1-GPU
+    box: 8 spawned ranks on cuda:0 over gloo, reduced depth; one JSON line from rank 0 that says what it is."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--model", "qwen", "--gpus", "8", "--cfg-pair", "--same-device", "--layers", "2",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing"], capture_output=True, text=True, timeout=1800, env=env)
+    assert res.returncode == 0, res.stderr[-4000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["config"]["ranks_in_process_group"] == 8 and line["config"]["global_batch"] == 4 and line["value"] > 0
+    assert "PROTOCOL TEST" in line["scaling_note"] and "REDUCED DEPTH" in line["config"]["workload"]
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL)")
 @pytest.mark.parametrize("mode", MODES)
 def test_two_ranks_rccl(mode):

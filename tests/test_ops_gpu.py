@@ -291,6 +291,42 @@ def test_fp8_matmul_reference_shapes(K, M, Kd, Nn):
     assert torch.isfinite(got.float()).all()
 
 
+@pytest.mark.parametrize("dt", ["fp8", "int8", "bf16"])
+def test_matmul_full_matrix_at_c3_shape(K, dt):
+    """EVERY element of one C3-sized product per dtype ([8704, 3072] x [3072, 9216]: the single-stream QKV projection, 1224 tiles = 4.8
+    rounds of 256 CUs -- 256-row tiles, the persistent and the one-tile-per-block kernels, all raster groups incl. the 2-row last one)
+    against the oracle's definition, not ~50 sampled rows.  fp8 / bf16: <= 1 bf16 ulp; int8: bit-exact."""
+    M, Kd, Nn = 8704, 3072, 9216
+    g = gen(4242)
+    bias = rbf(g, Nn)
+    if dt == "fp8":
+        a = torch.randn(M, Kd, generator=g).to(FP8)
+        b = torch.randn(Nn, Kd, generator=g).to(FP8).t()
+        sa, sb = torch.rand(M, 1, generator=g) + 0.5, torch.rand(Nn, 1, generator=g) * 0.02 + 0.001
+        got = K.fp8_matmul(a.cuda(), b.t().contiguous().cuda().t(), sa.cuda(), sb.cuda(), BF16, bias.cuda()).cpu()
+        ref = O.fp8_matmul(a, b, sa, sb, BF16, bias)
+        ulp_close(got, ref, 0.03, "fp8 full matrix")
+    elif dt == "int8":
+        a = torch.randint(-128, 128, (M, Kd), generator=g).to(torch.int8)
+        b = torch.randint(-128, 128, (Nn, Kd), generator=g).to(torch.int8).t()
+        sa, sb = torch.rand(M, 1, generator=g) * 0.01 + 0.001, torch.rand(Nn, 1, generator=g) * 0.01 + 0.001
+        adj = b.to(torch.int32).sum(dim=0, keepdim=True, dtype=torch.int32)
+        azp = torch.randint(-128, 127, (M, 1), generator=g).to(torch.int32)
+        got = K.int8_matmul(a.cuda(), b.t().contiguous().cuda().t(), sa.cuda(), sb.cuda(), BF16, adj.cuda(), azp.cuda(), bias.cuda()).cpu()
+        # the oracle's exact float64 accumulate, in row chunks (a [8704, 9216] float64 product at once is 640 MB)
+        ref = torch.cat([O.int8_matmul(a[r:r + 1088], b, sa[r:r + 1088], sb, BF16, adj, azp[r:r + 1088], bias) for r in range(0, M, 1088)])
+        assert torch.equal(got, ref), f"int8 full matrix: {(got != ref).sum().item()} of {got.numel()} elements differ"
+    else:
+        from fastdm_amd import _native as N
+        a = rbf(g, M, Kd)
+        w = (torch.randn(Nn, Kd, generator=g) * 0.05).to(BF16)            # [N, K]: the [K, N] weight with stride(0) == 1
+        out = torch.empty(M, Nn, dtype=BF16, device="cuda")
+        ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+        N.check(N.lib().fdm_gemm_bf16(N.ptr(out), N.ptr(ad), N.ptr(wd), N.ptr(bd), M, Nn, Kd, Kd, Kd, Nn, N.EPI_NONE, None, 0, None, 0, N.stream()), "bf16 gemm")
+        ref = (a.float() @ w.float().t() + bias.float()).to(BF16)
+        ulp_close(out.cpu(), ref, 0.03, "bf16 full matrix")
+
+
 @pytest.mark.parametrize("M,Kd,Nn", MM_SHAPES[::3] + [[130, 16, 16], [257, 48, 272]] + RAGGED_M_SHAPES)
 def test_int8_matmul_reference_shapes(K, M, Kd, Nn):
     g = gen(M * 13 + Kd * 5 + Nn)

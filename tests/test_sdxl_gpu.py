@@ -5,11 +5,13 @@
 * tests/golden/sdxl_full.npz: SDXL-base at full width (2.6 B synthetic parameters, generated bit-identically on the GPU)
   through the reference's own core and loaders, 256x256 image, CFG batch 2, bf16 / fp8.
 """
+import os
+
 import pytest
 import torch
 
 from oracle import sdxl as OX
-from oracle.make_golden import load
+from oracle.make_golden import GOLD, load
 
 pytestmark = pytest.mark.gpu
 BF16, FP8 = torch.bfloat16, torch.float8_e4m3fn
@@ -73,6 +75,54 @@ def test_full_width_sdxl_against_reference_core(tag, qt):
     print(f"SDXL full width {tag}: max|d| {d.max().item():.4f} mean|d| {d.mean().item():.5f} on mean|ref| {ref.float().abs().mean().item():.3f}")
     lim = {"bf16": (1.2e-1, 1.5e-2), "fp8": (4e-1, 5e-2)}[tag]
     assert torch.isfinite(out.float()).all() and d.max() <= lim[0] and d.mean() <= lim[1], (tag, d.max().item(), d.mean().item())
+
+
+@pytest.mark.parametrize("tag,qt", [("bf16", None), ("fp8", FP8)])
+def test_baseline_config1_sdxl_512x512_four_steps_against_reference(tag, qt):
+    """BASELINE.json configs[0] on the HIP path: SDXL-base-1.0 UNet at full width, 512 x 512 (latent 64 x 64), 4 denoise steps, CFG as one
+    batch-2 forward.  The fixture (`python -m oracle.make_golden c1`) holds the same 4-step loop through the reference's own core on CPU:
+    every step's UNet output and latents.  Two checks per step: the UNet output given the REFERENCE's latents of the previous step (no
+    error carried over: the per-forward deviation, limits as the 256 x 256 full-width test), and the free-running trajectory's latents."""
+    from fastdm_amd.model_entry import create_model
+    from fastdm_amd.pipeline import SyntheticSDXLPipeline
+    from fastdm_amd.synthetic import SyntheticSDXLStateDict, sdxl_step_inputs
+    path = "sdxl_c1_512x512_4steps.npz"
+    if not os.path.exists(os.path.join(GOLD, path)):
+        pytest.skip(f"{path} not generated")
+    g = load(path)
+    if f"lat_{tag}_0" not in g:
+        pytest.skip(f"{path} has no {tag} trajectory")
+    seed, steps, guidance, hw = int(g["seed"]), int(g["steps"]), float(g["guidance"]), int(g["height"])
+    model = create_model("sdxl", ckpt_path=SyntheticSDXLStateDict(seed=seed), dtype=BF16, quant_type=qt, kernel_backend="hip").eval()
+    pipe = SyntheticSDXLPipeline(model, seed=seed)
+    ts, sig = pipe.schedule(steps)
+    assert [int(t) for t in ts] == [int(t) for t in g["timesteps"]] and torch.equal(torch.tensor(sig), g["sigmas"].float())
+    inp = sdxl_step_inputs(2, hw, hw, int(g["n_txt"]), seed=seed)
+    lat = (inp["sample"][0:1].float() * float(sig[0])).to(BF16)
+    lines = []
+    lim_eps = {"bf16": (1.5e-1, 1.5e-2), "fp8": (5e-1, 5e-2)}[tag]
+    for i in range(steps):
+        # (a) one forward from the reference's own latents
+        prev = (inp["sample"][0:1].float() * float(sig[0])).to(BF16) if i == 0 else g[f"lat_{tag}_{i - 1}"].cuda()
+        x = (prev.float() / ((float(sig[i]) ** 2 + 1.0) ** 0.5)).to(BF16)
+        eps = model(x.expand(2, -1, -1, -1).contiguous(), torch.tensor(float(ts[i])).cuda(), inp["encoder_hidden_states"], inp["added_cond_kwargs"])[0]
+        de = (eps.float().cpu() - g[f"eps_{tag}_{i}"].float()).abs()
+        # (b) the free-running loop
+        lat = pipe.step(lat, inp, ts[i], float(sig[i]), float(sig[i + 1]), guidance)
+        dl = (lat.float().cpu() - g[f"lat_{tag}_{i}"].float()).abs()
+        ref_mag = g[f"lat_{tag}_{i}"].float().abs().mean().item()
+        lines.append(f"SDXL 512x512 {tag} step {i}: UNet output max|d| {de.max().item():.4f} mean {de.mean().item():.5f} (mean|eps| {g[f'eps_{tag}_{i}'].float().abs().mean().item():.3f})"
+                     f" | latents max|d| {dl.max().item():.4f} mean {dl.mean().item():.5f} (mean|lat| {ref_mag:.3f})")
+        assert torch.isfinite(eps.float()).all() and de.max() <= lim_eps[0] and de.mean() <= lim_eps[1], lines[-1]
+        # latents: x += d_sigma * (eps_u + g (eps_c - eps_u)): a per-forward deviation e reaches the latents as ~ sqrt((g - 1)^2 + g^2) |d_sigma| e
+        # (first order, g = 5: 6.4 x; sigma runs 14.6 -> 0 over the 4 steps), so the free-running limit is that propagation of the
+        # per-forward limit over the sigma already travelled -- a gross-error bound, the per-forward check above is the sharp one
+        travelled = float(sig[0] - sig[i + 1])
+        assert dl.mean() <= 6.4 * lim_eps[1] * travelled, lines[-1] + f" (limit {6.4 * lim_eps[1] * travelled:.3f})"
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/sdxl_c1_parity_{tag}.txt", "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
 
 
 def test_sdxl_blocks_keep_reference_signatures_and_errors():
