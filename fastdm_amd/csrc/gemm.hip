@@ -1408,19 +1408,6 @@ struct P4Args {           // offsets are part of the assembly's contract (gen_ge
 };
 static_assert(sizeof(P4Args) == 192, "P4Args layout is read by offset in gemm_p4_body_*.inc");
 __device__ __attribute__((aligned(256))) uint8_t g_zero_bias[65536] = {0};   // bias == nullptr: 32 K columns of bf16 zeros
-static const void* g_zero_bias_ptr() {      // device address of g_zero_bias, per device (looked up once per device)
-  static const void* ptr[64] = {nullptr};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  dev = dev < 0 || dev > 63 ? 0 : dev;
-  if (!ptr[dev]) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_bias)) != hipSuccess) return nullptr;
-    ptr[dev] = p;
-  }
-  return ptr[dev];
-}
-
 #ifndef FDM_P4_BODY_NONE
 #define FDM_P4_BODY_NONE "gemm_p4_body_none.inc"     // (bring-up builds point this at a generator variant)
 #endif
@@ -1429,11 +1416,12 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_p4_kernel(const P4Args arg
   __shared__ __attribute__((aligned(1024))) uint8_t smem[160 * 1024];   // 128 KiB ring + 4 x 8 KiB epilogue strips
   const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t lds0 = lds_addr_of(smem);
+  const uint8_t* zero_bias = g_zero_bias;      // what a null bias pointer is replaced by inside the assembly
   if constexpr (EPI == FDM_EPI_NONE) {
     asm volatile(
 #include FDM_P4_BODY_NONE
         :
-        : "s"(ka), "s"(blockIdx.x), "v"(threadIdx.x), "s"(lds0)
+        : "s"(ka), "s"(blockIdx.x), "v"(threadIdx.x), "s"(lds0), "s"(zero_bias)
         :
 #include "gemm_p4_clobbers.inc"
     );
@@ -1441,7 +1429,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_p4_kernel(const P4Args arg
     asm volatile(
 #include "gemm_p4_body_gelu_tanh.inc"
         :
-        : "s"(ka), "s"(blockIdx.x), "v"(threadIdx.x), "s"(lds0)
+        : "s"(ka), "s"(blockIdx.x), "v"(threadIdx.x), "s"(lds0), "s"(zero_bias)
         :
 #include "gemm_p4_clobbers.inc"
     );
@@ -1450,7 +1438,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_p4_kernel(const P4Args arg
     asm volatile(
 #include "gemm_p4_body_gelu_erf.inc"
         :
-        : "s"(ka), "s"(blockIdx.x), "v"(threadIdx.x), "s"(lds0)
+        : "s"(ka), "s"(blockIdx.x), "v"(threadIdx.x), "s"(lds0), "s"(zero_bias)
         :
 #include "gemm_p4_clobbers.inc"
     );
@@ -1547,8 +1535,7 @@ static bool use_p4(const GemmGroup& grp, P4Args& pa) {
   memset(&pa, 0, sizeof(pa));
   for (int i = 0; i < 2; ++i) {
     const GemmProblem& q = grp.p[i < grp.n ? i : 0];
-    pa.p[i] = P4Prob{q.A, q.B, q.C, q.sa, q.sb, q.bias ? (const void*)q.bias : g_zero_bias_ptr(), q.gate, q.res};
-    if (!pa.p[i].bias) return false;
+    pa.p[i] = P4Prob{q.A, q.B, q.C, q.sa, q.sb, q.bias, q.gate, q.res};      // (a null bias becomes g_zero_bias inside the kernel)
   }
   pa.tiles_m0 = a.tiles_m;
   pa.tiles_m1 = grp.n > 1 ? grp.p[1].tiles_m : 0;

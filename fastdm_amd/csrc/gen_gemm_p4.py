@@ -22,7 +22,7 @@ Structure of one block (256 threads = 4 waves, ONE per SIMD, wave tile 128 x 128
   * per-tile epilogue operands (sa rows, sb / bias columns) are requested in the tile's last K step and sit in 72 dedicated VGPRs.
 
 The emitted text is the body of ONE `asm volatile` statement of gemm.hip (operands: %0 kernel-argument pointer, %1 blockIdx.x,
-%2 threadIdx.x, %3 LDS base of the block's 160 KiB); it clobbers v8-v255, a0-a255, s8-s101, vcc.
+%2 threadIdx.x, %3 LDS base of the block's 160 KiB, %4 address of a zero bias vector); it clobbers v8-v255, a0-a255, s8-s101, vcc.
 """
 import os
 import sys
@@ -125,6 +125,10 @@ def build(epi):
     # problem fields: 0-1 A, 2-3 B, 4-5 C, 6-7 sa, 8-9 sb, 10-11 bias
     TM0, TM1, TN, T0T, TOTAL, NK, LDA, LDB, LDCB, PCOLS, PSTRB, STRIDE = (g.s1("cfg", i) for i in range(12))   # STRIDE = blocks per XCD = grid / 8
     e("s_waitcnt lgkmcnt(0)")
+    # bias == nullptr: 32 K columns of bf16 zeros in the library's own device memory (%4)
+    for nm in ("p0", "p1"):
+        e(f"s_cmp_eq_u64 {g.s2(nm, 10)}, 0")
+        e(f"s_cselect_b64 {g.s2(nm, 10)}, %4, {g.s2(nm, 10)}")
 
     c("---- lane decomposition")
     lane, fi, fq = T[1], T[2], T[3]
