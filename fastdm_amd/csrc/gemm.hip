@@ -757,7 +757,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
 // 256 CUs in MFMA-dense code the clock falls to ~1.35 GHz, so wall time follows energy per flop, not cycles).
 //   waves     4 (ONE per SIMD), 2 (M) x 2 (N), wave tile 128 x 128: a wave reads 128 + 128 operand rows per K byte instead of
 //             128 + 64, i.e. 64 KB of LDS fragment reads per 64 bytes of K and CU instead of 96 KB
-//   MFMA      16x16 shapes: v_mfma_scale_f32_16x16x128_f8f6f4 / v_mfma_i32_16x16x64_i8 / v_mfma_f32_16x16x32_bf16 (the chip
+//   MFMA      16x16 shapes: v_mfma_f32_16x16x128_f8f6f4 (non-scaled encoding) / v_mfma_i32_16x16x64_i8 / v_mfma_f32_16x16x32_bf16 (the chip
 //             holds a higher clock on them than on the 32x32 shapes)
 //   K step    128 bytes, two 64 KiB stages (512 rows x 128 B): an LDS-DMA instruction moves 8 whole 128-byte lines.
 //             16-byte chunk c of row r sits in slot ((c >> 1) ^ g(r)) * 2 + (c & 1), g(r) = bit 1 of r | bit 3 of r << 1: the
@@ -799,14 +799,13 @@ struct Mma16<DT_FP8> {
   static constexpr int KS = 128;  // bytes of K per MFMA
   using Frag = i32x8;
   template <int IDX, bool ZERO = false>
-  static __device__ __forceinline__ void run(const Frag& a, const Frag& b) {   // unit E8M0 scales (0x7f = 2^0) for both operands
-    const int one = 0x7f7f7f7f;
+  static __device__ __forceinline__ void run(const Frag& a, const Frag& b) {
+    // the NON-scaled encoding (cbsz = blgp = 0: e4m3 x e4m3): bit-identical to v_mfma_scale_f32_16x16x128_f8f6f4 with unit E8M0 scales
+    // (round 3's form; 0 of 80 M elements differ), half the instruction bytes and no scale register to read: 1-2 % in the A/B of round 4
     if constexpr (ZERO)   // a tile's first K step: C = 0 as an inline constant (the 256 accumulator registers are never zeroed)
-      asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 a[%c2:%c3], %0, %1, 0, %4, %4 op_sel_hi:[0,0,0]" ::"v"(a), "v"(b),
-                   "n"(4 * IDX), "n"(4 * IDX + 3), "v"(one));
+      asm volatile("v_mfma_f32_16x16x128_f8f6f4 a[%c2:%c3], %0, %1, 0" ::"v"(a), "v"(b), "n"(4 * IDX), "n"(4 * IDX + 3));
     else
-      asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 a[%c2:%c3], %0, %1, a[%c2:%c3], %4, %4 op_sel_hi:[0,0,0]" ::"v"(a), "v"(b),
-                   "n"(4 * IDX), "n"(4 * IDX + 3), "v"(one));
+      asm volatile("v_mfma_f32_16x16x128_f8f6f4 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(4 * IDX), "n"(4 * IDX + 3));
   }
 };
 template <>

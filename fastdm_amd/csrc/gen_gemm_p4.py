@@ -372,7 +372,12 @@ def build(epi):
     # ================================================================================================ building blocks
     def mfma(idx, bfrag, afrag, zero):
         cc = "0" if zero else f"a[{4 * idx}:{4 * idx + 3}]"
-        return f"v_mfma_scale_f32_16x16x128_f8f6f4 a[{4 * idx}:{4 * idx + 3}], {vr(bfrag, 8)}, {vr(afrag, 8)}, {cc}, v{ONE}, v{ONE} op_sel_hi:[0,0,0]"
+        # the NON-scaled encoding of the same fp8 MFMA (cbsz = blgp = 0: e4m3 x e4m3): 8 bytes instead of 16, no scale operands to read.
+        # Bit-identical to v_mfma_scale_... with unit E8M0 scales (0 of 80 M elements differ) and 1-2 % faster in the A/B
+        # (profiles/r04_experiments.md); P4_SCALED=1 (bring-up builds) emits the scaled form.
+        if os.environ.get("P4_OUT") and os.environ.get("P4_SCALED"):
+            return f"v_mfma_scale_f32_16x16x128_f8f6f4 a[{4 * idx}:{4 * idx + 3}], {vr(bfrag, 8)}, {vr(afrag, 8)}, {cc}, v{ONE}, v{ONE} op_sel_hi:[0,0,0]"
+        return f"v_mfma_f32_16x16x128_f8f6f4 a[{4 * idx}:{4 * idx + 3}], {vr(bfrag, 8)}, {vr(afrag, 8)}, {cc}"
 
     def read_frag(dst, base_lo, blk):
         return [f"ds_read_b128 {vr(dst, 4)}, v{base_lo} offset:{blk * 2048}",
@@ -385,9 +390,10 @@ def build(epi):
         lo, hi = pair("sta" if kind == "a" else "stb")
         step = A32 if kind == "a" else B32
         voff = V_OFFA if kind == "a" else V_OFFB
+        nt = " nt" if kind in os.environ.get("P4_NT", "") and os.environ.get("P4_OUT") else ""      # experiment: streaming hint on one operand
         return [f"s_add_u32 m0, {LDSW}, {lds_off}",
                 "s_nop 0",
-                f"global_load_lds_dwordx4 v{voff}, {st}",
+                f"global_load_lds_dwordx4 v{voff}, {st}{nt}",
                 f"s_add_u32 {lo}, {lo}, {step}",
                 f"s_addc_u32 {hi}, {hi}, 0"]
 

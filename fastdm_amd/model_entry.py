@@ -266,10 +266,10 @@ class FastDMEngine:
         have_ckpt = bool(model_path) and os.path.exists(model_path)
         if have_ckpt:
             self._init_checkpoint_pipeline(model_path, kernel_backend, sparse_attn_config)
-        elif architecture == "wan-i2v":
-            raise NotImplementedError("the synthetic pipeline has no image-to-video loop; 'wan-i2v' needs a checkpoint directory and diffusers "
-                                      "(the I2V transformer cores themselves are built and tested: tests/test_wan_gpu.py)")
-        elif architecture == "wan":
+        elif architecture in ("wan", "wan-i2v"):
+            if architecture == "wan-i2v":      # Wan2.2-I2V-A14B: the T2V wiring with 16 latent + 20 condition input channels
+                model_kwargs.setdefault("in_channels", 36)
+                model_kwargs.setdefault("out_channels", 16)
             from fastdm_amd.pipeline import SyntheticWanPipeline
             from fastdm_amd.sparse import SparseAttn
             from fastdm_amd.synthetic import SyntheticWanStateDict

@@ -159,7 +159,8 @@ class SyntheticQwenPipeline:
 
 
 class SyntheticWanPipeline:
-    """What diffusers' WanPipeline does around `pipe.transformer` for T2V with classifier-free guidance: latents
+    """What diffusers' WanPipeline (and, when the transformer takes more input than output channels, WanImageToVideoPipeline for
+    Wan2.2-I2V) does around `pipe.transformer` with classifier-free guidance: latents
     [B, 16, (frames-1)/4+1, H/8, W/8], `timestep = sigma * 1000`, a conditional and an unconditional forward per step,
     `noise = uncond + guidance * (cond - uncond)`, flow-match Euler update (shift 5 for 720p-class outputs)."""
 
@@ -180,8 +181,19 @@ class SyntheticWanPipeline:
             neg = synthetic.wan_step_inputs(batch, lf, height // 8, width // 8, max_sequence_length, cfg["in_channels"], cfg["text_dim"],
                                             seed=seed + 7919)
             pos["negative_encoder_hidden_states"] = neg["encoder_hidden_states"]
+            n_out = cfg.get("out_channels", cfg["in_channels"])
+            if cfg["in_channels"] > n_out:
+                # image-to-video (Wan2.2-I2V-A14B: 36 = 16 + 20 input channels, no image embedder): what WanImageToVideoPipeline feeds the
+                # transformer is cat([latents, condition], dim=1), condition = 4 first-frame mask channels + 16 channels of the encoded
+                # source image.  Synthetic: the latents are the first 16 channels of the generated tensor, the rest is the (fixed) condition.
+                full = pos["hidden_states"]
+                pos["hidden_states"], pos["condition"] = full[:, :n_out].contiguous(), full[:, n_out:].contiguous()
             self._inputs, self._inputs_key = pos, key
         return self._inputs
+
+    def _denoiser(self, latents, inp, t, enc):
+        x = latents if "condition" not in inp else torch.cat([latents, inp["condition"]], dim=1)
+        return self.transformer(x, timestep=t, encoder_hidden_states=enc, return_dict=False)[0]
 
     @staticmethod
     def sigmas(num_steps: int, shift: float = 5.0):
@@ -196,15 +208,15 @@ class SyntheticWanPipeline:
             name, key = ("cond", "encoder_hidden_states") if self.cfg_pair.role == 0 else ("uncond", "negative_encoder_hidden_states")
             self.cfg_pair.pin_cache(self.transformer)
             with self.transformer.cache_context(name):
-                mine = self.transformer(latents, timestep=t, encoder_hidden_states=inp[key], return_dict=False)[0]
+                mine = self._denoiser(latents, inp, t, inp[key])
             cond, uncond = self.cfg_pair.exchange(mine)
             noise = uncond.float() + guidance_scale * (cond.float() - uncond.float())
             return (latents.float() + float(sigma_next - sigma) * noise).to(latents.dtype)
         with self.transformer.cache_context("cond"):
-            cond = self.transformer(latents, timestep=t, encoder_hidden_states=inp["encoder_hidden_states"], return_dict=False)[0]
+            cond = self._denoiser(latents, inp, t, inp["encoder_hidden_states"])
         if guidance_scale is not None and guidance_scale > 1:
             with self.transformer.cache_context("uncond"):
-                uncond = self.transformer(latents, timestep=t, encoder_hidden_states=inp["negative_encoder_hidden_states"], return_dict=False)[0]
+                uncond = self._denoiser(latents, inp, t, inp["negative_encoder_hidden_states"])
             noise = uncond.float() + guidance_scale * (cond.float() - uncond.float())
         else:
             noise = cond.float()

@@ -280,5 +280,20 @@ def test_engine_rejects_what_it_cannot_do(fake_diffusers, tmp_path):
         FastDMEngine("", architecture="flux", sparse_attn_config="x.json")
     with pytest.raises(NotImplementedError, match="bfloat16"):
         FastDMEngine("", architecture="flux", data_type="float16")
-    with pytest.raises(NotImplementedError, match="checkpoint directory"):
-        FastDMEngine("", architecture="wan-i2v")
+
+
+def test_engine_synthetic_wan_i2v_feeds_latents_and_condition():
+    """architecture='wan-i2v' without a checkpoint: synthetic weights of the Wan2.2-I2V wiring (36 = 16 latent + 20 condition input
+    channels, 16 out) and the image-to-video loop -- every forward sees cat([latents, condition], dim=1), the latents stay 16-channel."""
+    from fastdm_amd.model_entry import FastDMEngine
+    eng = FastDMEngine("", architecture="wan-i2v", use_fp8=True, num_attention_heads=2, attention_head_dim=64, text_dim=96, ffn_dim=256, num_layers=2)
+    seen = []
+    orig = eng.pipe.transformer.forward
+
+    def spy(hidden_states, **kw):
+        seen.append(tuple(hidden_states.shape))
+        return orig(hidden_states, **kw)
+    eng.pipe.transformer.forward = spy
+    out = eng.generate(num_frames=5, steps=2, guidance_scale=4.0, gen_seed=1, gen_width=64, gen_height=64, max_seq_len=8)
+    assert tuple(out.shape) == (1, 16, 2, 8, 8) and torch.isfinite(out.float()).all()
+    assert seen == [(1, 36, 2, 8, 8)] * 4              # 2 steps x (cond, uncond)

@@ -10,6 +10,8 @@ python3 bench.py --quant int8 > "$out/${tag}_flux_int8_bench.json" 2> "$out/${ta
 python3 bench.py --model sd35 > "$out/${tag}_sd35_bench.json" 2> "$out/${tag}_sd35.err"
 python3 bench.py --model sdxl > "$out/${tag}_sdxl_bench.json" 2> "$out/${tag}_sdxl.err"
 python3 bench.py --model sdxl --graph > "$out/${tag}_sdxl_graph_bench.json" 2> "$out/${tag}_sdxl_graph.err"
+# BASELINE.json configs[0]: SDXL-base UNet 512 x 512, 4 steps (the line carries the CPU baseline of the same layers)
+python3 bench.py --model sdxl --height 512 --width 512 --steps 4 --warmup 1 > "$out/${tag}_sdxl_512_bench.json" 2> "$out/${tag}_sdxl_512.err"
 python3 bench.py --model wan > "$out/${tag}_wan_dense_bench.json" 2> "$out/${tag}_wan_dense.err"
 python3 bench.py --model wan --start-step 11 --sparse-config examples/sparse/radial_attn_wan.json > "$out/${tag}_wan_sparse_bench.json" 2> "$out/${tag}_wan_sparse.err"
-for f in qwen qwen_batchcfg flux_bf16_1024 flux_int8 sd35 sdxl sdxl_graph wan_dense wan_sparse; do echo "$f: $(tail -1 $out/${tag}_${f}_bench.json | cut -c1-60) ... $(tail -1 $out/${tag}_${f}_bench.json | grep -o '"ms_per_step": [0-9.]*')"; done
+for f in qwen qwen_batchcfg flux_bf16_1024 flux_int8 sd35 sdxl sdxl_graph sdxl_512 wan_dense wan_sparse; do echo "$f: $(tail -1 $out/${tag}_${f}_bench.json | cut -c1-60) ... $(tail -1 $out/${tag}_${f}_bench.json | grep -o '"ms_per_step": [0-9.]*')"; done
