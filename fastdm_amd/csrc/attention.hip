@@ -978,6 +978,27 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
 #endif
   };
 
+  // The same step for a wave that has nothing to compute on tile t: its quarter of the K / V DMAs and the tile's barrier, nothing else
+  // (the ring protocol -- 4 K DMAs in front of the counted wait, 4 V DMAs behind the barrier -- is the one `step` keeps).
+  auto idle_step = [&](int t, auto iidx) {
+    constexpr int I = decltype(iidx)::value;
+    bool klast, vlast;
+    int tk = t + 4, tv = t + 3;
+    if constexpr (MASKED) {
+      auto& le_ = le;
+      tk = le_[I + 4] & 0xfff;
+      tv = le_[I + 3] & 0xfff;
+    }
+    const uint8_t* ksrc = tile_src(kbase, p.k_ts, tk, klast);
+    const uint8_t* vsrc = tile_src(vbase, p.v_ts, tv, vlast);
+    static_for<4>([&](auto i) { dma_k(ksrc, klast, I & 3, i); });
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    FDM_FENCE();
+    static_for<4>([&](auto i) { dma_v(vsrc, vlast, (I + 3) & 3, i); });
+    FDM_FENCE();
+  };
+
 #ifdef FDM_ATT_STAMPS
   FDM_STAMP(st_t0);
   const unsigned long long st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -1020,6 +1041,13 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
     if constexpr (MASKED) {   // list entries of the NEXT group's positions t+8 .. t+11, consumed behind step 3 (dozens of counted waits later)
       asm volatile("ds_read_b64 %0, %1" : "=v"(nxt) : "v"(list_base + 2u * (uint32_t)(t + 8)) : FDM_VREGS);
       FDM_FENCE();
+    }
+    if ((FDM_A64_ABL & 256) && wave >= 2) {   // ablation: half of the block's waves only keep the ring going
+      idle_step(t, ic<0>{});
+      if (t + 1 < t_end) idle_step(t + 1, ic<1>{});
+      if (t + 2 < t_end) idle_step(t + 2, ic<2>{});
+      if (t + 3 < t_end) idle_step(t + 3, ic<3>{});
+      continue;
     }
     step(Sa, Sb, t, ic<0>{});
     if (t + 1 < t_end) step(Sb, Sa, t + 1, ic<1>{});
