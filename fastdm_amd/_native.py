@@ -34,9 +34,10 @@ SIGNATURES = {
     "fdm_gemm_last_kernel": (I32, []),
     "fdm_gemm_w8a8_int8": (I32, [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_gemm_bf16": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
+    "fdm_linear_skinny_bf16": (I32, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, P]),
     "fdm_attn_fwd": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I32, I32, P, I64, P]),
     "fdm_attn_fwd_workspace_bytes": (I64, [I32]),
-    "fdm_ln_modulate": (I32, [P, P, P, P, I32, P, P, P, I64, P, P, P, I64, I32, I64, F32, P]),
+    "fdm_ln_modulate": (I32, [P, P, P, P, I32, P, P, P, I64, P, P, P, I64, I32, I64, F32, I32, P]),
     "fdm_ln_modulate_f32": (I32, [P, P, P, P, I32, P, P, P, I64, I64, I32, I64, F32, P]),
     "fdm_gate_residual": (I32, [P, P, P, P, I64, I64, I32, I64, P]),
     "fdm_gelu": (I32, [P, P, I64, I32, P]),
@@ -49,7 +50,7 @@ SIGNATURES = {
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
 }
 
-ABI_VERSION = 10         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
+ABI_VERSION = 11         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL, EPI_GATE_RESIDUAL_F32 = 0, 1, 2, 3, 4
 
 

@@ -1036,18 +1036,19 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
   }
   __builtin_amdgcn_s_barrier();   // every wave has read the first K tile: step 0 refills its ring slot
   FDM_FENCE();
+  if ((FDM_A64_ABL & 256) && wave >= 2) {   // ablation: half of the block's waves only keep the ring going
+    for (int t = t_begin; t < t_end; t += 4) {
+      idle_step(t, ic<0>{});
+      if (t + 1 < t_end) idle_step(t + 1, ic<1>{});
+      if (t + 2 < t_end) idle_step(t + 2, ic<2>{});
+      if (t + 3 < t_end) idle_step(t + 3, ic<3>{});
+    }
+  } else
   for (int t = t_begin; t < t_end; t += 4) {
     i32x2 nxt;
     if constexpr (MASKED) {   // list entries of the NEXT group's positions t+8 .. t+11, consumed behind step 3 (dozens of counted waits later)
       asm volatile("ds_read_b64 %0, %1" : "=v"(nxt) : "v"(list_base + 2u * (uint32_t)(t + 8)) : FDM_VREGS);
       FDM_FENCE();
-    }
-    if ((FDM_A64_ABL & 256) && wave >= 2) {   // ablation: half of the block's waves only keep the ring going
-      idle_step(t, ic<0>{});
-      if (t + 1 < t_end) idle_step(t + 1, ic<1>{});
-      if (t + 2 < t_end) idle_step(t + 2, ic<2>{});
-      if (t + 3 < t_end) idle_step(t + 3, ic<3>{});
-      continue;
     }
     step(Sa, Sb, t, ic<0>{});
     if (t + 1 < t_end) step(Sb, Sa, t + 1, ic<1>{});

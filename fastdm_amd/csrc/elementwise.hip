@@ -390,7 +390,9 @@ __global__ void __launch_bounds__(256) quant_rowwise_wide_kernel(uint8_t* __rest
 
 // ------------------------------------------------------------------------------------ AdaLN modulate (+residual, +quant)
 // y = bf16(bf16(LN(x) * bf16(1+scale)) + shift); optional x := bf16(res + bf16(gate*x)) first.
-template <int THREADS, int QMODE, bool SW, int NIT = 0>
+// S1: `scale` already holds bf16(1 + scale) (the producer of the modulation vectors added the 1: one add + one rounding per ELEMENT
+// of every row become one per column of the step).
+template <int THREADS, int QMODE, bool SW, int NIT = 0, bool S1 = false>
 __global__ void __launch_bounds__(THREADS) ln_modulate_kernel(
     bf16_t* __restrict__ out_bf16, uint8_t* __restrict__ out_q, float* __restrict__ out_scale,
     int32_t* __restrict__ out_azp, const bf16_t* __restrict__ xin, const bf16_t* __restrict__ scale,
@@ -469,7 +471,7 @@ __global__ void __launch_bounds__(THREADS) ln_modulate_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float n = rbf((x[i].v[j] - mean) * rstd);
-        x[i].v[j] = rbf(rbf(n * rbf(1.0f + sc.v[j])) + sh.v[j]);
+        x[i].v[j] = rbf(rbf(n * (S1 ? sc.v[j] : rbf(1.0f + sc.v[j]))) + sh.v[j]);
       }
     }
   }
@@ -833,12 +835,14 @@ static int launch_quant(void* q, float* scale, int32_t* azp, const bf16_t* s0, i
 template <int THREADS>
 static int launch_ln(void* out_bf16, void* out_q, float* out_scale, int32_t* out_azp, int qm, const void* x, const void* scale,
                      const void* shift, int64_t mbs, const void* res, const void* gate, void* x_out, int64_t rows, int hidden,
-                     int64_t rpb, float eps, hipStream_t s) {
+                     int64_t rpb, float eps, bool s1, hipStream_t s) {
   const bool sw = g_fp8_sw_cvt;   // constexpr false in the product build
+#define FDM_LNARGS                                                                                                        \
+  (bf16_t*)out_bf16, (uint8_t*)out_q, out_scale, out_azp, (const bf16_t*)x, (const bf16_t*)scale, (const bf16_t*)shift, mbs, \
+      (const bf16_t*)res, (const bf16_t*)gate, (bf16_t*)x_out, hidden, rpb, eps
 #define FDM_LNK(QM, SWV, NITV)                                                                                           \
-  ln_modulate_kernel<THREADS, QM, SWV, NITV><<<(unsigned)rows, THREADS, 0, s>>>(                                         \
-      (bf16_t*)out_bf16, (uint8_t*)out_q, out_scale, out_azp, (const bf16_t*)x, (const bf16_t*)scale, (const bf16_t*)shift, \
-      mbs, (const bf16_t*)res, (const bf16_t*)gate, (bf16_t*)x_out, hidden, rpb, eps)
+  if (s1 && !(SWV)) ln_modulate_kernel<THREADS, QM, false, NITV, true><<<(unsigned)rows, THREADS, 0, s>>>(FDM_LNARGS);   \
+  else ln_modulate_kernel<THREADS, QM, SWV, NITV, false><<<(unsigned)rows, THREADS, 0, s>>>(FDM_LNARGS)
 #define FDM_LN(QM, SWV)                                                                                                  \
   if (SWV) FDM_LNK(QM, SWV, 0);                                                                                          \
   else switch (((hidden >> 3) + THREADS - 1) / THREADS) {                                                                 \
@@ -846,11 +850,13 @@ static int launch_ln(void* out_bf16, void* out_q, float* out_scale, int32_t* out
     case 4: FDM_LNK(QM, false, 4); break; case 5: FDM_LNK(QM, false, 5); break; case 6: FDM_LNK(QM, false, 6); break;    \
     case 7: FDM_LNK(QM, false, 7); break; default: FDM_LNK(QM, false, 8); break;                                         \
   }
+  if (s1 && sw) return FDM_ERR_UNSUPPORTED;
   if (qm == 0) { FDM_LN(0, false) }
   else if (qm == 1) { if (sw) { FDM_LN(1, true) } else { FDM_LN(1, false) } }
   else if (qm == 2) { FDM_LN(2, false) }
   else return FDM_ERR_UNSUPPORTED;
 #undef FDM_LNK
+#undef FDM_LNARGS
 #undef FDM_LN
   FDM_CHECK_LAUNCH();
   return FDM_OK;
@@ -1047,8 +1053,9 @@ int fdm_gate_residual(void* out, const void* res, const void* y, const void* gat
 
 int fdm_ln_modulate(void* out_bf16, void* out_q, float* out_scale, int32_t* out_azp, int quant_mode, const void* x,
                     const void* scale, const void* shift, int64_t mod_batch_stride, const void* res, const void* gate,
-                    void* x_out, int64_t rows, int hidden, int64_t rows_per_batch, float eps, fdm_stream_t stream) {
+                    void* x_out, int64_t rows, int hidden, int64_t rows_per_batch, float eps, int scale_has_one, fdm_stream_t stream) {
   (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (scale_has_one != 0 && scale_has_one != 1) return FDM_ERR_INVALID;
   if (!x || !scale || !shift || rows < 0 || hidden <= 0 || (hidden & 7) || rows_per_batch <= 0 || (mod_batch_stride & 7))
     return FDM_ERR_INVALID;
   if (quant_mode != 0 && (!out_q || !out_scale)) return FDM_ERR_INVALID;
@@ -1062,9 +1069,9 @@ int fdm_ln_modulate(void* out_bf16, void* out_q, float* out_scale, int32_t* out_
   hipStream_t s = to_stream(stream);
   if (hidden <= 4096)
     return launch_ln<64>(out_bf16, out_q, out_scale, out_azp, quant_mode, x, scale, shift, mod_batch_stride, res, gate, x_out,
-                         rows, hidden, rows_per_batch, eps, s);
+                         rows, hidden, rows_per_batch, eps, scale_has_one != 0, s);
   return launch_ln<256>(out_bf16, out_q, out_scale, out_azp, quant_mode, x, scale, shift, mod_batch_stride, res, gate, x_out,
-                        rows, hidden, rows_per_batch, eps, s);
+                        rows, hidden, rows_per_batch, eps, scale_has_one != 0, s);
 }
 
 int fdm_qk_norm_rope(void* q_out, void* k_out, void* v_out, const void* qkv, const void* wq, const void* wk,

@@ -1721,10 +1721,13 @@ using namespace fdm;
 // The AdaLN modulation / timestep-embedding projections have M = batch (1..8) rows: 2*M*N*K flops against N*K*2 bytes
 // of weights, i.e. HBM-bound GEMVs.  The weights are [K, N] with stride(0) == 1, so one output column is K contiguous
 // bf16: a wave streams 4 columns at a time with 16-byte loads, dots them against the activation rows held in LDS and
-// butterfly-reduces.  fp32 accumulate, out = bf16(acc + bias) like the tile kernel's EPI_NONE epilogue.
+// butterfly-reduces.  fp32 accumulate, out = bf16(acc + bias) like the tile kernel's EPI_NONE epilogue.  post_add (optional, [N]): a
+// second bf16 addend applied AFTER that rounding where it is non-zero, out = bf16(out + post_add[n]) -- the AdaLN table writes
+// bf16(1 + scale) for its scale columns this way (the reference's `1 + scale` tensor), so that fdm_ln_modulate need not.
 template <int MR>
 __global__ void __launch_bounds__(256) gemv_bf16_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ a,
                                                         const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
+                                                        const bf16_t* __restrict__ post_add,
                                                         int M, int64_t N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                                                         int passes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gemv_smem[];
@@ -1777,7 +1780,12 @@ __global__ void __launch_bounds__(256) gemv_bf16_kernel(bf16_t* __restrict__ out
     const int m = lane / C, c = lane % C;
     if (m < M && n0 + c < N) {
       const float bv = bias ? bf2f(bias[n0 + c]) : 0.f;
-      out[(int64_t)m * ldc + n0 + c] = f2bf(mine + bv);
+      bf16_t y = f2bf(mine + bv);
+      if (post_add != nullptr) {
+        const float pa = bf2f(post_add[n0 + c]);
+        if (pa != 0.f) y = f2bf(bf2f(y) + pa);
+      }
+      out[(int64_t)m * ldc + n0 + c] = y;
     }
   }
 }
@@ -1788,8 +1796,8 @@ static bool gemv_applicable(int64_t M, int64_t N, int64_t K, int64_t lda, int64_
          !(reinterpret_cast<uintptr_t>(a) & 15) && !(reinterpret_cast<uintptr_t>(b) & 15);
 }
 
-static int launch_gemv(void* out, const void* a, const void* b, const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
-                       int64_t ldb, int64_t ldc, hipStream_t s) {
+static int launch_gemv(void* out, const void* a, const void* b, const void* bias, const void* post_add, int64_t M, int64_t N, int64_t K,
+                       int64_t lda, int64_t ldb, int64_t ldc, hipStream_t s) {
   const int MR = M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : 8;
   const int64_t groups = (N + 15) / 16;  // 4 waves x 4 columns per pass
   int passes = (int)(groups / 2048);     // keep >= 2048 blocks in flight before a block loops
@@ -1797,8 +1805,8 @@ static int launch_gemv(void* out, const void* a, const void* b, const void* bias
   const unsigned grid = (unsigned)((groups + passes - 1) / passes);
   const size_t smem = (size_t)MR * K * 2;
 #define FDM_GEMV(R)                                                                                                     \
-  gemv_bf16_kernel<R><<<grid, 256, smem, s>>>((bf16_t*)out, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)bias, (int)M, N, \
-                                              (int)K, lda, ldb, ldc, passes)
+  gemv_bf16_kernel<R><<<grid, 256, smem, s>>>((bf16_t*)out, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)bias,            \
+                                              (const bf16_t*)post_add, (int)M, N, (int)K, lda, ldb, ldc, passes)
   if (MR == 1) FDM_GEMV(1);
   else if (MR == 2) FDM_GEMV(2);
   else if (MR == 4) FDM_GEMV(4);
@@ -1911,13 +1919,22 @@ int fdm_gemm_w8a8_int8_x2_ws(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_d
   return launch_gemm<DT_INT8>(g, to_stream(stream), workspace, workspace_bytes);
 }
 
+int fdm_linear_skinny_bf16(void* out, const void* a, const void* b, const void* bias, const void* post_add, int64_t M, int64_t N,
+                           int64_t K, int64_t lda, int64_t ldb, int64_t ldc, fdm_stream_t stream) {
+  (void)hipGetLastError();
+  if (!out || !a || !b || M < 0 || N <= 0 || K <= 0 || ldc < N || lda < K || ldb < K) return FDM_ERR_INVALID;
+  if (M == 0) return FDM_OK;
+  if (!gemv_applicable(M, N, K, lda, ldb, FDM_EPI_NONE, a, b)) return FDM_ERR_UNSUPPORTED;
+  return launch_gemv(out, a, b, bias, post_add, M, N, K, lda, ldb, ldc, to_stream(stream));
+}
+
 int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
                   int64_t ldb, int64_t ldc, int epilogue, const void* epi_gate, int64_t epi_gate_stride, const void* epi_res,
                   int64_t epi_rows_per_batch, fdm_stream_t stream) {
   (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (M == 0 && N > 0 && K > 0) return FDM_OK;
   if (out && a && b && ldc >= N && lda >= K && ldb >= K && gemv_applicable(M, N, K, lda, ldb, epilogue, a, b))
-    return launch_gemv(out, a, b, bias, M, N, K, lda, ldb, ldc, to_stream(stream));
+    return launch_gemv(out, a, b, bias, nullptr, M, N, K, lda, ldb, ldc, to_stream(stream));
   GemmGroup g;
   int rc = fill_problem(g.p[0], out, a, b, M, N, K, lda, ldb, ldc, 2, epilogue, epi_gate, epi_gate_stride, epi_res, epi_rows_per_batch);
   if (rc != FDM_OK) return rc;

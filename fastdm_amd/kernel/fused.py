@@ -32,8 +32,9 @@ def _alloc_q(rows, width, quant, device):
 
 def ln_modulate(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, rows_per_batch: int, quant=None,
                 want_bf16: bool = False, res: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
-                eps: float = 1e-6) -> Tuple[Optional[torch.Tensor], Optional[Quantized], Optional[torch.Tensor]]:
+                eps: float = 1e-6, scale_has_one: bool = False) -> Tuple[Optional[torch.Tensor], Optional[Quantized], Optional[torch.Tensor]]:
     """y = LN(x)*(1+scale)+shift (torch bf16 rounding order), optionally quantised per row.
+    scale_has_one: `scale` is already bf16(1 + scale) (ModulationTable adds the 1 in the GEMV that produces it).
 
     scale/shift/gate are [B, width] views (any batch stride, unit inner stride).  With res/gate:
     x := res + gate*x first; the updated x is returned as the third value.
@@ -48,7 +49,7 @@ def ln_modulate(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, rows_
     N.check(N.lib().fdm_ln_modulate(N.ptr(out), N.ptr(qz.q) if qz else None, N.ptr(qz.scale) if qz else None,
                                     N.ptr(qz.azp) if (qz and qz.azp is not None) else None, QUANT_MODE[quant], N.ptr(x),
                                     N.ptr(scale), N.ptr(shift), scale.stride(0), N.ptr(res), N.ptr(gate), N.ptr(x_new), rows,
-                                    width, rows_per_batch, eps, N.stream()), "ln_modulate")
+                                    width, rows_per_batch, eps, 1 if scale_has_one else 0, N.stream()), "ln_modulate")
     return out, qz, x_new
 
 

@@ -9,7 +9,9 @@ from typing import Optional, Tuple
 import torch
 import torch.nn.functional as F
 
+from fastdm_amd import _native as N
 from fastdm_amd.kernel import fused
+from fastdm_amd.kernel.timing import span
 from fastdm_amd.layer.qlinear import QLinear
 
 BF16 = torch.bfloat16
@@ -49,12 +51,14 @@ class FP32LayerNorm:
 
 class _AdaLNBase:
     chunks = 0
+    scale_chunks = ()         # which of the `chunks` column blocks of the projection are `scale` (multiplied as 1 + scale)
 
     def __init__(self, embedding_dim: int, cond_dim: Optional[int] = None, bias=True, eps=1e-6, data_type=BF16):
         self.dim = embedding_dim
         self.linear = QLinear(cond_dim or embedding_dim, self.chunks * embedding_dim, bias=bias, data_type=data_type)
         self.norm_eps = eps
         self._cached_mod = None     # set by ModulationTable for the current step
+        self.scale_has_one = False  # ... together with this: the cached scale chunks already hold bf16(1 + scale)
 
     def modulation(self, emb: torch.Tensor) -> torch.Tensor:
         """[B, chunks*D] = Linear(silu(emb)) (normalization.py:195,231; never quantised for FLUX)."""
@@ -64,15 +68,18 @@ class _AdaLNBase:
 
     def _apply(self, x, scale, shift):
         B, S, D = x.shape
-        y, _, _ = fused.ln_modulate(x.reshape(B * S, D), scale, shift, S, quant=None, eps=self.norm_eps)
+        y, _, _ = fused.ln_modulate(x.reshape(B * S, D), scale, shift, S, quant=None, eps=self.norm_eps, scale_has_one=self.scale_has_one)
         return y.view(B, S, D)
 
 
 class AdaLayerNormZero(_AdaLNBase):
     """normalization.py:162-199."""
     chunks = 6
+    scale_chunks = (1, 4)
 
     def forward(self, x, emb=None):
+        # NB inside a ModulationTable(fold_one=True) step `scale_mlp` is returned as bf16(1 + scale_mlp) (`self.scale_has_one`); the only
+        # in-step caller of this reference-signature method is the TeaCache probe, which takes element [0]
         shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.modulation(emb).chunk(6, dim=1)
         return self._apply(x, scale_msa, shift_msa), gate_msa, shift_mlp, scale_mlp, gate_mlp
 
@@ -81,6 +88,7 @@ class SD35AdaLayerNormZeroX(_AdaLNBase):
     """normalization.py:45-88: nine chunks (the six of AdaLayerNormZero + shift/scale/gate of SD3.5's second attention);
     LayerNorm eps 1e-5 (the reference's default for this class)."""
     chunks = 9
+    scale_chunks = (1, 4, 7)
 
     def __init__(self, embedding_dim: int, elementwise_affine=False, norm_type: str = "layer_norm", bias: bool = True, eps=1e-5,
                  data_type=BF16):
@@ -96,6 +104,7 @@ class SD35AdaLayerNormZeroX(_AdaLNBase):
 class AdaLayerNormZeroSingle(_AdaLNBase):
     """normalization.py:201-236."""
     chunks = 3
+    scale_chunks = (1,)
 
     def forward(self, x, emb=None):
         shift_msa, scale_msa, gate_msa = self.modulation(emb).chunk(3, dim=1)
@@ -105,6 +114,7 @@ class AdaLayerNormZeroSingle(_AdaLNBase):
 class AdaLayerNormContinuous(_AdaLNBase):
     """normalization.py:90-128: chunks are (scale, shift) -- scale first."""
     chunks = 2
+    scale_chunks = (0,)
 
     def __init__(self, embedding_dim, conditioning_embedding_dim, elementwise_affine=False, eps=1e-5, bias=True, data_type=BF16):
         assert not elementwise_affine, "FLUX uses elementwise_affine=False (model/flux.py:259)"
@@ -124,7 +134,11 @@ class ModulationTable:
     single weight-streaming launch instead of 77 M=1 GEMVs.
     """
 
-    def __init__(self, layers):
+    def __init__(self, layers, fold_one: bool = False):
+        """fold_one: the table's GEMV also writes bf16(1 + scale) into the layers' `scale` chunks (fdm_linear_skinny_bf16's post_add)
+        and marks the layers `scale_has_one` for the step, so fdm_ln_modulate multiplies by the stored value instead of adding and
+        rounding once per element of every row.  Same bits: the reference forms `1 + scale` as a bf16 tensor (normalization.py:197,233).
+        Only for consumers that pass `scale_has_one` on (the FLUX blocks); off, the table is the plain projection."""
         self.layers = list(layers)
         ws = [l.linear.weight.t() for l in self.layers]            # [n_i, K] each (K contiguous)
         K = ws[0].shape[1]
@@ -132,6 +146,7 @@ class ModulationTable:
         dev = ws[0].device
         w_all = torch.empty((total, K), device=dev, dtype=ws[0].dtype)
         b_all = torch.empty((total,), device=dev, dtype=ws[0].dtype)
+        self.post_add = torch.zeros((total,), device=dev, dtype=ws[0].dtype) if fold_one else None
         self.offsets = []
         off = 0
         for l, w in zip(self.layers, ws):
@@ -140,6 +155,10 @@ class ModulationTable:
             b_all[off:off + n].copy_(l.linear.bias)
             l.linear.weight = w_all[off:off + n].t()                # view into the table
             l.linear.bias = b_all[off:off + n]
+            if fold_one:
+                d = n // l.chunks
+                for c in l.scale_chunks:
+                    self.post_add[off + c * d:off + (c + 1) * d] = 1.0
             self.offsets.append((off, n))
             off += n
         self.table = QLinear(K, total, bias=True, data_type=ws[0].dtype)
@@ -147,10 +166,26 @@ class ModulationTable:
         self.table.quant_type = None
 
     def begin_step(self, temb: torch.Tensor):
-        mod = self.table.forward(F.silu(temb))                      # [B, total]
+        a = F.silu(temb)
+        folded = False
+        if self.post_add is not None and a.dim() == 2 and a.shape[0] <= 8 and a.stride(1) == 1:
+            wt = self.table.weight
+            K, total = wt.shape
+            mod = torch.empty((a.shape[0], total), device=a.device, dtype=a.dtype)
+            with span("gemm_bf16", 2.0 * a.shape[0] * total * K):
+                rc = N.lib().fdm_linear_skinny_bf16(N.ptr(mod), N.ptr(a), N.ptr(wt), N.ptr(self.table.bias), N.ptr(self.post_add),
+                                                    a.shape[0], total, K, a.stride(0), wt.stride(1), mod.stride(0), N.stream())
+            if rc == 0:
+                folded = True
+            elif rc != -2:                                          # FDM_ERR_UNSUPPORTED: not GEMV-shaped, take the tile kernel below
+                N.check(rc, "modulation table")
+        if not folded:
+            mod = self.table.forward(a)                             # [B, total]
         for l, (off, n) in zip(self.layers, self.offsets):
             l._cached_mod = mod[:, off:off + n]
+            l.scale_has_one = folded
 
     def end_step(self):
         for l in self.layers:
             l._cached_mod = None
+            l.scale_has_one = False

@@ -47,7 +47,7 @@ class FluxSingleTransformerBlock:
         x = hidden_states.reshape(B * S, D)
         shift, scale, gate = self.norm.modulation(temb).chunk(3, dim=1)
         quant = self.proj_mlp.quant_type
-        nh, nq, _ = fused.ln_modulate(x, scale, shift, S, quant=quant)
+        nh, nq, _ = fused.ln_modulate(x, scale, shift, S, quant=quant, scale_has_one=self.norm.scale_has_one)
         xin = nq if quant is not None else nh
         mlp = self.proj_mlp.forward_q(xin, epilogue=N.EPI_GELU_ERF)
         attn = self.attn.attend(xin, B, S, image_rotary_emb)
@@ -74,17 +74,19 @@ class FluxTransformerBlock:
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, temb: torch.Tensor,
                 image_rotary_emb=None, joint_attention_kwargs=None):
         return fused_double_stream(self.attn, self.ff, self.ff_context, self.norm1.modulation(temb), self.norm1_context.modulation(temb),
-                                   hidden_states, encoder_hidden_states, image_rotary_emb)
+                                   hidden_states, encoder_hidden_states, image_rotary_emb,
+                                   scale_has_one=(self.norm1.scale_has_one, self.norm1_context.scale_has_one))
 
 
 def fused_double_stream(attn, ff_img, ff_txt, mod_img, mod_txt, hidden_states, encoder_hidden_states, image_rotary_emb,
-                        attn2=None, eps_img: float = 1e-6, context_pre_only: bool = False):
+                        attn2=None, eps_img: float = 1e-6, context_pre_only: bool = False, scale_has_one=(False, False)):
     """One double-stream (MMDiT) block on the fused kernels.  `mod_img` is the image stream's [B, 6*D] modulation projection
     in the order (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp) -- [B, 9*D] with (shift_msa2, scale_msa2,
     gate_msa2) appended when `attn2` (SD3.5's second, image-only attention) is given; `mod_txt` likewise [B, 6*D], or
     [B, 2*D] = (scale, shift) for a `context_pre_only` last block whose text stream ends in the attention.
     Shared by the FLUX double block (flux.py:130-178), the Qwen-Image block (qwenimage.py:58-124) and SD3's
-    JointTransformerBlock (sd35.py:133-200), whose arithmetic is identical.  Returns (encoder_hidden_states | None, hidden_states)."""
+    JointTransformerBlock (sd35.py:133-200), whose arithmetic is identical.  `scale_has_one` = (image, text): the scale chunks of that
+    stream's modulation already hold bf16(1 + scale) (ModulationTable(fold_one=True)).  Returns (encoder_hidden_states | None, hidden_states)."""
     B, s_img, D = hidden_states.shape
     s_txt = encoder_hidden_states.shape[1]
     quant = attn.qkv.quant_type
@@ -100,8 +102,9 @@ def fused_double_stream(attn, ff_img, ff_txt, mod_img, mod_txt, hidden_states, e
     def pick(t):
         return t[1] if quant is not None else t[0]
 
-    xin = pick(fused.ln_modulate(x, scale_msa, shift_msa, s_img, quant=quant, eps=eps_img))
-    ein = pick(fused.ln_modulate(e, c_scale_msa, c_shift_msa, s_txt, quant=quant))
+    one_img, one_txt = scale_has_one
+    xin = pick(fused.ln_modulate(x, scale_msa, shift_msa, s_img, quant=quant, eps=eps_img, scale_has_one=one_img))
+    ein = pick(fused.ln_modulate(e, c_scale_msa, c_shift_msa, s_txt, quant=quant, scale_has_one=one_txt))
     o = attn.attend(xin, B, s_img, image_rotary_emb, ein, s_txt).view(B, s_txt + s_img, D)
 
     # attention rows of a stream are a strided slice of the joint output: quantise / project per batch element;
@@ -125,15 +128,15 @@ def fused_double_stream(attn, ff_img, ff_txt, mod_img, mod_txt, hidden_states, e
     if attn2 is not None:
         # second, image-only attention on the same LayerNorm output with its own modulation (sd35.py:166-169)
         shift_msa2, scale_msa2, gate_msa2 = im[6:]
-        xin2 = pick(fused.ln_modulate(x, scale_msa2, shift_msa2, s_img, quant=quant, eps=eps_img))
+        xin2 = pick(fused.ln_modulate(x, scale_msa2, shift_msa2, s_img, quant=quant, eps=eps_img, scale_has_one=one_img))
         o2 = attn2.attend(xin2, B, s_img, None)
         oq2 = attn2.to_out.quantize_input(o2) if attn2.to_out.quant_type is not None else o2
         attn2.to_out.forward_q(oq2, epilogue=N.EPI_GATE_RESIDUAL, gate=gate_msa2, res=x_new, rows_per_batch=s_img, out=x_new)
-    fin_x = pick(fused.ln_modulate(x_new, scale_mlp, shift_mlp, s_img, quant=quant))
+    fin_x = pick(fused.ln_modulate(x_new, scale_mlp, shift_mlp, s_img, quant=quant, scale_has_one=one_img))
     if context_pre_only:
         x_out = ff_img.forward_fused(fin_x, gate_mlp, x_new, s_img)
         return None, x_out.view(B, s_img, D)
-    fin_e = pick(fused.ln_modulate(e_new, c_scale_mlp, c_shift_mlp, s_txt, quant=quant))
+    fin_e = pick(fused.ln_modulate(e_new, c_scale_mlp, c_shift_mlp, s_txt, quant=quant, scale_has_one=one_txt))
     x, e = FeedForward.forward_fused_pair(ff_img, fin_x, gate_mlp, x_new, s_img, ff_txt, fin_e, c_gate_mlp, e_new, s_txt)
     return e.view(B, s_txt, D), x.view(B, s_img, D)
 
@@ -226,7 +229,7 @@ class FluxTransformer2DModelCore(BaseModelCore):
             layers += [blk.norm1, blk.norm1_context]
         layers += [blk.norm for blk in self.single_transformer_blocks]
         layers.append(self.norm_out)
-        self.mod_table = ModulationTable(layers)
+        self.mod_table = ModulationTable(layers, fold_one=True)     # every consumer above passes `scale_has_one` on
 
     # ------------------------------------------------------------------ forward (flux.py:334-494)
     def _rope_cache(self, txt_ids, img_ids, dtype):

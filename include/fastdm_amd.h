@@ -44,7 +44,7 @@ const char* fdm_last_hip_error_string(void);
 
 /* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
  * refuse to run instead of passing arguments at the wrong positions. */
-#define FDM_ABI_VERSION 10
+#define FDM_ABI_VERSION 11
 int fdm_abi_version(void);
 
 /* ---- replaces cuda_ops.rms_norm_ (ops.h:17-20; csrc/elmwise_ops.cu:56-84,433-449) -------------
@@ -179,6 +179,15 @@ int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias,
                   int epilogue, const void* epi_gate, int64_t epi_gate_stride,
                   const void* epi_res, int64_t epi_rows_per_batch, fdm_stream_t stream);
 
+/* The same linear for M <= 8 rows (AdaLN modulation / embedder projections: one weight-streaming GEMV launch, the kernel
+ * fdm_gemm_bf16 itself picks for such shapes), with an optional second addend applied AFTER the output rounding:
+ * out[m,n] = bf16(acc + bias[n]); where post_add != NULL and post_add[n] != 0: out[m,n] = bf16(out[m,n] + post_add[n]).
+ * With post_add = 1 on the `scale` columns of a concatenated AdaLN projection the output holds the reference's
+ * `1 + scale` tensor (layer/normalization.py:197,233: bf16 add) and fdm_ln_modulate takes it with scale_has_one = 1.
+ * FDM_ERR_UNSUPPORTED when the shape is not GEMV-shaped (M > 8, K > 16384 or not a multiple of 8, unaligned): use fdm_gemm_bf16. */
+int fdm_linear_skinny_bf16(void* out, const void* a, const void* b, const void* bias, const void* post_add,
+                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, fdm_stream_t stream);
+
 /* ---- scaled_dot_product_attention / sparse_... (kernel/operators_set.py:154-208) --------------
  * q [B,Sq,Hq*D], k/v [B,Sk,Hkv*D], o [B,Sq,Hq*D] bf16, token strides in elements (batch stride =
  * S * token stride).  Non-causal softmax(q k^T * scale) v with fp32 softmax state.  D in {64,128}.
@@ -204,7 +213,10 @@ int64_t fdm_attn_fwd_workspace_bytes(int head_dim);
  * Any of the three outputs may be NULL: out_bf16 [rows,hidden]; out_q + out_scale = the per-row
  * fp8 (quant_mode 1) or asymmetric int8 (quant_mode 2, also out_azp) quantisation of y.
  * Optional fused residual: if res != NULL, x := bf16(res + bf16(gate[b,:] * x)) first and, when
- * x_out != NULL, that updated x is written there (model/flux.py:153-156).                        */
+ * x_out != NULL, that updated x is written there (model/flux.py:153-156).
+ * scale_has_one = 1: `scale` already holds bf16(1 + scale) (fdm_linear_skinny_bf16's post_add wrote it so), the kernel
+ * multiplies by it as is -- the same value the reference's `1 + scale` tensor holds, computed once per column
+ * instead of once per element.                                                                    */
 /* Wan's fp32 modulation (model/wan.py:99,109-111,362): y = bf16(LN_f32(x) * (1 + scale_f32[b,:]) + shift_f32[b,:]) with ONE
  * rounding (FP32LayerNorm, then fp32 multiply-add, then type_as).  scale/shift are fp32 [B, hidden] with
  * mod_batch_stride in floats (0 broadcasts one row: an affine FP32LayerNorm is scale = weight - 1, shift = bias).
@@ -216,7 +228,7 @@ int fdm_ln_modulate_f32(void* out_bf16, void* out_q, float* out_scale, int32_t* 
 int fdm_ln_modulate(void* out_bf16, void* out_q, float* out_scale, int32_t* out_azp, int quant_mode,
                     const void* x, const void* scale, const void* shift, int64_t mod_batch_stride,
                     const void* res, const void* gate, void* x_out,
-                    int64_t rows, int hidden, int64_t rows_per_batch, float eps, fdm_stream_t stream);
+                    int64_t rows, int hidden, int64_t rows_per_batch, float eps, int scale_has_one, fdm_stream_t stream);
 
 /* out = bf16(res + bf16(gate[b,:] * y))  (model/flux.py:153-154,161-163,70-72). */
 int fdm_gate_residual(void* out, const void* res, const void* y, const void* gate,

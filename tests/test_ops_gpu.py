@@ -496,6 +496,57 @@ def test_bf16_skinny_rows_gemv_path(M, Kd, Nn):
     ulp_close(out2, (a.float() @ w.float().t()).to(BF16), 0.03, f"gemv nobias {M}x{Kd}x{Nn}", ulps=1)
 
 
+@pytest.mark.parametrize("M,Kd,D,chunks,scale_chunks", [(1, 3072, 3072, 6, (1, 4)), (2, 256, 128, 3, (1,)), (8, 512, 64, 2, (0,))])
+def test_skinny_linear_post_add_writes_one_plus_scale_and_ln_modulate_takes_it(M, Kd, D, chunks, scale_chunks):
+    """fdm_linear_skinny_bf16's post_add: out = bf16(bf16(acc + bias) + 1) on the `scale` columns of an AdaLN projection, untouched
+    (bit for bit, -0.0 included) elsewhere; fdm_ln_modulate(scale_has_one = 1) on those columns gives the bits of the plain call on the
+    raw ones, for every output kind.  The reference forms `1 + scale` as a bf16 tensor (layer/normalization.py:197,233)."""
+    from fastdm_amd import _native as N
+    from fastdm_amd.kernel import fused
+    Nn = chunks * D
+    g = gen(M * 17 + D)
+    a, w, bias = rbf(g, M, Kd).cuda(), rbf(g, Nn, Kd, scale=Kd ** -0.5).cuda(), rbf(g, Nn, scale=0.1).cuda()
+    w[5] = 0
+    bias[5] = -0.0                                             # a column whose plain output is -0.0: must stay -0.0 where post_add is 0
+    post = torch.zeros(Nn, dtype=BF16, device="cuda")
+    for c in scale_chunks:
+        post[c * D:(c + 1) * D] = 1.0
+    plain = torch.empty((M, Nn), dtype=BF16, device="cuda")
+    N.check(N.lib().fdm_gemm_bf16(plain.data_ptr(), a.data_ptr(), w.data_ptr(), bias.data_ptr(), M, Nn, Kd, Kd, Kd, Nn, N.EPI_NONE,
+                                  None, 0, None, 0, N.stream()), "gemm_bf16 skinny")
+    assert N.lib().fdm_gemm_last_kernel() == 3                 # the GEMV kernel
+    folded = torch.empty_like(plain)
+    N.check(N.lib().fdm_linear_skinny_bf16(folded.data_ptr(), a.data_ptr(), w.data_ptr(), bias.data_ptr(), post.data_ptr(), M, Nn, Kd,
+                                           Kd, Kd, Nn, N.stream()), "skinny post_add")
+    want = torch.where(post.bool()[None, :], plain + 1, plain)    # torch bf16 add: float add, one rounding
+    assert torch.equal(folded.view(torch.int16), want.view(torch.int16))
+    nopost = torch.empty_like(plain)
+    N.check(N.lib().fdm_linear_skinny_bf16(nopost.data_ptr(), a.data_ptr(), w.data_ptr(), bias.data_ptr(), None, M, Nn, Kd, Kd, Kd, Nn,
+                                           N.stream()), "skinny")
+    assert torch.equal(nopost.view(torch.int16), plain.view(torch.int16))
+    # not GEMV-shaped: refused, never a silent other path
+    big = torch.empty((9, Nn), dtype=BF16, device="cuda")
+    a9 = rbf(g, 9, Kd).cuda()
+    assert N.lib().fdm_linear_skinny_bf16(big.data_ptr(), a9.data_ptr(), w.data_ptr(), bias.data_ptr(), post.data_ptr(), 9, Nn, Kd, Kd, Kd,
+                                          Nn, N.stream()) == -2
+    rows = 24
+    x = rbf(g, M * rows, D).cuda()
+    sc_chunk, sh_chunk = scale_chunks[0], (scale_chunks[0] + 1) % chunks
+    for quant in (None, FP8, torch.int8):
+        raw = fused.ln_modulate(x, plain[:, sc_chunk * D:(sc_chunk + 1) * D], plain[:, sh_chunk * D:(sh_chunk + 1) * D], rows, quant=quant,
+                                want_bf16=True)
+        one = fused.ln_modulate(x, folded[:, sc_chunk * D:(sc_chunk + 1) * D], plain[:, sh_chunk * D:(sh_chunk + 1) * D], rows, quant=quant,
+                                want_bf16=True, scale_has_one=True)
+        assert torch.equal(raw[0].view(torch.int16), one[0].view(torch.int16))
+        if quant is not None:
+            assert torch.equal(raw[1].q.view(torch.uint8), one[1].q.view(torch.uint8)) and torch.equal(raw[1].scale, one[1].scale)
+            if raw[1].azp is not None:
+                assert torch.equal(raw[1].azp, one[1].azp)
+    with pytest.raises(RuntimeError):
+        N.check(N.lib().fdm_ln_modulate(None, None, None, None, 0, x.data_ptr(), plain.data_ptr(), plain.data_ptr(), Nn, None, None, None,
+                                        rows, D, rows, 1e-6, 2, N.stream()), "bad flag")
+
+
 ATT_SHAPES = [  # /root/reference/tests/test_attention.py:7-21  (B, Sq, Skv, H, hd)
     (1, 4608, 4608, 24, 128), (1, 4110, 4110, 24, 128), (2, 4096, 4096, 10, 64), (2, 4096, 77, 10, 64), (2, 1024, 1024, 20, 64),
     (2, 1024, 77, 20, 64), (1, 4106, 4106, 24, 128), (2, 4685, 4685, 24, 64), (1, 8704, 8704, 24, 128),

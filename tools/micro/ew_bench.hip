@@ -53,9 +53,9 @@ int main() {
   };
   for (int64_t rows : {8192, 8704, 512}) {
     char nm[64]; snprintf(nm, 64, "ln_modulate+fp8 [%ld,3072]", (long)rows);
-    time(nm, rows * 3072 * 3.0, [&] { fdm_ln_modulate(nullptr, q, s, nullptr, 1, y, sc, sh, 3072, nullptr, nullptr, nullptr, rows, 3072, rows, 1e-6f, nullptr); });
+    time(nm, rows * 3072 * 3.0, [&] { fdm_ln_modulate(nullptr, q, s, nullptr, 1, y, sc, sh, 3072, nullptr, nullptr, nullptr, rows, 3072, rows, 1e-6f, (getenv("EW_S1") ? 1 : 0), nullptr); });
     snprintf(nm, 64, "ln_modulate+int8 (generic) [%ld,3072]", (long)rows);
-    time(nm, rows * 3072 * 3.0, [&] { fdm_ln_modulate(nullptr, q, s, nullptr, 3, y, sc, sh, 3072, nullptr, nullptr, nullptr, rows, 3072, rows, 1e-6f, nullptr); });
+    time(nm, rows * 3072 * 3.0, [&] { fdm_ln_modulate(nullptr, q, s, nullptr, 3, y, sc, sh, 3072, nullptr, nullptr, nullptr, rows, 3072, rows, 1e-6f, (getenv("EW_S1") ? 1 : 0), nullptr); });
   }
   time("quant fp8 cat2 [8704,3072+12288]", R * 15360 * 3.0, [&] { fdm_quant_rowwise_cat2(q, s, nullptr, 1, y, 3072, 3072, x, 12288, W, R, nullptr); });
   time("quant int8 (generic) cat2", R * 15360 * 3.0, [&] { fdm_quant_rowwise_cat2(q, s, nullptr, 3, y, 3072, 3072, x, 12288, W, R, nullptr); });
