@@ -67,6 +67,7 @@ struct AttnParams {
   int batch, heads, kv_heads;
   int n_qblocks;
   int mask_bq, mask_bk, mask_nq, mask_nk;
+  int mask_stretch;   // 1: a wave pair computes only on its own stretch of the block's union list; 0 (FDM_ATT_STRETCH=0, A/B): on all of it
   float scale_log2e;
   float q_prescale;   // what Q is multiplied by before its bf16 rounding (= scale_log2e; FDM_ATT_EXACT_Q: the nearest power of two)
   float exp_r;        // FDM_ATT_EXACT_Q: scale_log2e / q_prescale, applied in fp32 in front of every exp2
@@ -510,14 +511,17 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
   const int ntiles = (int)((p.sk + KT - 1) / KT);
   const int t_tail = (p.sk % KT != 0) ? ntiles - 1 : -1;   // the one tile whose keys need masking
 
-  // ---- block mask (MASKED): a 256-row block spans the mask rows of its four waves (two rows of a 128 x 64 block mask).
-  //      The block walks the UNION of their active key tiles; entry = tile index | (wave w's row keeps it) << (12 + w),
-  //      compacted once into LDS by wave 0 (ballot + popcount).  A wave whose own row drops a tile of the union still
-  //      runs its MFMAs (the block moves in lockstep behind one barrier per tile) and overwrites the scores with -inf.
-  //      The loop then runs over list positions instead of tile indices.
+  // ---- block mask (MASKED): a 256-row block spans the mask rows of its four waves (two rows of a 128 x 64 block mask: waves 0-1 and
+  //      waves 2-3).  The block walks the UNION of their active key tiles -- one ring, one barrier per tile -- but a wave computes only
+  //      on the stretch of the list its own pair needs: the list is ordered [kept by pair 0 only | kept by both | kept by pair 1 only]
+  //      (the online softmax does not care about key order), pair 0 works on positions [0, nA + nAB), pair 1 on [nA rounded down to a
+  //      multiple of 4 (the ring phase), end); outside its stretch a wave only does its quarter of the tile DMAs and the barrier
+  //      (`idle_rt`).  entry = tile index | (wave w's row keeps it) << (12 + w): inside its stretch a wave whose own row drops a tile
+  //      (the rounded-down head of pair 1, or mask rows finer than a wave pair) still runs its MFMAs and overwrites the scores with
+  //      -inf.  Compacted once into LDS by wave 0 (ballot + popcount).  The loop runs over list positions instead of tile indices.
   constexpr int MAXL = MASKED ? 4096 : 4, LPAD = 16;
   __shared__ __attribute__((aligned(16))) uint16_t slist[MAXL + LPAD];
-  __shared__ int s_nlist;
+  __shared__ int s_nlist, s_na, s_nab;
   if constexpr (MASKED) {
     if (wave == 0) {
       const int8_t* mrow[4];
@@ -527,27 +531,65 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
         if (r > p.mask_nq - 1) r = p.mask_nq - 1;
         mrow[w] = p.mask + (((int64_t)b * p.heads + head) * p.mask_nq + r) * p.mask_nk;
       }
-      int cnt = 0, last_t = 0;
-      for (int base = 0; base < ntiles; base += 64) {
-        const int tt = base + lane;
+      auto tile_bits = [&](int tt) -> unsigned {
         unsigned bits = 0;
         if (tt < ntiles) {
           const int c = (int)(((int64_t)tt * KT) / p.mask_bk);
 #pragma unroll
           for (int w = 0; w < 4; ++w) bits |= (mrow[w][c] != 0 ? 1u : 0u) << w;
         }
+        return bits;
+      };
+      int na = 0, nab = 0, nb = 0, last_t = 0;
+      for (int base = 0; base < ntiles; base += 64) {   // pass 1: class sizes
+        const unsigned bits = tile_bits(base + lane);
+        const bool a = (bits & 3u) != 0, bb = (bits & 12u) != 0;
+        na += __popcll(__ballot(a && !bb));
+        nab += __popcll(__ballot(a && bb));
         const unsigned long long bal = __ballot(bits != 0);
-        if (bits != 0) slist[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(tt | (bits << 12));
+        nb += __popcll(__ballot(!a && bb));
         if (bal != 0) last_t = base + 63 - __builtin_clzll(bal);
-        cnt += __popcll(bal);
       }
+      int oa = 0, oab = na, ob = na + nab;
+      const unsigned long long below = (1ull << lane) - 1ull;
+      for (int base = 0; base < ntiles; base += 64) {   // pass 2: placement
+        const int tt = base + lane;
+        const unsigned bits = tile_bits(tt);
+        const bool a = (bits & 3u) != 0, bb = (bits & 12u) != 0;
+        const unsigned long long ba = __ballot(a && !bb), bab = __ballot(a && bb), bo = __ballot(!a && bb);
+        const uint16_t ent = (uint16_t)(tt | (bits << 12));
+        if (a && !bb) slist[oa + __popcll(ba & below)] = ent;
+        if (a && bb) slist[oab + __popcll(bab & below)] = ent;
+        if (!a && bb) slist[ob + __popcll(bo & below)] = ent;
+        oa += __popcll(ba);
+        oab += __popcll(bab);
+        ob += __popcll(bo);
+      }
+      const int cnt = na + nab + nb;
       if (lane < LPAD) slist[cnt + lane] = (uint16_t)last_t;   // run-ahead DMAs past the end re-read the last tile (no wave keeps it)
-      if (lane == 0) s_nlist = cnt;
+      if (lane == 0) {
+        s_nlist = cnt;
+        s_na = na;
+        s_nab = nab;
+      }
     }
     __syncthreads();
   }
-  const int t_begin = MASKED ? 0 : (is_part ? (int)((int64_t)part * ntiles / p.split) : 0);
-  const int t_end = MASKED ? s_nlist : (is_part ? (int)((int64_t)(part + 1) * ntiles / p.split) : ntiles);
+  int n_union = 0, t_begin_m = 0, t_end_m = 0;   // MASKED: list length, this wave's stretch of it
+  if constexpr (MASKED) {
+    n_union = __builtin_amdgcn_readfirstlane(s_nlist);
+    const int na = __builtin_amdgcn_readfirstlane(s_na), nab = __builtin_amdgcn_readfirstlane(s_nab);
+    if (!p.mask_stretch) {
+      t_end_m = n_union;
+    } else if (wave < 2) {
+      t_end_m = na + nab;
+    } else if (n_union > na) {
+      t_begin_m = na & ~3;
+      t_end_m = n_union;
+    }
+  }
+  const int t_begin = MASKED ? t_begin_m : (is_part ? (int)((int64_t)part * ntiles / p.split) : 0);
+  const int t_end = MASKED ? t_end_m : (is_part ? (int)((int64_t)(part + 1) * ntiles / p.split) : ntiles);
   int le[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // MASKED: list entries of positions g .. g+7 (g = the 4-step group's first position), wave-uniform
   if constexpr (MASKED) {
 #pragma unroll
@@ -978,24 +1020,25 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
 #endif
   };
 
-  // The same step for a wave that has nothing to compute on tile t: its quarter of the K / V DMAs and the tile's barrier, nothing else
-  // (the ring protocol -- 4 K DMAs in front of the counted wait, 4 V DMAs behind the barrier -- is the one `step` keeps).
-  auto idle_step = [&](int t, auto iidx) {
-    constexpr int I = decltype(iidx)::value;
-    bool klast, vlast;
-    int tk = t + 4, tv = t + 3;
-    if constexpr (MASKED) {
-      auto& le_ = le;
-      tk = le_[I + 4] & 0xfff;
-      tv = le_[I + 3] & 0xfff;
-    }
+  // The same step for a wave that has nothing to compute at list position `pos` (dense ablation: tile pos): its quarter of the K / V
+  // DMAs and the tile's barrier, nothing else.  The ring protocol -- 4 K DMAs of position pos + 4 in front of the counted wait, 4 V DMAs
+  // of position pos + 3 behind the barrier, slot = position % 4 -- is the one `step` keeps; the slot is a run-time value here.
+  auto idle_k = [&](int pos) {
+    bool klast;
+    int tk = pos + 4;
+    if constexpr (MASKED) tk = __builtin_amdgcn_readfirstlane((int)slist[pos + 4]) & 0xfff;
     const uint8_t* ksrc = tile_src(kbase, p.k_ts, tk, klast);
+    static_for<4>([&](auto i) { dma_k(ksrc, klast, pos & 3, i); });
+  };
+  auto idle_v = [&](int pos) {
+    bool vlast;
+    int tv = pos + 3;
+    if constexpr (MASKED) tv = __builtin_amdgcn_readfirstlane((int)slist[pos + 3]) & 0xfff;
     const uint8_t* vsrc = tile_src(vbase, p.v_ts, tv, vlast);
-    static_for<4>([&](auto i) { dma_k(ksrc, klast, I & 3, i); });
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     FDM_FENCE();
-    static_for<4>([&](auto i) { dma_v(vsrc, vlast, (I + 3) & 3, i); });
+    static_for<4>([&](auto i) { dma_v(vsrc, vlast, (pos + 3) & 3, i); });
     FDM_FENCE();
   };
 
@@ -1007,8 +1050,24 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q and the prologue tiles have landed
   __builtin_amdgcn_s_barrier();
   FDM_FENCE();
+  // MASKED, a wave whose stretch starts late (t_begin = 4k > 0): ring duty for positions 0 .. t_begin - 2, then position t_begin - 1
+  // split around this wave's FIRST S tile -- K(t_begin) has landed since the barrier of position t_begin - 2 and its slot (0) is not
+  // refilled before position t_begin's own K DMAs, so the first S tile is computed in front of position t_begin - 1's barrier (while the
+  // other pair runs that position's phase A), the next tile's first K fragments behind it (K(t_begin + 1) lands with that barrier).
+  const bool late = MASKED && t_begin > 0;
+  if (late) {
+    __builtin_amdgcn_s_barrier();   // the other pair's "first K tile read" barrier below
+    for (int pos = 0; pos < t_begin - 1; ++pos) {
+      idle_k(pos);
+      idle_v(pos);
+    }
+    idle_k(t_begin - 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) le[i] = __builtin_amdgcn_readfirstlane((int)slist[t_begin + i]);
+    FDM_FENCE();
+  }
   if (t_begin < t_end) {
-    // S tile of the first KV tile (ring slot 0), plain fragment reads, then the next tile's first three K fragments
+    // S tile of the first KV tile (ring slot 0), plain fragment reads
     static_for<16>([&](auto f_) {
       constexpr int F = decltype(f_)::value, kb = F >> 3, ks = F & 7;
       auto& qa_ = qa;
@@ -1029,19 +1088,20 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
     if constexpr (MASKED) decide(Sa, mx, le[0] & 0xfff, true, false, ((le[0] >> (12 + wave)) & 1) == 0);
     else decide(Sa, mx, t_begin, true, false, false);
     FDM_FENCE();
+  }
+  if (late) idle_v(t_begin - 1);
+  if (t_begin < t_end) {   // the next tile's first three K fragments
     FDM_READ_K(1, 0);
     FDM_READ_K(1, 1);
     FDM_READ_K(1, 2);
     FDM_FENCE();
   }
-  __builtin_amdgcn_s_barrier();   // every wave has read the first K tile: step 0 refills its ring slot
+  if (!late) __builtin_amdgcn_s_barrier();   // every wave has read the first K tile: step 0 refills its ring slot
   FDM_FENCE();
   if ((FDM_A64_ABL & 256) && wave >= 2) {   // ablation: half of the block's waves only keep the ring going
-    for (int t = t_begin; t < t_end; t += 4) {
-      idle_step(t, ic<0>{});
-      if (t + 1 < t_end) idle_step(t + 1, ic<1>{});
-      if (t + 2 < t_end) idle_step(t + 2, ic<2>{});
-      if (t + 3 < t_end) idle_step(t + 3, ic<3>{});
+    for (int t = t_begin; t < t_end; ++t) {
+      idle_k(t);
+      idle_v(t);
     }
   } else
   for (int t = t_begin; t < t_end; t += 4) {
@@ -1121,6 +1181,17 @@ __global__ void __launch_bounds__(256, 1) attn_fwd64_kernel(const AttnParams p) 
           w[1] = (int)pack2bf(o[d][4 * g4 + 2] * inv, o[d][4 * g4 + 3] * inv);
           *reinterpret_cast<i32x2*>(op + 32 * d + 8 * g4 + 4 * h) = w;
         }
+    }
+  }
+  if constexpr (MASKED) {
+    // a wave whose stretch ended early has written its rows; the ring duty for the rest of the list remains
+    if (t_end < n_union) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the output stores are out: the counted waits of idle_v see DMAs only
+      for (int pos = t_end; pos < n_union; ++pos) {
+        idle_k(pos);
+        idle_v(pos);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
 #undef FDM_READ_K
@@ -1214,6 +1285,10 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
   p.n_qblocks = (int)((sq + qb_rows - 1) / qb_rows);
   p.mask_bq = p.mask_bk = 1;
   p.mask_nq = p.mask_nk = 0;
+  {
+    static const int stretch = [] { const char* e = getenv("FDM_ATT_STRETCH"); return (e != nullptr && e[0] == '0') ? 0 : 1; }();
+    p.mask_stretch = stretch;
+  }
   if (block_mask != nullptr) {
     if (block_q <= 0 || block_k <= 0 || block_q % 128 || block_k % 64) return FDM_ERR_UNSUPPORTED;
     p.mask_bq = block_q;

@@ -29,6 +29,7 @@ done
 if [ -z "$FDM_SKIP_AUDIT" ]; then
   FDM_AUDIT_ASM="$OUT/gemm.gfx950.s" bash "$HERE/../../tools/micro/audit_gemm_asm.sh" > "$OUT/audit_gemm.log" 2>&1 || { cat "$OUT/audit_gemm.log"; echo "audit_gemm_asm.sh FAILED (FDM_SKIP_AUDIT=1 builds anyway)"; exit 1; }
   FDM_AUDIT_ASM="$OUT/attention.gfx950.s" bash "$HERE/../../tools/micro/audit_attn_asm.sh" > "$OUT/audit_attn.log" 2>&1 || { cat "$OUT/audit_attn.log"; echo "audit_attn_asm.sh FAILED (FDM_SKIP_AUDIT=1 builds anyway)"; exit 1; }
+  MASKED=1 FDM_AUDIT_ASM="$OUT/attention.gfx950.s" bash "$HERE/../../tools/micro/audit_attn_asm.sh" > "$OUT/audit_attn_masked.log" 2>&1 || { cat "$OUT/audit_attn_masked.log"; echo "audit_attn_asm.sh (MASKED) FAILED (FDM_SKIP_AUDIT=1 builds anyway)"; exit 1; }
 fi
 # link under a temporary name and rename: a process that has the old library mapped (another rank, another job) keeps its inode
 # instead of seeing a truncated file

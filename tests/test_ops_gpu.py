@@ -716,6 +716,46 @@ def test_sparse_attention_random_masks(K, S, seed, density):
     assert (got.float() - ref.float()).abs().mean().item() < 1e-3
 
 
+def test_sparse_attention_wave_pair_stretches(K):
+    """The masked kernel orders a block's union list [pair 0 only | both | pair 1 only] and a wave pair computes only on its own
+    stretch (pair 1 starts at nA rounded down to a multiple of 4, pair 0 stops at nA + nAB; outside it a wave only keeps the K / V ring
+    going).  One 256-row kernel block per case (nA, nAB, nB), several per launch: late starts with and without a rounded-down head,
+    an early end with a long tail, stretches shorter than a 4-step group, an empty stretch for either pair, tiles listed in mask order
+    but consumed in class order, the partial last key tile in each class."""
+    cases = [(0, 5, 0), (1, 0, 1), (3, 2, 9), (4, 0, 0), (0, 0, 4), (5, 3, 0), (8, 1, 7), (13, 0, 13), (4, 4, 4), (7, 1, 0), (0, 1, 6),
+             (2, 0, 21), (21, 0, 2), (9, 9, 9)]
+    g = gen(91)
+    B, H, hd = 1, 2, 128
+    Sk = 64 * 31 + 17                                      # 32 key tiles, the last one partial
+    nk = -(-Sk // 64)
+    Sq = 256 * len(cases)
+    q, k, v = rbf(g, B, Sq, H * hd), rbf(g, B, Sk, H * hd), rbf(g, B, Sk, H * hd)
+    m = torch.zeros(B, H, Sq // 128, nk, dtype=torch.int8)
+    for i, (na, nab, nb) in enumerate(cases):
+        for hh in range(H):
+            perm = torch.randperm(nk, generator=g)
+            if hh == 1 and na + nab + nb > 0:              # head 1: the partial last tile is always in the list, in a class that varies
+                j = int((perm == nk - 1).nonzero()[0, 0])
+                perm[[i % (na + nab + nb), j]] = perm[[j, i % (na + nab + nb)]]
+            a, ab, bb = perm[:na], perm[na:na + nab], perm[na + nab:na + nab + nb]
+            m[0, hh, 2 * i, a] = 1
+            m[0, hh, 2 * i, ab] = 1
+            m[0, hh, 2 * i + 1, ab] = 1
+            m[0, hh, 2 * i + 1, bb] = 1
+    got = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=m.cuda()).cpu()
+    ref = O.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5, block_mask=m)
+    assert torch.isfinite(got.float()).all()
+    live = m.sum(-1).bool()[0]                             # [H, mask rows]: rows with no key at all are undefined upstream (the kernel writes 0)
+    for hh in range(H):
+        for r in range(Sq // 128):
+            blk = (slice(None), slice(128 * r, 128 * r + 128), slice(hh * hd, (hh + 1) * hd))
+            if live[hh, r]:
+                torch.testing.assert_close(got[blk], ref[blk], rtol=0.0, atol=1.8e-2, msg=lambda s_: f"case {cases[r // 2]} head {hh} mask row {r}: {s_}")
+                assert (got[blk].float() - ref[blk].float()).abs().mean().item() < 1.5e-3
+            else:
+                assert (got[blk] == 0).all(), f"case {cases[r // 2]} head {hh} mask row {r}: a row without keys must come out as zeros"
+
+
 def test_sparse_attention_negative_logits_with_dropped_first_union_tile(K):
     """inside a 256-row kernel block the second mask row drops the first tile of the union list, and every kept logit of
     those rows is far below -126 in the exp2 domain (q . k = -40 per element pair: scale * 128 * -40 * log2 e = -650).  A wave that

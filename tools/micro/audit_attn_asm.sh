@@ -26,23 +26,31 @@ import re, sys
 lines = open("k.s").read().split("\n")
 inasm = False
 bad = []
-loop_start = None
+# the tile loop = the loop with the MFMAs in its body (the masked variant has others: it builds its tile list in two, and waves outside
+# their stretch of the list keep the ring going in two more, where compiler-managed LDS reads and waits are fine)
+loop_start = loop_end = None
+best = 0
 for i, l in enumerate(lines):
-    if "Loop Header" in l:
-        loop_start = i          # the tile loop is the LAST loop of the kernel (the masked variant builds its tile list in an earlier one)
+    m = re.match(r"^(\.LBB\d+_\d+):.*Loop Header", l)
+    if m:
+        back = [j for j in range(i, len(lines)) if re.search(r"s_c?branch\w*\s+" + re.escape(m.group(1)) + r"\b", lines[j])]
+        if back:
+            n = sum("v_mfma" in x for x in lines[i:back[-1]])
+            if n > best:
+                best, loop_start, loop_end = n, i, back[-1]
 for i, l in enumerate(lines):
     if "#ASMSTART" in l: inasm = True; continue
     if "#ASMEND" in l: inasm = False; continue
     code = l.split(";")[0]
     if not inasm and re.search(r"\ba(24[0-9]|25[0-5])\b|a\[(2[0-9][0-9]):(24[0-9]|25[0-5])\]", code):
         bad.append((i, l.strip()))
-    if not inasm and loop_start is not None and i > loop_start and re.search(r"^\s*(s_load|s_buffer_load|ds_)", code) and "s_endpgm" not in code:
-        # compiler-generated scalar loads / LDS ops inside the loop region (the epilogue's ds_bpermute comes after the loop: allow ds_bpermute)
-        if "ds_bpermute" not in code:
-            bad.append((i, "in-loop: " + l.strip()))
+    if not inasm and loop_start is not None and loop_start < i < loop_end and re.search(r"^\s*(s_load|s_buffer_load|ds_)", code) and "s_endpgm" not in code:
+        # compiler-generated scalar loads / LDS ops inside the tile loop
+        bad.append((i, "in-loop: " + l.strip()))
 scratch = [l for l in lines if re.search(r"^\s*scratch_", l)]
 n_ins = sum(1 for l in lines if re.match(r"^\s+[a-z]", l))
-print("instructions: %d, mfma %d, scratch ops %d" % (n_ins, sum("v_mfma" in l for l in lines), len(scratch)))
+print("instructions: %d, mfma %d (%d in the tile loop, lines %s-%s), scratch ops %d" % (n_ins, sum("v_mfma" in l for l in lines), best, loop_start, loop_end, len(scratch)))
+if loop_start is None: bad.append((0, "no loop with MFMAs found"))
 for b in bad[:20]: print("VIOLATION line %d: %s" % b)
 sys.exit(1 if bad or scratch else 0)
 PY
