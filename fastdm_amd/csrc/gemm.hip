@@ -1296,6 +1296,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     if constexpr (EPI == FDM_EPI_GATE_RESIDUAL) {
       const int m_first = m0 + wm * 128, m_last = min(m0 + wm * 128 + 128, p.M) - 1;
       const bool one_batch = (m_first / p.rows_per_batch) == (m_last / p.rows_per_batch);
+      const bool n_ok_all = n0 + BN <= p.N;     // (this kernel only takes problems of whole N tiles: always true)
       auto res_row = [&](int it) -> i32x4 {
         const int mc = min(m0 + wm * 128 + it * 4 + rsub, p.M - 1);
         return *reinterpret_cast<const i32x4*>(p.res + (int64_t)mc * p.ldc + ncc);
@@ -1323,7 +1324,16 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
       auto pipelined = [&](auto f32_c, auto fast_c) {
         // groups of 8 row-instructions: loads(g) run one group ahead of combine(g - 1) + stores(g - 1); every load of a
         // group precedes the stores of the previous one in program order (vmcnt retires in order).
-        // FAST (whole tile): unpredicated stores off one base pointer -- the guarded store re-reads M / ldc / C per row.
+        // FAST (whole tile): unpredicated stores off one base pointer.  !FAST (the last, ragged row of M tiles; residual rows are
+        // clamped): the same pipeline, a lane stores its first `it_max` row-instructions only -- one compare against a per-lane
+        // count per store.  (The row-at-a-time edge path below is one exposed gate + residual round trip per row-instruction:
+        // +12 ... 19 us on a launch whose last tiles are ragged, Qwen-Image's M = 6889: profiles/r04_experiments.md.)
+        constexpr bool FAST = decltype(fast_c)::value;
+        int it_max = 32;
+        if constexpr (!FAST) {
+          const int rows_valid = p.M - (m0 + wm * 128) - rsub;    // rows 4 it + rsub < M - tile row 0
+          it_max = rows_valid <= 0 ? 0 : (rows_valid + 3) >> 2;
+        }
         float g8[8];
         load_gate(m_first / p.rows_per_batch, g8);
         i32x4 rr[2][8], oo[8];
@@ -1341,13 +1351,16 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int it = 0; it < 8; ++it) {
-            *reinterpret_cast<i32x4*>(cptr + (gi * 8 + it) * step4) = oo[it];
+            if (FAST || gi * 8 + it < it_max) *reinterpret_cast<i32x4*>(cptr + (gi * 8 + it) * step4) = oo[it];
           }
         }
       };
       if (one_batch && full) {
         if (p.gate_f32) pipelined(std::true_type{}, std::true_type{});
         else pipelined(std::false_type{}, std::true_type{});
+      } else if (one_batch && n_ok_all) {
+        if (p.gate_f32) pipelined(std::true_type{}, std::false_type{});
+        else pipelined(std::false_type{}, std::false_type{});
       } else {
         // edge tiles and waves whose rows straddle a batch boundary (rare): per-row gate vector, guarded stores, unpipelined
         // (the double-buffered form with guarded stores ran out of registers: hipcc parked three of them in a0..a2)
