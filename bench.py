@@ -143,6 +143,55 @@ def cpu_baseline_leg(height, width, n_txt, quant_tag):
                       f"{torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs), extrapolated x19/x38 to one denoise step ({step_s:.0f}s)"}
 
 
+class DeviceStateSampler:
+    """Shader clock / package power of THIS rank's GPU while the timed steps run (rocm-smi as a child process, ~2 samples a second):
+    MFMA-dense kernels are power-limited on this part, and the boxes of one pool differ by several per cent with identical code --
+    the bench line carries what the device was doing (`device_state`), so a slow box can be told from a slow build."""
+
+    def __init__(self, device_index: int):
+        import threading
+        self.dev, self.samples, self._stop = device_index, [], threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def usable() -> bool:
+        """Not under a profiler (rocprofv3's tool library would ride into the child processes), and rocm-smi on PATH."""
+        import shutil
+        if any(k.startswith(("ROCP", "HSA_TOOLS")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+            return False
+        return shutil.which("rocm-smi") is not None
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+                sclk = re.search(r"sclk clock level:[^(]*\((\d+)Mhz\)", out)
+                pw = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+                if sclk:
+                    self.samples.append((int(sclk.group(1)), float(pw.group(1)) if pw else None))
+            except Exception:
+                return
+            self._stop.wait(0.25)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=15)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        clk = sorted(c for c, _ in self.samples)
+        pw = sorted(p_ for _, p_ in self.samples if p_ is not None)
+        return {"samples": len(clk), "sclk_mhz": {"min": clk[0], "median": clk[len(clk) // 2], "max": clk[-1]},
+                "package_power_w_median": pw[len(pw) // 2] if pw else None, "source": "rocm-smi --showclocks --showpower, polled during the timed steps"}
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh child processes (one per GPU, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* set) BEFORE anything in this process touches the GPU, relay rank 0's JSON line, and return
@@ -261,6 +310,7 @@ def main():
                     "sharding / CFG-pair exchange / final gather with real HIP forwards); the line says so and is not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event spans")
+    ap.add_argument("--no-device-state", action="store_true", help="do not poll rocm-smi (shader clock / package power) during the timed steps")
     args = ap.parse_args()
     dflt = {"flux": (1024, 2048, 512, "fp8"), "qwen": (1328, 1328, 128, "int8"), "wan": (768, 1280, 512, "fp8"), "sd35": (1024, 1024, 333, "fp8"), "sdxl": (1024, 1024, 77, "fp8")}[args.model]
     args.height, args.width = args.height or dflt[0], args.width or dflt[1]
@@ -440,6 +490,9 @@ def main():
         D.barrier()
         torch.cuda.synchronize()
         rec = timing.Recorder() if not args.no_kernel_timing else None
+        smi = DeviceStateSampler(local_rank) if (rank == 0 and not args.no_device_state and not args.same_device and DeviceStateSampler.usable()) else None
+        if smi:
+            smi.__enter__()
         t0 = time.perf_counter()
         if rec:
             rec.__enter__()
@@ -449,6 +502,8 @@ def main():
             rec.__exit__(None, None, None)
         torch.cuda.synchronize()
         t_steps = time.perf_counter() - t0          # this rank's own steps (a straggler shows here, not only in the max)
+        if smi:
+            smi.__exit__(None, None, None)
         final = gather_final()      # the job's single end-of-job collective (RCCL all-gather)
         torch.cuda.synchronize()
         t_gather = time.perf_counter() - t0 - t_steps
@@ -513,6 +568,7 @@ def main():
         "per_rank_ms_per_step": [round(r[0], 3) for r in per_rank],
         "final_allgather_ms": round(max(r[1] for r in per_rank), 3),
         "vs_baseline": None,
+        "device_state": smi.summary() if smi else None,
         "dtype": {"fp8": "fp8_e4m3 W8A8 GEMM (fp32 accumulate) + bf16 attention", "int8": "int8 W8A8 + bf16 attention", "bf16": "bf16"}[args.quant],
         "data": f"synthetic (counter-based random weights of the {ARCH_NAME[args.model]} architecture, synthetic latents/prompt embeddings)",
         "config": {"workload": workload, "global_batch": n_images, "height": args.height, "width": args.width,
