@@ -503,13 +503,15 @@ def main():
         torch.cuda.synchronize()
         t_steps = time.perf_counter() - t0          # this rank's own steps (a straggler shows here, not only in the max)
         if smi:
-            smi.__exit__(None, None, None)
+            smi._stop.set()                         # no more samples; the thread is joined after the clock below has stopped
         final = gather_final()      # the job's single end-of-job collective (RCCL all-gather)
         torch.cuda.synchronize()
         t_gather = time.perf_counter() - t0 - t_steps
         D.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        if smi:
+            smi.__exit__(None, None, None)
     elapsed = D.max_over_ranks(elapsed, dev)
     per_rank = D.gather_floats([t_steps / args.steps * 1e3, t_gather * 1e3], dev)     # [world][2]
     assert torch.isfinite(final.float()).all(), "non-finite latents"
