@@ -161,16 +161,22 @@ class DeviceStateSampler:
             return False
         return shutil.which("rocm-smi") is not None
 
-    def _run(self):
+    @staticmethod
+    def parse(out: str):
+        """(shader clock MHz, package power W | None) from `rocm-smi --showclocks --showpower` text, None without a clock line."""
         import re
+        sclk = re.search(r"sclk clock level:[^(]*\((\d+)Mhz\)", out)
+        pw = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+        return (int(sclk.group(1)), float(pw.group(1)) if pw else None) if sclk else None
+
+    def _run(self):
         import subprocess
         while not self._stop.is_set():
             try:
                 out = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
-                sclk = re.search(r"sclk clock level:[^(]*\((\d+)Mhz\)", out)
-                pw = re.search(r"Power \(W\):\s*([0-9.]+)", out)
-                if sclk:
-                    self.samples.append((int(sclk.group(1)), float(pw.group(1)) if pw else None))
+                smp = self.parse(out)
+                if smp:
+                    self.samples.append(smp)
             except Exception:
                 return
             self._stop.wait(0.25)

@@ -207,6 +207,30 @@ def test_bench_stdout_carries_only_the_result_line():
     assert "library banner on fd 1" in res.stderr and "python print" in res.stderr and "late banner" in res.stderr
 
 
+def test_bench_device_state_sampler_parses_rocm_smi_and_stays_off_under_a_profiler(monkeypatch):
+    """bench.py's `device_state`: shader clock / package power from rocm-smi's text; no sample without a clock line; the sampler is
+    not started when a profiler's tool library is in the environment (it would ride into the child processes)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    txt = ("GPU[0]\t\t: mclk clock level: 0: (2000Mhz)\nGPU[0]\t\t: sclk clock level: S: (2243Mhz)\n"
+           "GPU[0]\t\t: Current Socket Graphics Package Power (W): 1361.0\n")
+    assert bench.DeviceStateSampler.parse(txt) == (2243, 1361.0)
+    assert bench.DeviceStateSampler.parse("GPU[0]\t\t: sclk clock level: S: (94Mhz)\n") == (94, None)
+    assert bench.DeviceStateSampler.parse("no GPU here") is None
+    s = bench.DeviceStateSampler(0)
+    assert s.summary() is None
+    s.samples = [(2237, 1350.0), (2248, None), (2243, 1361.0)]
+    out = s.summary()
+    assert out["samples"] == 3 and out["sclk_mhz"] == {"min": 2237, "median": 2243, "max": 2248} and out["package_power_w_median"] == 1361.0
+    monkeypatch.setenv("ROCP_TOOL_LIB", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert not bench.DeviceStateSampler.usable()
+    monkeypatch.delenv("ROCP_TOOL_LIB")
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert not bench.DeviceStateSampler.usable()
+
+
 # ------------------------------------------------------------------ supervised rank launcher (fastdm_amd/launch.py)
 def _child(code):
     import sys
