@@ -143,18 +143,21 @@ def cpu_baseline_leg(height, width, n_txt, quant_tag):
                       f"{torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs), extrapolated x19/x38 to one denoise step ({step_s:.0f}s)"}
 
 
-class DeviceStateSampler:
-    """Shader clock / package power of THIS rank's GPU while the timed steps run (rocm-smi as a child process, ~2 samples a second):
-    MFMA-dense kernels are power-limited on this part, and the boxes of one pool differ by several per cent with identical code --
-    the bench line carries what the device was doing (`device_state`), so a slow box can be told from a slow build."""
+class DeviceState:
+    """What THIS rank's GPU was doing around the timed steps, measured OUTSIDE the timed window (rocm-smi
+    forked four times a second inside it, and its DPM level is not the clock an MFMA-dense kernel runs at):
+      * `mfma_clock_mhz`: the shader clock the chip sustains under an fp8-MFMA + LDS-read loop on random data, from in-kernel
+        delta(s_memtime) / delta(s_memrealtime) x 100 MHz stamps of the library's probe kernel (fdm_clock_probe), median over its
+        256 workgroups, launched right after the timed steps while the package is still at its loaded operating point;
+      * one `rocm-smi --showclocks --showpower` reading before the warm-up and one right after the probe (DPM level / package power:
+        context only -- MI355X_MICROARCH.md: pp_dpm_sclk reads up to ~10 % above the in-kernel clock of an MFMA-dense loop)."""
 
     def __init__(self, device_index: int):
-        import threading
-        self.dev, self.samples, self._stop = device_index, [], threading.Event()
-        self._thread = threading.Thread(target=self._run, daemon=True)
+        self.dev, self.smi = device_index, {}
+        self.probe = None
 
     @staticmethod
-    def usable() -> bool:
+    def smi_usable() -> bool:
         """Not under a profiler (rocprofv3's tool library would ride into the child processes), and rocm-smi on PATH."""
         import shutil
         if any(k.startswith(("ROCP", "HSA_TOOLS")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
@@ -169,33 +172,29 @@ class DeviceStateSampler:
         pw = re.search(r"Power \(W\):\s*([0-9.]+)", out)
         return (int(sclk.group(1)), float(pw.group(1)) if pw else None) if sclk else None
 
-    def _run(self):
+    def sample_smi(self, tag: str):
         import subprocess
-        while not self._stop.is_set():
-            try:
-                out = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
-                smp = self.parse(out)
-                if smp:
-                    self.samples.append(smp)
-            except Exception:
-                return
-            self._stop.wait(0.25)
+        if not self.smi_usable():
+            return
+        try:
+            out = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+            smp = self.parse(out)
+            if smp:
+                self.smi[tag] = {"sclk_dpm_mhz": smp[0], "package_power_w": smp[1]}
+        except Exception:  # noqa: BLE001
+            pass
 
-    def __enter__(self):
-        self._thread.start()
-        return self
-
-    def __exit__(self, *exc):
-        self._stop.set()
-        self._thread.join(timeout=15)
+    def run_probe(self, ms: float = 40.0):
+        from fastdm_amd.kernel import fused
+        try:
+            self.probe = fused.clock_probe(torch.device("cuda", self.dev), ms)
+        except Exception as e:  # noqa: BLE001
+            self.probe = {"error": str(e)}
 
     def summary(self):
-        if not self.samples:
-            return None
-        clk = sorted(c for c, _ in self.samples)
-        pw = sorted(p_ for _, p_ in self.samples if p_ is not None)
-        return {"samples": len(clk), "sclk_mhz": {"min": clk[0], "median": clk[len(clk) // 2], "max": clk[-1]},
-                "package_power_w_median": pw[len(pw) // 2] if pw else None, "source": "rocm-smi --showclocks --showpower, polled during the timed steps"}
+        return {"mfma_clock_mhz": self.probe, "rocm_smi": self.smi or None,
+                "source": "fdm_clock_probe (s_memtime / s_memrealtime stamps of an fp8 MFMA + LDS loop) right AFTER the timed steps; rocm-smi "
+                          "once before the warm-up and once after the probe; nothing is sampled inside the timed window"}
 
 
 def spawn_ranks(n: int) -> int:
@@ -316,7 +315,9 @@ def main():
                     "sharding / CFG-pair exchange / final gather with real HIP forwards); the line says so and is not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event spans")
-    ap.add_argument("--no-device-state", action="store_true", help="do not poll rocm-smi (shader clock / package power) during the timed steps")
+    ap.add_argument("--no-device-state", action="store_true", help="skip the MFMA clock probe / rocm-smi readings taken around (never inside) the timed steps")
+    ap.add_argument("--allow-build-flags", action="store_true", help="A/B only: accept a library built with extra hipcc flags (FDM_LIB_DIR=tools/micro/_ab/<name>); "
+                    "the line then carries lib_flags and \"experimental\": true and is not a headline number")
     args = ap.parse_args()
     dflt = {"flux": (1024, 2048, 512, "fp8"), "qwen": (1328, 1328, 128, "int8"), "wan": (768, 1280, 512, "fp8"), "sd35": (1024, 1024, 333, "fp8"), "sdxl": (1024, 1024, 77, "fp8")}[args.model]
     args.height, args.width = args.height or dflt[0], args.width or dflt[1]
@@ -335,6 +336,11 @@ def main():
         sys.exit("--cfg-pair needs a two-forward model (qwen / wan / sd35 / sdxl) and an even --gpus")
 
     claim_stdout()
+    from fastdm_amd import _native
+    prov = _native.provenance()          # what the LOADED binary says it was built from (fdm_source_digest / fdm_build_flags)
+    if prov["lib_flags"] and not args.allow_build_flags:
+        sys.exit(f"bench.py: refusing to benchmark a library built with extra flags '{prov['lib_flags']}' ({prov['lib_path']}); "
+                 "--allow-build-flags marks the line as an experiment")
     from fastdm_amd import distributed as D
     rank, world, local_rank = D.init_from_env(backend="gloo" if args.same_device else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run or let bench.py spawn the ranks"
@@ -482,6 +488,9 @@ def main():
         state["lat"] = (state["lat"].float() + float(sig[i + 1] - sig[i]) * v.float()).to(torch.bfloat16)
         state["i"] += 1
 
+    smi = DeviceState(local_rank) if (rank == 0 and not args.no_device_state and not args.same_device) else None
+    if smi:
+        smi.sample_smi("before")
     with torch.no_grad():
         for _ in range(args.warmup):
             one_step()
@@ -496,9 +505,6 @@ def main():
         D.barrier()
         torch.cuda.synchronize()
         rec = timing.Recorder() if not args.no_kernel_timing else None
-        smi = DeviceStateSampler(local_rank) if (rank == 0 and not args.no_device_state and not args.same_device and DeviceStateSampler.usable()) else None
-        if smi:
-            smi.__enter__()
         t0 = time.perf_counter()
         if rec:
             rec.__enter__()
@@ -508,16 +514,15 @@ def main():
             rec.__exit__(None, None, None)
         torch.cuda.synchronize()
         t_steps = time.perf_counter() - t0          # this rank's own steps (a straggler shows here, not only in the max)
-        if smi:
-            smi._stop.set()                         # no more samples; the thread is joined after the clock below has stopped
         final = gather_final()      # the job's single end-of-job collective (RCCL all-gather)
         torch.cuda.synchronize()
         t_gather = time.perf_counter() - t0 - t_steps
         D.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        if smi:
-            smi.__exit__(None, None, None)
+        if smi:                                     # the clock has stopped: probe the loaded chip, then read rocm-smi once more
+            smi.run_probe()
+            smi.sample_smi("after")
     elapsed = D.max_over_ranks(elapsed, dev)
     per_rank = D.gather_floats([t_steps / args.steps * 1e3, t_gather * 1e3], dev)     # [world][2]
     assert torch.isfinite(final.float()).all(), "non-finite latents"
@@ -576,6 +581,7 @@ def main():
         "per_rank_ms_per_step": [round(r[0], 3) for r in per_rank],
         "final_allgather_ms": round(max(r[1] for r in per_rank), 3),
         "vs_baseline": None,
+        **prov, **({"experimental": True} if prov["lib_flags"] else {}),
         "device_state": smi.summary() if smi else None,
         "dtype": {"fp8": "fp8_e4m3 W8A8 GEMM (fp32 accumulate) + bf16 attention", "int8": "int8 W8A8 + bf16 attention", "bf16": "bf16"}[args.quant],
         "data": f"synthetic (counter-based random weights of the {ARCH_NAME[args.model]} architecture, synthetic latents/prompt embeddings)",

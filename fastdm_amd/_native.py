@@ -10,7 +10,11 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libfastdm_amd.so")
+_PRODUCT_LIB_DIR = os.path.join(_HERE, "_lib")
+# FDM_LIB_DIR: run the whole Python stack on an A/B variant built by `FDM_OUT=tools/micro/_ab/<name> csrc/build.sh -D...`
+# (same sources, extra flags; bench.py refuses to print a headline line from one unless told to)
+LIB_DIR = os.path.abspath(os.environ.get("FDM_LIB_DIR") or _PRODUCT_LIB_DIR)
+LIB_PATH = os.path.join(LIB_DIR, "libfastdm_amd.so")
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
 P, I64, I32, U32, F32 = C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_float
@@ -46,11 +50,14 @@ SIGNATURES = {
     "fdm_qk_norm_rope_inplace": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, P]),
     "fdm_absdiff_sums": (I32, [P, P, P, I64, P]),
     "fdm_abi_version": (I32, []),
+    "fdm_source_digest": (C.c_char_p, []),
+    "fdm_build_flags": (C.c_char_p, []),
+    "fdm_clock_probe": (I32, [P, P, I32, I32, P]),
     "fdm_synth_fill_bf16": (I32, [P, I64, U32, I32, F32, F32, P]),
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
 }
 
-ABI_VERSION = 11         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
+ABI_VERSION = 12         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL, EPI_GATE_RESIDUAL_F32 = 0, 1, 2, 3, 4
 
 
@@ -79,48 +86,65 @@ class NativeLibraryError(ImportError):
     pass
 
 
-def _source_digest(srcs) -> str:
-    import hashlib
-    h = hashlib.sha256()
-    for path in sorted(srcs):
-        h.update(os.path.basename(path).encode())
-        with open(path, "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()
-
-
 def current_source_digest() -> str:
-    """Content digest of everything libfastdm_amd.so is built from (kernel sources, build script, the C-ABI header)."""
-    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))
-            if f.endswith((".hip", ".h", ".sh", ".inc", ".py"))]      # .inc: the generated assembly bodies of gemm_p4_kernel, .py: their generator
+    """Content digest of everything libfastdm_amd.so is built from (kernel sources, the generated assembly bodies and their
+    generator, the build script, the C-ABI header): sha256 of the manifest "<sha256 of file>  <basename>\\n", basenames in C
+    order -- csrc/build.sh computes the same value and compiles it INTO the library (fdm_source_digest())."""
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".sh", ".inc", ".py"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "fastdm_amd.h"))
-    return _source_digest(srcs)
+    manifest = ""
+    for path in sorted(srcs, key=lambda p: os.path.basename(p).encode()):
+        with open(path, "rb") as f:
+            manifest += f"{hashlib.sha256(f.read()).hexdigest()}  {os.path.basename(path)}\n"
+    return hashlib.sha256(manifest.encode()).hexdigest()
+
+
+def embedded_provenance(path=None):
+    """(source digest, extra build flags) compiled into a library file, read from its what(1)-style markers WITHOUT loading it
+    (a stale library has to be replaced before dlopen); (None, None) for a file without them."""
+    import re
+    try:
+        with open(path or LIB_PATH, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None, None
+    d = re.search(rb"@\(#\)fdm_source_digest=([0-9a-f]{64})\0", blob)
+    fl = re.search(rb"@\(#\)fdm_build_flags=([^\0]*)\0", blob)
+    return (d.group(1).decode() if d else None), (fl.group(1).decode() if fl else None)
+
+
+def is_current(path=None) -> bool:
+    return embedded_provenance(path)[0] == current_source_digest()
+
+
+def _run_build():
+    env = dict(os.environ)
+    if LIB_DIR != _PRODUCT_LIB_DIR:
+        env["FDM_OUT"] = LIB_DIR
+    flags = os.environ.get("FDM_LIB_FLAGS", "").split() if LIB_DIR != _PRODUCT_LIB_DIR else []
+    return subprocess.run(["bash", BUILD_SCRIPT] + flags, capture_output=True, text=True, env=env)
 
 
 def build(force: bool = False) -> str:
-    """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU).  The library is rebuilt only
-    when the sources' content digest changed (file times do not survive a copy to another machine)."""
-    digest = current_source_digest()
-    stamp = LIB_PATH + ".srcdigest"
-
-    def current():
-        return os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest
-
-    if not force and current():
+    """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU).  The library is rebuilt only when the
+    digest compiled into it differs from the sources' (file times do not survive a copy to another machine, and a stamp file
+    beside the binary can lie about it: round 4 shipped a rejected experiment under HEAD's stamp)."""
+    if not force and is_current():
         return LIB_PATH
     # one builder at a time: the ranks of a multi-GPU launch all come through here
     import fcntl
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
     with open(LIB_PATH + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        if force or not current():          # another process may have finished the build while this one waited
-            res = subprocess.run(["bash", BUILD_SCRIPT], capture_output=True, text=True)
+        if force or not is_current():          # another process may have finished the build while this one waited
+            res = _run_build()
             if res.returncode != 0 or not os.path.exists(LIB_PATH):
                 raise NativeLibraryError(f"building libfastdm_amd.so failed:\n{res.stdout}\n{res.stderr}")
-            tmp = f"{stamp}.{os.getpid()}"
-            with open(tmp, "w") as f:
-                f.write(digest)
-            os.replace(tmp, stamp)           # atomic, like the library itself (build.sh links to a temporary name and renames)
+            if not is_current():
+                raise NativeLibraryError(f"{BUILD_SCRIPT} produced a library whose embedded digest {embedded_provenance()[0]} is not the "
+                                         f"sources' {current_source_digest()} (sources edited during the build?)")
     return LIB_PATH
 
 
@@ -132,16 +156,21 @@ def lib():
     with _lock:
         if _lib is not None:
             return _lib
-        # Build artefacts are git-ignored, so a checkout can hold a library older than the sources: whenever a compiler is
-        # at hand, build() compares the sources' digest with the one the library was built from and rebuilds on mismatch.
-        # (On the GPU box the prebuilt library travels with its digest file and matches.)
-        have_hipcc = os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"))
-        if not os.path.exists(LIB_PATH) or (have_hipcc and os.environ.get("FDM_NO_REBUILD") != "1"):
+        # Build artefacts are git-ignored, so a checkout can hold a library older than the sources.  The digest compiled into
+        # the binary is compared with the sources' BEFORE dlopen: on mismatch the library is rebuilt when a compiler is at hand
+        # and refused otherwise -- never loaded.  (On the GPU box the prebuilt library travels with the sources and matches.)
+        have_hipcc = os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) and os.environ.get("FDM_NO_REBUILD") != "1"
+        if not is_current():
+            if not have_hipcc:
+                raise NativeLibraryError(
+                    f"fastdm_amd: {LIB_PATH} is missing or was built from other sources (embedded digest {embedded_provenance()[0]}, "
+                    f"sources {current_source_digest()}) and there is no hipcc to rebuild it (or FDM_NO_REBUILD=1). "
+                    "This package has no CPU / eager fallback.")
             try:
                 build()
             except Exception as e:  # noqa: BLE001
                 raise NativeLibraryError(
-                    f"fastdm_amd: HIP library {LIB_PATH} is missing and could not be built ({e}). "
+                    f"fastdm_amd: HIP library {LIB_PATH} is missing or stale and could not be built ({e}). "
                     "This package has no CPU / eager fallback.") from e
         # torch bundles its own libamdhip64; it must be the HIP runtime of the process.  Loading our library first
         # would pull in /opt/rocm's copy, and kernels launched through that second runtime fail with
@@ -151,14 +180,31 @@ def lib():
             handle = C.CDLL(LIB_PATH)
         except OSError as e:
             raise NativeLibraryError(f"fastdm_amd: cannot load {LIB_PATH}: {e}") from e
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(handle, name)  # AttributeError -> missing export: let it propagate loudly
-            fn.restype, fn.argtypes = res, args
+        for name in ("fdm_abi_version", "fdm_source_digest", "fdm_build_flags"):      # identity first, before anything else is bound
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = SIGNATURES[name]
         if handle.fdm_abi_version() != ABI_VERSION:
             raise NativeLibraryError(f"fastdm_amd: {LIB_PATH} was built from another revision of include/fastdm_amd.h (ABI "
                                      f"{handle.fdm_abi_version()}, these bindings expect {ABI_VERSION}); rebuild it with __graft_entry__.build()")
+        if handle.fdm_source_digest().decode() != current_source_digest():
+            raise NativeLibraryError(f"fastdm_amd: {LIB_PATH} reports source digest {handle.fdm_source_digest().decode()}, the sources are "
+                                     f"{current_source_digest()}")
+        flags = handle.fdm_build_flags().decode()
+        if flags and LIB_DIR == _PRODUCT_LIB_DIR:
+            raise NativeLibraryError(f"fastdm_amd: the product library {LIB_PATH} was built with extra flags '{flags}'; A/B variants "
+                                     "live under tools/micro/_ab/<name> (FDM_LIB_DIR), never in fastdm_amd/_lib")
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError -> missing export: let it propagate loudly
+            fn.restype, fn.argtypes = res, args
         _lib = handle
     return _lib
+
+
+def provenance() -> dict:
+    """What the LOADED library says about itself (bench.py prints this on its JSON line)."""
+    h = lib()
+    return {"lib_digest": h.fdm_source_digest().decode(), "lib_flags": h.fdm_build_flags().decode(),
+            "lib_path": os.path.relpath(LIB_PATH, os.path.dirname(_HERE))}
 
 
 def check(rc: int, what: str):
@@ -196,34 +242,41 @@ def attn_workspace(device, head_dim):
 import collections
 
 _gemm_ws = collections.OrderedDict()      # (device, stream handle) -> buffer, least recently used first
-_GEMM_WS_MAX = 8                           # 8 x 64 MiB: more streams than that in flight at once is not a denoise loop
+_gemm_ws_pinned = set()                    # keys whose buffer address may be baked into a captured HIP graph: never evicted
+_GEMM_WS_MAX = 8                           # unpinned buffers PER DEVICE (8 x 64 MiB): more streams in flight is not a denoise loop
 
 
-def gemm_int8_workspace(device):
+def gemm_int8_workspace(device, pin=False):
     """Scratch of fdm_gemm_w8a8_int8_x2_ws's split-K tail (64 MiB), one buffer per (device, STREAM): the library's merge launch has
     consumed it before the next GEMM's parts write only when both are on one stream, so launches on another stream get their own
     buffer instead of silently sharing partial sums.  Allocate it before any HIP-graph capture (`warm_gemm_int8_workspace`): an
-    allocation inside a capture would land in the graph's private pool."""
+    allocation inside a capture would land in the graph's private pool.  A buffer that was warmed explicitly, or is handed out
+    while a capture is in flight, is PINNED: a graph replay writes split-K partials to that address for as long as the graph
+    lives, so it must never go back to the allocator."""
     import torch
     dev = device.index if device.index is not None else torch.cuda.current_device()
     key = (dev, int(torch.cuda.current_stream(dev).cuda_stream))
+    capturing = torch.cuda.is_current_stream_capturing()
     ws = _gemm_ws.get(key)
     if ws is None:
-        if torch.cuda.is_current_stream_capturing():
+        if capturing:
             raise RuntimeError("fastdm_amd: the int8 split-K workspace of this stream must be allocated before graph capture "
                                "(call fastdm_amd._native.warm_gemm_int8_workspace(device) on the capture stream first)")
         ws = torch.empty(int(lib().fdm_gemm_int8_workspace_bytes()), dtype=torch.uint8, device=device)
         _gemm_ws[key] = ws
-        # bounded: a stream handle is not an identity (a destroyed stream's handle can come back), and every stream that ever ran an
-        # int8 GEMM used to keep its 64 MiB for good.  The least recently used entry goes; torch's caching allocator keeps the block
-        # alive until the work queued on it has run.
-        while len(_gemm_ws) > _GEMM_WS_MAX:
-            _gemm_ws.popitem(last=False)
+        # bounded per device: a stream handle is not an identity (a destroyed stream's handle can come back), and every stream that
+        # ever ran an int8 GEMM used to keep its 64 MiB for good.  The least recently used UNPINNED entry of this device goes; for
+        # eager use torch's caching allocator keeps the block alive until the work queued on it has run.
+        mine = [k for k in _gemm_ws if k[0] == dev and k not in _gemm_ws_pinned]
+        for k in mine[:max(0, len(mine) - _GEMM_WS_MAX)]:
+            del _gemm_ws[k]
     else:
         _gemm_ws.move_to_end(key)
+    if pin or capturing:
+        _gemm_ws_pinned.add(key)
     return ws
 
 
 def warm_gemm_int8_workspace(device):
-    """Allocate the int8 split-K workspace of the current stream eagerly (model load / warm-up path)."""
-    return gemm_int8_workspace(device)
+    """Allocate (and pin) the int8 split-K workspace of the current stream eagerly (model load / warm-up path before a capture)."""
+    return gemm_int8_workspace(device, pin=True)

@@ -5,6 +5,15 @@
 
 #include <atomic>
 
+// build.sh writes build_info.h into the output directory (source digest of everything the library is built from + the extra hipcc
+// flags of an A/B build).  A library compiled any other way says so instead of carrying somebody else's identity.
+#ifdef FDM_HAVE_BUILD_INFO
+#include "build_info.h"
+#else
+#define FDM_SOURCE_DIGEST "0000000000000000000000000000000000000000000000000000000000000000"
+#define FDM_BUILD_FLAGS "[not built by build.sh]"
+#endif
+
 namespace fdm {
 thread_local int g_last_hip_error = 0;
 
@@ -21,6 +30,59 @@ int device_cu_count() {
   if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
   if (dev >= 0 && dev < MAX_DEV) cache[dev].store(cu, std::memory_order_relaxed);
   return cu;
+}
+}  // namespace fdm
+
+// ---- fdm_clock_probe: the shader clock the chip sustains under an MFMA-dense load -------------------------------------------
+// One block per CU, one wave per SIMD (64 KiB of LDS per block keeps a second block off the CU).  Each wave runs `iters` rounds of
+// 4 ds_read_b128 (operands re-read from LDS, rotating addresses, random finite e4m3 bytes) + 16 v_mfma_f32_16x16x128_f8f6f4 on 8
+// independent accumulators: the instruction mix of the W8A8 tile loops without their global traffic.  Stamps: s_memtime (shader
+// cycles) and s_memrealtime (100 MHz) once before and once after the loop; out[2 b] / out[2 b + 1] = the two deltas of block b's
+// wave 0.  The stamps go to a buffer nothing else reads (MI355X_MICROARCH.md, DVFS item 6); no product kernel carries a stamp.
+namespace fdm {
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* __restrict__ out, float* __restrict__ sink, int iters) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[16384];
+  uint32_t h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+  for (int i = threadIdx.x; i < 16384; i += 256) {
+    h = h * 1664525u + 1013904223u;
+    lds[i] = (h ^ (h >> 13)) & 0xBFBFBFBFu;          // exponent MSB clear: finite, |x| < 2
+  }
+  __syncthreads();
+  f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t lane_off = (threadIdx.x & 255u) * 4u;   // dwords; 16-byte pieces
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t base = (lane_off + (uint32_t)it * 1024u) & 16383u;
+    i32x8 a, b;
+    {
+      const i32x4 a0 = *reinterpret_cast<const i32x4*>(&lds[base]);
+      const i32x4 a1 = *reinterpret_cast<const i32x4*>(&lds[(base + 4096u) & 16383u]);
+      const i32x4 b0 = *reinterpret_cast<const i32x4*>(&lds[(base + 8192u) & 16383u]);
+      const i32x4 b1 = *reinterpret_cast<const i32x4*>(&lds[(base + 12288u) & 16383u]);
+      a = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      b = i32x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc[i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 123.456f) sink[threadIdx.x] = s;             // keeps the MFMAs alive; practically never taken
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = t1 - t0;
+    out[2 * blockIdx.x + 1] = r1 - r0;
+  }
 }
 }  // namespace fdm
 
@@ -50,6 +112,20 @@ const char* fdm_error_string(int code) {
 }
 
 int fdm_abi_version(void) { return FDM_ABI_VERSION; }
+
+// what(1)-style markers: _native.py reads them from the file WITHOUT loading it (a stale library must be rebuilt before dlopen)
+extern "C" const char fdm_source_digest_marker[] = "@(#)fdm_source_digest=" FDM_SOURCE_DIGEST;
+extern "C" const char fdm_build_flags_marker[] = "@(#)fdm_build_flags=" FDM_BUILD_FLAGS;
+const char* fdm_source_digest(void) { return fdm_source_digest_marker + sizeof("@(#)fdm_source_digest=") - 1; }
+const char* fdm_build_flags(void) { return fdm_build_flags_marker + sizeof("@(#)fdm_build_flags=") - 1; }
+
+int fdm_clock_probe(void* out_pairs, void* sink, int n_blocks, int iters, fdm_stream_t stream) {
+  if (out_pairs == nullptr || sink == nullptr || n_blocks < 1 || n_blocks > 4096 || iters < 1) return FDM_ERR_INVALID;
+  hipLaunchKernelGGL(fdm::clock_probe_kernel, dim3(n_blocks), dim3(256), 0, fdm::to_stream(stream),
+                     static_cast<unsigned long long*>(out_pairs), static_cast<float*>(sink), iters);
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
 
 const char* fdm_last_hip_error_string(void) { return hipGetErrorString((hipError_t)fdm::g_last_hip_error); }
 

@@ -776,16 +776,30 @@ def render(g):
     return "\n".join(lines) + "\n"
 
 
-if __name__ == "__main__":
-    here = os.path.dirname(os.path.abspath(__file__))
+def outputs():
+    """file name -> text of every generated file."""
+    files = {}
     for epi, name in ((EPI_NONE, "none"), (EPI_GELU_TANH, "gelu_tanh"), (EPI_GELU_ERF, "gelu_erf")):
         g = build(epi)
-        text = "// generated by gen_gemm_p4.py -- do not edit\n" + render(g)
-        with open(os.path.join(os.environ.get("P4_OUT", here), f"gemm_p4_body_{name}.inc"), "w") as f:
-            f.write(text)
+        files[f"gemm_p4_body_{name}.inc"] = "// generated by gen_gemm_p4.py -- do not edit\n" + render(g)
         n_ins = sum(1 for l in g.out if not l.startswith(";") and not l.rstrip().endswith(":"))
-        print(f"gemm_p4_body_{name}.inc: {n_ins} instructions, {g.s_next} SGPRs")
+        print(f"gemm_p4_body_{name}.inc: {n_ins} instructions, {g.s_next} SGPRs", file=sys.stderr if "--check" in sys.argv else sys.stdout)
     # the statement's clobber list: everything the body names (inputs are therefore allocated in v0-v7 / s0-s7)
     regs = [f"v{i}" for i in range(8, 256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(8, 102)] + ["vcc", "memory"]
-    with open(os.path.join(os.environ.get("P4_OUT", here), "gemm_p4_clobbers.inc"), "w") as f:
-        f.write("// generated by gen_gemm_p4.py -- do not edit\n" + ",\n".join(", ".join(f'"{r}"' for r in regs[i:i + 16]) for i in range(0, len(regs), 16)) + "\n")
+    files["gemm_p4_clobbers.inc"] = ("// generated by gen_gemm_p4.py -- do not edit\n"
+                                     + ",\n".join(", ".join(f'"{r}"' for r in regs[i:i + 16]) for i in range(0, len(regs), 16)) + "\n")
+    return files
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = outputs()
+    if "--check" in sys.argv:      # build.sh: the committed files must be exactly what this generator emits (nothing is written)
+        stale = [n for n, text in files.items() if not os.path.exists(os.path.join(here, n)) or open(os.path.join(here, n)).read() != text]
+        if stale:
+            print("stale generated files: " + ", ".join(stale), file=sys.stderr)
+            sys.exit(1)
+        sys.exit(0)
+    for n, text in files.items():
+        with open(os.path.join(os.environ.get("P4_OUT", here), n), "w") as f:
+            f.write(text)

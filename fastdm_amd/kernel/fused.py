@@ -157,3 +157,26 @@ def synth_fill(out: torch.Tensor, seed: int, kind: int, scale: float = 0.0, offs
     assert out.dtype == BF16 and out.is_contiguous()
     N.check(N.lib().fdm_synth_fill_bf16(N.ptr(out), out.numel(), seed, kind, scale, offset, N.stream()), "synth_fill")
     return out
+
+
+def clock_probe(device: torch.device, ms: float = 40.0, n_blocks: int = 256) -> dict:
+    """Shader clock (MHz) the chip sustains under an fp8-MFMA + LDS loop (fdm_clock_probe): a short calibration launch sizes the
+    loop for about `ms` milliseconds, a second launch is the measurement; clock of a workgroup = delta s_memtime / delta
+    s_memrealtime x 100 MHz.  Returns the median / min / max over the workgroups.  A measurement aid for bench.py's
+    `device_state`, never part of a step."""
+    with torch.cuda.device(device):
+        out = torch.zeros(2 * n_blocks, dtype=torch.int64, device=device)
+        sink = torch.zeros(256, dtype=torch.float32, device=device)
+
+        def run(iters):
+            N.check(N.lib().fdm_clock_probe(N.ptr(out), N.ptr(sink), n_blocks, int(iters), N.stream()), "clock_probe")
+            torch.cuda.synchronize()
+            return out.cpu().view(n_blocks, 2).double()
+
+        cal = run(20000)
+        ticks = float(cal[:, 1].median())                        # 100 MHz ticks for 20000 rounds
+        iters = max(1000, int(20000 * (ms * 1e5) / max(ticks, 1.0)))
+        r = run(iters)
+        clk = (r[:, 0] / r[:, 1].clamp(min=1.0) * 100.0).sort().values
+        return {"median": round(float(clk[n_blocks // 2]), 1), "min": round(float(clk[0]), 1), "max": round(float(clk[-1]), 1),
+                "probe_ms": round(float(r[:, 1].median()) / 1e5, 2), "rounds": iters, "workgroups": n_blocks}

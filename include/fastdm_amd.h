@@ -44,8 +44,22 @@ const char* fdm_last_hip_error_string(void);
 
 /* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
  * refuse to run instead of passing arguments at the wrong positions. */
-#define FDM_ABI_VERSION 11
+#define FDM_ABI_VERSION 12
 int fdm_abi_version(void);
+
+/* Provenance the binary carries itself (no stamp file beside it): the content digest (64 hex digits) of every source the
+ * library was built from -- the .hip / .h / .sh / .inc / .py files of csrc + this header, the manifest rule of csrc/build.sh -- and the
+ * extra hipcc flags of an A/B build ("" for the product library; build.sh refuses flags in fastdm_amd/_lib/).  The single
+ * build identity plays the role of the reference's one-arch guard (/root/reference/setup.py:99-111).  The same two strings sit
+ * in the file as "@(#)fdm_source_digest=..." / "@(#)fdm_build_flags=..." so a loader can check them before dlopen. */
+const char* fdm_source_digest(void);
+const char* fdm_build_flags(void);
+
+/* Measurement aid (bench.py `device_state`; no reference counterpart, no product kernel carries a stamp): n_blocks workgroups
+ * (one per CU) each run `iters` rounds of 4 LDS reads + 16 fp8 16x16x128 MFMAs on random finite data and write
+ * out_pairs[2 b] = delta s_memtime (shader cycles), out_pairs[2 b + 1] = delta s_memrealtime (100 MHz ticks) of block b, both
+ * uint64: clock = cycles / ticks x 100 MHz, median over blocks.  `sink`: 256 floats, never written in practice. */
+int fdm_clock_probe(void* out_pairs, void* sink, int n_blocks, int iters, fdm_stream_t stream);
 
 /* ---- replaces cuda_ops.rms_norm_ (ops.h:17-20; csrc/elmwise_ops.cu:56-84,433-449) -------------
  * out[r,:] = bf16(bf16(x[r,:] * rsqrt(mean(x^2)+eps)) * w[:]);  rows x hidden, contiguous.  Any hidden >= 1: widths that

@@ -94,3 +94,143 @@ def test_hand_scheduled_kernels_pass_their_asm_audit(script):
     env = dict(os.environ, FDM_AUDIT_ASM=asm) if os.path.exists(asm) else dict(os.environ)   # else the audit compiles (minutes)
     r = subprocess.run(["bash", path], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+# ------------------------------------------------------------------ provenance: the binary says what it was built from
+def _sha(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def test_library_carries_the_digest_of_the_sources_it_was_built_from():
+    """No stamp file: the digest compiled into libfastdm_amd.so (read from the file before dlopen AND returned by
+    fdm_source_digest()) equals the digest of the sources in the tree, and the product library has no extra build flags."""
+    lib = N.lib()
+    want = N.current_source_digest()
+    emb, flags = N.embedded_provenance()
+    assert emb == want == lib.fdm_source_digest().decode()
+    assert flags == "" == lib.fdm_build_flags().decode()
+    assert N.provenance() == {"lib_digest": want, "lib_flags": "", "lib_path": "fastdm_amd/_lib/libfastdm_amd.so"}
+    assert not os.path.exists(N.LIB_PATH + ".srcdigest")
+
+
+def test_build_script_and_python_agree_on_the_digest_rule():
+    """build.sh computes the digest with sha256sum, _native with hashlib: the same manifest rule (else every import rebuilds)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "fastdm_amd", "csrc")
+    sh = r'''
+for f in "$1"/*.hip "$1"/*.h "$1"/*.sh "$1"/*.inc "$1"/*.py "$1/../../include/fastdm_amd.h"; do [ -f "$f" ] && printf '%s %s\n' "$(basename "$f")" "$f"; done \
+ | LC_ALL=C sort | while read -r base path; do printf '%s  %s\n' "$(sha256sum < "$path" | cut -d' ' -f1)" "$base"; done | sha256sum | cut -d' ' -f1'''
+    out = subprocess.run(["bash", "-c", sh, "x", csrc], capture_output=True, text=True, check=True).stdout.strip()
+    assert out == N.current_source_digest()
+    assert "digest_manifest | sha256sum" in open(os.path.join(csrc, "build.sh")).read()
+
+
+def test_build_script_refuses_extra_flags_in_the_product_directory():
+    import subprocess
+    before = _sha(N.LIB_PATH)
+    r = subprocess.run(["bash", N.BUILD_SCRIPT, "-DFDM_GEMM_STAMPS"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "never go into" in r.stderr, r.stderr[-500:]
+    r = subprocess.run(["bash", N.BUILD_SCRIPT], capture_output=True, text=True, timeout=120, env=dict(os.environ, FDM_SKIP_AUDIT="1"))
+    assert r.returncode == 2, "a product build without its audits must be refused too"
+    assert _sha(N.LIB_PATH) == before
+
+
+def test_ab_variant_builds_beside_the_product_library_and_says_what_it_is(tmp_path):
+    """An A/B build (extra -D flags) goes to its own directory under tools/micro/_ab/ and records its flags; the product library
+    is byte for byte untouched.  (Two small units only -- the full kernels take minutes; the routing is what is tested.)"""
+    import shutil
+    import subprocess
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc here")
+    N.lib()
+    before = _sha(N.LIB_PATH)
+    out = os.path.join(ROOT, "tools", "micro", "_ab", "test_routing")
+    shutil.rmtree(out, ignore_errors=True)
+    try:
+        r = subprocess.run(["bash", N.BUILD_SCRIPT, "-DFDM_GEMM_STAMPS", "-DFDM_AB_TEST=1"], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, FDM_OUT=out, FDM_BUILD_UNITS="capi"))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        emb, flags = N.embedded_provenance(os.path.join(out, "libfastdm_amd.so"))
+        assert emb == N.current_source_digest()
+        assert "-DFDM_GEMM_STAMPS" in flags and "-DFDM_AB_TEST=1" in flags and "units: capi" in flags
+        assert _sha(N.LIB_PATH) == before and N.embedded_provenance()[1] == ""
+        # and a flagged binary is refused as THE product library (here: the variant's directory declared to be the product's)
+        code = """
+from fastdm_amd import _native as N
+N._PRODUCT_LIB_DIR = N.LIB_DIR
+try:
+    N.lib()
+except N.NativeLibraryError as e:
+    assert "extra flags" in str(e) and "FDM_GEMM_STAMPS" in str(e), str(e)
+    print("REFUSED")
+"""
+        r = _run_native_snippet(code, out)
+        assert r.returncode == 0 and "REFUSED" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def _run_native_snippet(code, lib_dir, **env):
+    import subprocess
+    import sys
+    e = dict(os.environ, FDM_LIB_DIR=str(lib_dir), **env)
+    return subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r})\n" + code], capture_output=True, text=True, timeout=600, env=e)
+
+
+def _stale_copy(tmp_path):
+    """A copy of the product library whose embedded digest has been overwritten (= a binary built from other sources)."""
+    import shutil
+    N.lib()
+    dst = tmp_path / "libfastdm_amd.so"
+    shutil.copy(N.LIB_PATH, dst)
+    blob = dst.read_bytes()
+    marker = b"@(#)fdm_source_digest="
+    at = blob.index(marker) + len(marker)
+    dst.write_bytes(blob[:at] + b"f" * 64 + blob[at + 64:])
+    assert N.embedded_provenance(str(dst))[0] == "f" * 64
+    return dst
+
+
+def test_stale_library_is_rebuilt_before_it_is_loaded(tmp_path):
+    """The loader compares the digest INSIDE the binary with the sources' before dlopen and rebuilds on mismatch.  (The build step is
+    replaced by a recorder that installs the good library: the logic is under test, not the 3-minute compile.)"""
+    _stale_copy(tmp_path)
+    code = f"""
+import shutil, types
+from fastdm_amd import _native as N
+calls = []
+def fake_build():
+    calls.append(1)
+    assert N.embedded_provenance()[0] == "f" * 64          # still the stale file, and it has NOT been loaded
+    shutil.copy({N.LIB_PATH!r}, N.LIB_PATH)
+    return types.SimpleNamespace(returncode=0, stdout="", stderr="")
+N._run_build = fake_build
+h = N.lib()
+assert calls == [1], calls
+assert h.fdm_source_digest().decode() == N.current_source_digest()
+print("REBUILT", N.LIB_PATH)
+"""
+    r = _run_native_snippet(code, tmp_path)
+    assert r.returncode == 0 and "REBUILT" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_stale_library_without_a_compiler_is_refused_not_loaded(tmp_path):
+    _stale_copy(tmp_path)
+    code = """
+from fastdm_amd import _native as N
+try:
+    N.lib()
+except N.NativeLibraryError as e:
+    assert "built from other sources" in str(e) and "ffffffff" in str(e), str(e)
+    print("REFUSED")
+"""
+    for env in ({"HIPCC": "/nonexistent/hipcc"}, {"FDM_NO_REBUILD": "1"}):
+        r = _run_native_snippet(code, tmp_path, **env)
+        assert r.returncode == 0 and "REFUSED" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_bench_line_carries_the_library_identity():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if prov["lib_flags"] and not args.allow_build_flags' in src and '"experimental": True' in src
+    assert "**prov" in src            # lib_digest / lib_flags / lib_path on the JSON line

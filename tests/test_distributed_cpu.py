@@ -207,28 +207,34 @@ def test_bench_stdout_carries_only_the_result_line():
     assert "library banner on fd 1" in res.stderr and "python print" in res.stderr and "late banner" in res.stderr
 
 
-def test_bench_device_state_sampler_parses_rocm_smi_and_stays_off_under_a_profiler(monkeypatch):
-    """bench.py's `device_state`: shader clock / package power from rocm-smi's text; no sample without a clock line; the sampler is
-    not started when a profiler's tool library is in the environment (it would ride into the child processes)."""
+def test_bench_device_state_parses_rocm_smi_and_stays_off_under_a_profiler(monkeypatch):
+    """bench.py's `device_state`: DPM clock / package power from rocm-smi's text; no reading without a clock line; rocm-smi is not
+    forked when a profiler's tool library is in the environment (it would ride into the child process).  Nothing is sampled inside
+    the timed window any more: readings are taken before the warm-up and after the clock has stopped."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
     txt = ("GPU[0]\t\t: mclk clock level: 0: (2000Mhz)\nGPU[0]\t\t: sclk clock level: S: (2243Mhz)\n"
            "GPU[0]\t\t: Current Socket Graphics Package Power (W): 1361.0\n")
-    assert bench.DeviceStateSampler.parse(txt) == (2243, 1361.0)
-    assert bench.DeviceStateSampler.parse("GPU[0]\t\t: sclk clock level: S: (94Mhz)\n") == (94, None)
-    assert bench.DeviceStateSampler.parse("no GPU here") is None
-    s = bench.DeviceStateSampler(0)
-    assert s.summary() is None
-    s.samples = [(2237, 1350.0), (2248, None), (2243, 1361.0)]
+    assert bench.DeviceState.parse(txt) == (2243, 1361.0)
+    assert bench.DeviceState.parse("GPU[0]\t\t: sclk clock level: S: (94Mhz)\n") == (94, None)
+    assert bench.DeviceState.parse("no GPU here") is None
+    s = bench.DeviceState(0)
     out = s.summary()
-    assert out["samples"] == 3 and out["sclk_mhz"] == {"min": 2237, "median": 2243, "max": 2248} and out["package_power_w_median"] == 1361.0
+    assert out["mfma_clock_mhz"] is None and out["rocm_smi"] is None and "inside the timed window" in out["source"]
     monkeypatch.setenv("ROCP_TOOL_LIB", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
-    assert not bench.DeviceStateSampler.usable()
+    assert not bench.DeviceState.smi_usable()
+    s.sample_smi("before")
+    assert s.smi == {}
     monkeypatch.delenv("ROCP_TOOL_LIB")
     monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
-    assert not bench.DeviceStateSampler.usable()
+    assert not bench.DeviceState.smi_usable()
+    # the timed region of main() forks nothing: no subprocess / rocm-smi call between the two perf_counter() reads
+    src = open(os.path.join(root, "bench.py")).read()
+    timed = src[src.index("rec = timing.Recorder()"):src.index("elapsed = time.perf_counter() - t0")]
+    assert "t0 = time.perf_counter()" in timed and "one_step()" in timed
+    assert "subprocess" not in timed and "smi" not in timed and "probe" not in timed
 
 
 # ------------------------------------------------------------------ supervised rank launcher (fastdm_amd/launch.py)
