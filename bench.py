@@ -28,13 +28,26 @@ import torch  # noqa: E402
 
 PEAK_TFLOPS = {"fp8": 5000.0, "bf16": 2500.0, "int8": 5000.0}   # dense MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 IMAGE_STEPS = 25
-# timing-span name -> HIP kernel it launches (the name rocprofv3 reports; profiles/*_summary.txt).  For the GEMM spans this is only the
-# name used for the `roofline` entry when a GEMM span dominates; what each launch really ran is recorded per span ("hip_kernels")
-HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128, false>", "attn_sparse_bf16": "fdm::attn_fwd64_kernel<128, true>",
-              # GEMM spans: the kernel the dispatch policy (gemm.hip use_w4) picks for the default workloads' launches of that span
-              "gemm_w8a8_fp8": "fdm::gemm_w4_kernel<0, false>", "gemm_w8a8_fp8_res": "fdm::gemm_w4_kernel<0, true>",
-              "gemm_w8a8_int8": "fdm::gemm_w4_kernel<1, false>", "gemm_w8a8_int8_res": "fdm::gemm_w4_kernel<1, true>",
-              "gemm_bf16": "fdm::gemm_w4_kernel<2, false>", "gemm_bf16_res": "fdm::gemm_w4_kernel<2, true>"}
+# timing-span name -> HIP kernel it launches (the name rocprofv3 reports; profiles/*_summary.txt)
+HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128, false>", "attn_sparse_bf16": "fdm::attn_fwd64_kernel<128, true>"}
+
+
+def span_kernel(span: str, by_kernel=None) -> str:
+    """rocprofv3 name of the kernel that carried most of a span's time.  GEMM spans are dispatched per launch (gemm.hip use_p4 / use_w4):
+    the name comes from what fdm_gemm_last_kernel() reported for the span's launches (timing.Recorder `by_kernel`), with the template
+    arguments the span implies (data type, gate + residual), never from a static table."""
+    if span in HIP_KERNEL:
+        return HIP_KERNEL[span]
+    if not span.startswith("gemm") or not by_kernel:
+        return span
+    top = max(by_kernel, key=lambda k: by_kernel[k]["total_ms"])
+    dt = 2 if "bf16" in span else (1 if "int8" in span else 0)
+    res = "true" if span.endswith("_res") else "false"
+    if top == "fdm::gemm_p4_kernel":
+        return "fdm::gemm_p4_kernel<0>"            # plain epilogue carries most p4 launches (<1> = tanh-GELU, <2> = erf-GELU)
+    if top in ("fdm::gemm_w4_kernel", "fdm::gemm_kernel"):
+        return f"{top}<{dt}, {res}>"
+    return top
 
 
 def pmc_traffic(kernel):
@@ -311,6 +324,9 @@ def main():
     ap.add_argument("--nhwc", action="store_true", help="sdxl: keep convolution activations channels-last instead of NCHW")
     ap.add_argument("--cfg-pair", action="store_true", help="qwen / wan / sd35 / sdxl with --gpus 2k: ranks (2i, 2i+1) share image i -- one runs the "
                     "conditional, the other the unconditional forward, one all-gather of the noise predictions per step (strong scaling of a step)")
+    ap.add_argument("--images-per-rank", type=int, default=1, help="images each rank (or CFG pair) denoises, one after the other inside every step, as the "
+                    "reference's per-process prompt loop does (examples/evaluation/clip_score.py:346-365); BASELINE.json configs[3] = 8 images on "
+                    "4 CFG pairs: --gpus 8 --cfg-pair --images-per-rank 2.  A step still means one denoise step of EVERY image in flight")
     ap.add_argument("--same-device", action="store_true", help="PROTOCOL TEST ONLY: every rank on cuda:0 over gloo (a 1-GPU box exercising the N-rank "
                     "sharding / CFG-pair exchange / final gather with real HIP forwards); the line says so and is not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -334,6 +350,9 @@ def main():
         sys.exit(spawn_ranks(args.gpus))       # nothing above this line has touched the GPU
     if args.cfg_pair and (args.model == "flux" or args.gpus % 2):
         sys.exit("--cfg-pair needs a two-forward model (qwen / wan / sd35 / sdxl) and an even --gpus")
+    if args.images_per_rank < 1 or (args.images_per_rank > 1 and (args.cache_config or args.graph)):
+        sys.exit("--images-per-rank k > 1 runs the images one after the other through ONE model: a step cache / a captured graph holds the state "
+                 "of one image only (use one process per image for those)")
 
     claim_stdout()
     from fastdm_amd import _native
@@ -397,8 +416,10 @@ def main():
     # rank r denoises image r of the global batch (different latents/prompt per image); under --cfg-pair ranks 2i and 2i+1
     # share image i (fastdm_amd/distributed.py: CFGPair)
     pair = D.make_cfg_pairs(rank, world) if args.cfg_pair else None
-    n_images = world // 2 if pair is not None else world
-    img_rank = rank // 2 if pair is not None else rank
+    K_IMG = args.images_per_rank
+    n_images = (world // 2 if pair is not None else world) * K_IMG
+    my_images = D.images_of_rank(rank, world, K_IMG, cfg_pair=pair is not None)
+    img_rank = my_images[0]
     if pair is not None:
         if args.model in ("qwen", "wan"):
             pipe.cfg_pair = pair
@@ -408,41 +429,56 @@ def main():
         else:
             from fastdm_amd.pipeline import SyntheticSDXLPipeline
             pipe2 = SyntheticSDXLPipeline(model, seed=0, use_graph=args.graph, cfg_pair=pair)
-    if args.model == "sd35":
-        IMAGE_STEPS = 28
-        inp = sd3_step_inputs(2, args.height // 8, args.width // 8, args.max_seq_len, seed=img_rank)      # cond + uncond batched (CFG), as diffusers does
-        n_img = (args.height // 16) * (args.width // 16)
-        lin = np.linspace(1.0, 1.0 / IMAGE_STEPS, IMAGE_STEPS)
-        sig = np.concatenate([3.0 * lin / (1.0 + 2.0 * lin), [0.0]]).astype(np.float32)      # flow-match schedule, shift 3
-    elif args.model == "sdxl":
-        IMAGE_STEPS = 30
-        inp = sdxl_step_inputs(2, args.height // 8, args.width // 8, args.max_seq_len, seed=img_rank)     # cond + uncond batched (CFG), as diffusers does
-        inp["hidden_states"] = inp["sample"]
-        n_img = (args.height // 16) * (args.width // 16)
-        sig = np.concatenate([np.linspace(1.0, 1.0 / IMAGE_STEPS, IMAGE_STEPS), [0.0]]).astype(np.float32)
-    elif args.model == "wan":
-        IMAGE_STEPS = 40
-        inp = pipe.prepare(1, args.height, args.width, args.frames, args.max_seq_len, seed=img_rank)
-        n_img = inp["hidden_states"].shape[2] * (inp["hidden_states"].shape[3] // 2) * (inp["hidden_states"].shape[4] // 2)
-        sig = pipe.sigmas(IMAGE_STEPS)
-    else:
-        inp = pipe.prepare(1, args.height, args.width, args.max_seq_len, seed=img_rank)
-        n_img = inp["hidden_states"].shape[1]
-        sig = flow_match_sigmas(IMAGE_STEPS, n_img) if args.model == "flux" else flow_match_sigmas(IMAGE_STEPS, n_img, max_seq_len=8192, max_shift=0.9)
+    def make_inputs(img_id):
+        global IMAGE_STEPS
+        if args.model == "sd35":
+            IMAGE_STEPS = 28
+            inp = sd3_step_inputs(2, args.height // 8, args.width // 8, args.max_seq_len, seed=img_id)      # cond + uncond batched (CFG), as diffusers does
+            n_img = (args.height // 16) * (args.width // 16)
+            lin = np.linspace(1.0, 1.0 / IMAGE_STEPS, IMAGE_STEPS)
+            sig = np.concatenate([3.0 * lin / (1.0 + 2.0 * lin), [0.0]]).astype(np.float32)      # flow-match schedule, shift 3
+        elif args.model == "sdxl":
+            IMAGE_STEPS = 30
+            inp = sdxl_step_inputs(2, args.height // 8, args.width // 8, args.max_seq_len, seed=img_id)     # cond + uncond batched (CFG), as diffusers does
+            inp["hidden_states"] = inp["sample"]
+            n_img = (args.height // 16) * (args.width // 16)
+            sig = np.concatenate([np.linspace(1.0, 1.0 / IMAGE_STEPS, IMAGE_STEPS), [0.0]]).astype(np.float32)
+        elif args.model == "wan":
+            IMAGE_STEPS = 40
+            inp = pipe.prepare(1, args.height, args.width, args.frames, args.max_seq_len, seed=img_id)
+            n_img = inp["hidden_states"].shape[2] * (inp["hidden_states"].shape[3] // 2) * (inp["hidden_states"].shape[4] // 2)
+            sig = pipe.sigmas(IMAGE_STEPS)
+        else:
+            inp = pipe.prepare(1, args.height, args.width, args.max_seq_len, seed=img_id)
+            n_img = inp["hidden_states"].shape[1]
+            sig = flow_match_sigmas(IMAGE_STEPS, n_img) if args.model == "flux" else flow_match_sigmas(IMAGE_STEPS, n_img, max_seq_len=8192, max_shift=0.9)
+        return inp, n_img, sig
+
+    inps = []
+    for img_id in my_images:
+        inp, n_img, sig = make_inputs(img_id)
+        inps.append(inp)
+    inp = inps[0]
     guidance = torch.full((1,), 3.5, device=dev, dtype=torch.float32)
 
-    state = {"lat": inp["hidden_states"].clone(), "i": 0}
+    states = [{"lat": x["hidden_states"].clone(), "i": 0} for x in inps]
+    state = states[0]
     if args.model == "sdxl":
         from fastdm_amd.graph import GraphedForward
-        unet = lambda lat, t: model(lat, t, inp["encoder_hidden_states"], inp["added_cond_kwargs"])[0]
-        graphed = GraphedForward(unet, inp["hidden_states"], torch.zeros((), device=dev)) if args.graph else None
+        unet = lambda lat, t, ip=inp: model(lat, t, ip["encoder_hidden_states"], ip["added_cond_kwargs"])[0]
+        graphed = GraphedForward(unet, inp["hidden_states"], torch.zeros((), device=dev)) if args.graph else None     # (--graph: one image per rank)
 
-        def sdxl_forward(lat, t):
+        def sdxl_forward(lat, t, ip):
             if graphed is not None:
                 return graphed(lat, torch.tensor(t, device=dev))
-            return unet(lat, torch.tensor(t, device=dev))
+            return unet(lat, torch.tensor(t, device=dev), ip)
 
     def one_step():
+        """one denoise step of every image this rank holds (the images take turns through the one model, as the reference's prompt loop)"""
+        for st, ip in zip(states, inps):
+            one_image_step(st, ip)
+
+    def one_image_step(state, inp):
         i = (state["i"] + args.start_step) % IMAGE_STEPS
         if i == 0:
             state["lat"] = inp["hidden_states"].clone()
@@ -467,7 +503,7 @@ def main():
             return
         if args.model == "sdxl":
             lat = state["lat"]
-            eps = sdxl_forward(lat, float(sig[i]) * 999.0).float()
+            eps = sdxl_forward(lat, float(sig[i]) * 999.0, inp).float()
             noise = eps[1:2] + 5.0 * (eps[0:1] - eps[1:2])
             state["lat"] = (lat.float() + float(sig[i + 1] - sig[i]) * noise).to(torch.bfloat16).expand(2, -1, -1, -1).contiguous()
             state["i"] += 1
@@ -495,12 +531,13 @@ def main():
         for _ in range(args.warmup):
             one_step()
         def gather_final():
-            own = state["lat"][0:1]        # sd35 / sdxl keep the CFG batch-2 copy of the ONE latent this rank owns
+            own = torch.cat([st["lat"][0:1] for st in states], dim=0)        # sd35 / sdxl keep the CFG batch-2 copy of each latent this rank owns
             if pair is not None:
                 return D.gather_pair_latents(own, pair, rank, world)
-            return D.gather_latents(own, world, rank, world)
+            return D.gather_latents(own, n_images, rank, world)
         gather_final()   # RCCL builds its all-gather channels on the first call: not part of a step
-        state["i"] = 0
+        for st in states:
+            st["i"] = 0
         torch.cuda.synchronize()
         D.barrier()
         torch.cuda.synchronize()
@@ -531,18 +568,19 @@ def main():
         D.shutdown()
         return
     ms_per_step = elapsed / args.steps * 1e3
+    IMG_NOTE = "" if K_IMG == 1 else f" x {K_IMG} images in turn per {'CFG pair' if pair is not None else 'GPU'}"
     skipped = 0
     if cache is not None:
         skipped = sum(1 for t in cache.trace[-(args.steps * (2 if args.model == "qwen" else 1)):] if not t[3])
     if args.model == "flux":
         workload = (f"FLUX.1-dev {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step flow-match schedule, "
-                    f"batch 1 per GPU, 19 double + 38 single blocks" + (f", TeaCache (threshold {cache.config.threshold}{' [OVERRIDDEN]' if args.cache_threshold is not None else ''}; {skipped}/{args.steps} steps skipped)" if cache else ""))
+                    f"batch 1 per GPU{IMG_NOTE}, 19 double + 38 single blocks" + (f", TeaCache (threshold {cache.config.threshold}{' [OVERRIDDEN]' if args.cache_threshold is not None else ''}; {skipped}/{args.steps} steps skipped)" if cache else ""))
     elif args.model == "sd35":
         workload = (f"SD3.5-large {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), 28-step schedule, CFG as one batch-2 forward "
-                    f"per step, 38 joint blocks")
+                    f"per step{IMG_NOTE}, 38 joint blocks")
     elif args.model == "sdxl":
         workload = (f"SDXL-base-1.0 UNet {args.quant} {args.height}x{args.width} (latent {args.height // 8}x{args.width // 8}; {n_img} and {n_img // 4} "
-                    f"tokens at the two attention levels, {args.max_seq_len} prompt tokens), 30-step schedule, CFG as one batch-2 forward per step, "
+                    f"tokens at the two attention levels, {args.max_seq_len} prompt tokens), 30-step schedule, CFG as one batch-2 forward per step{IMG_NOTE}, "
                     f"70 transformer layers + 52 MIOpen convolutions")
     elif args.model == "wan":
         hs = inp["hidden_states"].shape
@@ -552,32 +590,33 @@ def main():
                                                      f"dense layers {sp.config.dense_layers}, dense steps {sp.config.dense_steps}; timed steps "
                                                      f"{args.start_step}..{args.start_step + args.steps - 1})")
         workload = (f"Wan2.2-T2V-A14B {args.quant} {args.height}x{args.width}x{args.frames}f (latents {tuple(hs[1:])}, S={n_img}+{args.max_seq_len}), "
-                    f"40-step schedule, CFG (2 forwards per step), batch 1 per GPU, {nl} blocks"
+                    f"40-step schedule, CFG (2 forwards per step), batch 1 per GPU{IMG_NOTE}, {nl} blocks"
                     + ("" if nl == 40 else " [REDUCED DEPTH]") + f", {mode}")
     else:
         nfw = 2 * args.steps
         workload = (f"Qwen-Image {args.quant} {args.height}x{args.width} (S={n_img}+{args.max_seq_len}), {IMAGE_STEPS}-step schedule, true CFG "
-                    f"({'one batch-2 forward' if args.batch_cfg else '2 forwards'} per step), batch 1 per GPU, {args.layers or 60} double-stream blocks"
+                    f"({'one batch-2 forward' if args.batch_cfg else '2 forwards'} per step), batch 1 per GPU{IMG_NOTE}, {args.layers or 60} double-stream blocks"
                     + (" [REDUCED DEPTH]" if args.layers and args.layers != 60 else "")
                     + (f", TeaCache (threshold {cache.config.threshold}{' [OVERRIDDEN]' if args.cache_threshold is not None else ''}{', negative cache' if args.cache_negative else ''}; {skipped}/{nfw} forwards skipped)" if cache else ""))
     out = {
-        # value counts denoise steps of ALL images in flight (n_images = n_gpus, or n_gpus / 2 with --cfg-pair)
-        "metric": {"flux": f"denoise it/s (sec/image = 25 / (value / {n_images})), FLUX 1024x2048 fp8 @25 steps",
-                   "qwen": f"denoise it/s (sec/image = 25 / (value / {n_images})), Qwen-Image 1328x1328 int8 @25 steps, true CFG",
-                   "sd35": f"denoise it/s (sec/image = 28 / (value / {n_images})), SD3.5-large 1024x1024 fp8 @28 steps, CFG",
-                   "sdxl": f"denoise it/s (sec/image = 30 / (value / {n_images})), SDXL-base UNet 1024x1024 fp8 @30 steps, CFG",
-                   "wan": f"denoise it/s (sec/video = 40 / (value / {n_images})), Wan2.2-T2V-A14B 768x1280x81f fp8 @40 steps, CFG"}[args.model],
+        # value counts denoise steps of ALL images in flight (n_images = images-per-rank x n_gpus, or x n_gpus / 2 with --cfg-pair);
+        # sec/image is per image SLOT (a rank or pair works through its images in turn) divided by the images it holds
+        "metric": {"flux": f"denoise it/s (sec/image = 25 / (value / {n_images // K_IMG})), FLUX 1024x2048 fp8 @25 steps",
+                   "qwen": f"denoise it/s (sec/image = 25 / (value / {n_images // K_IMG})), Qwen-Image 1328x1328 int8 @25 steps, true CFG",
+                   "sd35": f"denoise it/s (sec/image = 28 / (value / {n_images // K_IMG})), SD3.5-large 1024x1024 fp8 @28 steps, CFG",
+                   "sdxl": f"denoise it/s (sec/image = 30 / (value / {n_images // K_IMG})), SDXL-base UNet 1024x1024 fp8 @30 steps, CFG",
+                   "wan": f"denoise it/s (sec/video = 40 / (value / {n_images // K_IMG})), Wan2.2-T2V-A14B 768x1280x81f fp8 @40 steps, CFG"}[args.model],
         "value": n_images * args.steps / elapsed,
         "unit": "it/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
-        "sec_per_image": ms_per_step * IMAGE_STEPS / 1e3,
+        "sec_per_image": ms_per_step * IMAGE_STEPS / 1e3 / K_IMG,     # a step advances every image a rank (pair) holds
         "higher_is_better": True,
         "scaling": "strong" if (pair is not None and world == 2) else "weak",
-        "scaling_note": (f"dp{n_images} x cfg2: each image is strong-scaled over a GPU pair (cond / uncond forward), pairs are added weakly"
-                         if pair is not None else f"dp{world}: one image per GPU"),
+        "scaling_note": (f"dp{world // 2} x cfg2 x {K_IMG} image(s) per pair: each image is strong-scaled over a GPU pair (cond / uncond forward), pairs are added weakly"
+                         if pair is not None else f"dp{world}: {K_IMG} image(s) per GPU"),
         "per_rank_ms_per_step": [round(r[0], 3) for r in per_rank],
         "final_allgather_ms": round(max(r[1] for r in per_rank), 3),
         "vs_baseline": None,
@@ -586,9 +625,9 @@ def main():
         "dtype": {"fp8": "fp8_e4m3 W8A8 GEMM (fp32 accumulate) + bf16 attention", "int8": "int8 W8A8 + bf16 attention", "bf16": "bf16"}[args.quant],
         "data": f"synthetic (counter-based random weights of the {ARCH_NAME[args.model]} architecture, synthetic latents/prompt embeddings)",
         "config": {"workload": workload, "global_batch": n_images, "height": args.height, "width": args.width,
-                   "parallelism": (f"dp{n_images} x cfg2 (ranks 2i, 2i+1 run the conditional / unconditional forward of image i; one all-gather of the "
+                   "parallelism": (f"dp{world // 2} x cfg2 x {K_IMG} image(s) per pair (ranks 2i, 2i+1 run the conditional / unconditional forward of image i; one all-gather of the "
                                    f"two noise predictions per step inside the pair, one all-gather of final latents)" if pair is not None else
-                                   f"dp{world} (image-sharded, one all-gather of final latents)"),
+                                   f"dp{world} x {K_IMG} image(s) per GPU (image-sharded, one all-gather of final latents)"),
                    "ranks_in_process_group": D.group_size()},
     }
     if args.same_device:
@@ -607,8 +646,9 @@ def main():
                                                     "achieved_TFLOPs": v["work"] / (v["total_ms"] * 1e-3) / 1e12} for k, v in s["by_kernel"].items()}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         default_workload = (args.model, args.height, args.width, args.max_seq_len, args.quant, args.cache_config) == ("flux", 1024, 2048, 512, "fp8", None)
-        traffic, traffic_src = pmc_traffic(HIP_KERNEL.get(dom, dom)) if default_workload else (None, "not the default workload")
-        out["roofline"] = {"kernel": HIP_KERNEL.get(dom, dom), "span": dom, "bound": "mfma", "achieved": kernels[dom]["achieved_TFLOPs"],
+        dom_kernel = span_kernel(dom, summ[dom].get("by_kernel"))
+        traffic, traffic_src = pmc_traffic(dom_kernel) if default_workload else (None, "not the default workload")
+        out["roofline"] = {"kernel": dom_kernel, "span": dom, "bound": "mfma", "achieved": kernels[dom]["achieved_TFLOPs"],
                            "peak": kernels[dom]["peak_TFLOPs"], "unit": "TFLOP/s", "frac": kernels[dom]["frac"],
                            "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": kernels[dom]["avg_ms"]}
         out["kernels"] = kernels

@@ -906,7 +906,10 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
   const GemmProblem& p = grp.p[prob];
 #ifdef FDM_GEMM_STAMPS
   unsigned long long* stamp = grp.stamps + (size_t)blockIdx.x * 8;
-  if (tid == 0) stamp[0] = __builtin_readcyclecounter();
+  if (tid == 0) {
+    stamp[0] = __builtin_readcyclecounter();
+    stamp[6] = __builtin_amdgcn_s_memrealtime();   // 100 MHz: in-kernel clock = (stamp[3] - stamp[0]) / (stamp[7] - stamp[6]) x 100 MHz
+  }
 #endif
 
   int64_t Kb = p.Kb, k_off = 0;
@@ -1390,7 +1393,10 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
 #ifdef FDM_GEMM_STAMPS
   if (tid == 0) stamp[5] = __builtin_readcyclecounter();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (tid == 0) stamp[3] = __builtin_readcyclecounter();
+  if (tid == 0) {
+    stamp[3] = __builtin_readcyclecounter();
+    stamp[7] = __builtin_amdgcn_s_memrealtime();
+  }
 #endif
 }
 

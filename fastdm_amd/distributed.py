@@ -48,6 +48,20 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
+def images_of_rank(rank: int, world: int, per_rank: int = 1, cfg_pair: bool = False) -> List[int]:
+    """Global image ids a rank denoises when every rank (CFG pair) holds `per_rank` images and works through them in turn, as the
+    reference's per-process prompt loop does (/root/reference/examples/evaluation/clip_score.py:346-365).  Image sharding: rank r owns
+    r, r + world, ... (`shard_indices`, the order `gather_latents` restores).  CFG pairs: ranks 2i and 2i+1 both own
+    i * per_rank ... i * per_rank + per_rank - 1 (the order `gather_pair_latents` returns)."""
+    if per_rank < 1:
+        raise ValueError("per_rank must be >= 1")
+    if cfg_pair:
+        if world % 2:
+            raise ValueError(f"CFG-pair sharding needs an even number of ranks, got {world}")
+        return [(rank // 2) * per_rank + j for j in range(per_rank)]
+    return shard_indices(world * per_rank, rank, world)
+
+
 def gather_latents(local: torch.Tensor, n_items: int, rank: int, world: int) -> torch.Tensor:
     """All-gather per-rank latents [n_local, S, C] into the global batch order [n_items, S, C].
 

@@ -944,6 +944,91 @@ def gen_sdxl_c1(quants=("bf16", "fp8")):
     save("sdxl_c1_512x512_4steps.npz", d)
 
 
+def gen_sdxl_c1_control(quants=("bf16", "fp8")):
+    """CONTROL for BASELINE.json configs[0] (the FLUX `c3_depth` recipe applied to the SDXL UNet): how far apart are two
+    LEGITIMATE implementations of the same network?  For every step of the committed 4-step trajectory (sdxl_c1_512x512_4steps.npz) the
+    reference's own core is run once more from the REFERENCE's latents of the previous step, with
+      * attention = fp32 scores / fp32 softmax (oracle.ops.scaled_dot_product_attention) instead of the bf16 SDPA, and
+      * fp8: the W8A8 products accumulated in float64 instead of the fp32 chunks of `cpu_fp8` (another summation order / width),
+    giving `ceps_<tag>_<i>`; mean|control - ref| per step is the yardstick the GPU test holds mean|HIP - ref| to.  Step 0 also records
+    the seven stage outputs (down 0-2, mid, up 0-2; sub-sampled) of the reference run (`tap_<tag>_ref_*`, re-run here and asserted equal to
+    the committed eps) and of the control (`tap_<tag>_ctl_*`), so a deviation can be located."""
+    reg = import_reference()
+    from oracle import sdxl as OX
+    from oracle import ops as OO
+    from oracle.sdxl import sdxl_block_taps
+    g = load("sdxl_c1_512x512_4steps.npz")
+    cfg = OX.SDXLConfig()
+    seed, steps, hw = int(g["seed"]), int(g["steps"]), int(g["height"])
+    sig, ts = g["sigmas"].float().numpy(), g["timesteps"].numpy()
+    sd = OX.synth_state_dict(cfg, seed=seed)
+    inp = OX.synth_inputs(cfg, batch=2, height=hw, width=hw, n_txt=int(g["n_txt"]), seed=seed)
+    d = {"seed": seed, "steps": steps, "height": hw, "tap_sub": torch.tensor([4, 2, 2])}
+    d.update({f"meta_prov_{k}": str(v) for k, v in provenance().items()})
+    d["meta_control"] = "attention: fp32 scores + fp32 softmax; fp8_matmul: float64 accumulate (bf16 run: attention only)"
+
+    def attn_fp32(query, key, value, num_q_heads, num_kv_heads, head_dim, is_causal=False, scale=None):
+        return OO.scaled_dot_product_attention(query, key, value, num_q_heads, num_kv_heads, head_dim, is_causal=is_causal, scale=scale)
+
+    def fp8_matmul_f64(a, b, scale_a, scale_b, out_dtype, bias=None):
+        outs = []
+        bd = b.to(torch.float64)
+        for s0 in range(0, a.shape[0], 1024):
+            acc = a[s0:s0 + 1024].to(torch.float64) @ bd
+            r = acc.float() * scale_a[s0:s0 + 1024] * scale_b.reshape(1, -1)
+            if bias is not None:
+                r = r + bias.float()
+            outs.append(r.to(out_dtype))
+        return torch.cat(outs, 0)
+
+    def forward(core, i):
+        prev = (inp["sample"][0:1].float() * float(sig[0])).to(torch.bfloat16) if i == 0 else g[f"lat_{tag}_{i - 1}"]
+        x = (prev.float() / ((float(sig[i]) ** 2 + 1.0) ** 0.5)).to(torch.bfloat16)
+        return core.forward(x.expand(2, -1, -1, -1).contiguous(), torch.tensor(float(ts[i])), inp["encoder_hidden_states"], inp["added_cond_kwargs"])[0].float()
+
+    for tag in quants:
+        qt = {"bf16": None, "fp8": torch.float8_e4m3fn}[tag]
+        use_backend("cpu_fp8" if tag == "fp8" else "torch")
+        core = ref_sdxl_core(cfg, qt, sd)
+        # reference, step 0, with taps: must reproduce the committed eps bit for bit (the fixture and this run are the same computation)
+        taps = {}
+        restore = sdxl_block_taps(core, taps)
+        t0 = time.time()
+        eps = forward(core, 0)
+        restore()
+        assert torch.equal(eps.to(torch.bfloat16), g[f"eps_{tag}_0"]), f"re-run of the reference step 0 ({tag}) differs from the committed fixture"
+        print(f"reference SDXL c1 {tag} step 0 re-run with taps: {time.time() - t0:.0f}s (bit-identical to the fixture)", flush=True)
+        for k, v in taps.items():
+            d[f"tap_{tag}_ref_{k}"] = v
+        # control
+        saved_attn = dict(reg._registry["sdpa"])
+        saved_mm = dict(reg._registry["fp8_matmul"])
+        for b in list(reg._registry["sdpa"]):
+            reg._registry["sdpa"][b] = attn_fp32
+        if tag == "fp8":
+            reg._registry["fp8_matmul"]["cpu_fp8"] = fp8_matmul_f64
+        try:
+            for i in range(steps):
+                taps = {}
+                restore = sdxl_block_taps(core, taps) if i == 0 else (lambda: None)
+                t0 = time.time()
+                ceps = forward(core, i)
+                restore()
+                ref = g[f"eps_{tag}_{i}"].float()
+                dd = (ceps.to(torch.bfloat16).float() - ref).abs()
+                print(f"control SDXL c1 {tag} step {i}: {time.time() - t0:.0f}s, |control - ref| max {dd.max():.4f} mean {dd.mean():.5f} on mean|eps| {ref.abs().mean():.3f}", flush=True)
+                d[f"ceps_{tag}_{i}"] = ceps.to(torch.bfloat16)
+                for k, v in taps.items():
+                    d[f"tap_{tag}_ctl_{k}"] = v
+        finally:
+            reg._registry["sdpa"].update(saved_attn)
+            reg._registry["fp8_matmul"].update(saved_mm)
+        del core
+    use_backend("torch")
+    save("sdxl_c1_control.npz", d)
+
+
+
 def gen_sd3_full(seed=0):
     """SD3.5-large WIDTH (38 x 64 heads, D = 2432, text 4096, pooled 2048) at three blocks -- a dual-attention block (as SD3.5-medium
     has), a plain one and the context_pre_only last one -- through the reference's own core, fp8 and bf16, 512 x 512 (1024 image +
@@ -1490,7 +1575,7 @@ def gen_radial_full():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c1", "c3", "c2", "c3_traj", "c3_depth", "teacache_flux", "teacache_qwen", "radial_full", "c3_equal", "c3_equal_single", "wan_ti2v"])
+    ap.add_argument("what", choices=["small", "ops", "layers", "tiny", "teacache", "qwen", "qwen_full", "wan", "fbcache", "dicache", "sd3", "sd3_full", "wan_i2v", "wan_full", "controlnet", "sd3_wan_cache", "sdxl", "sdxl_full", "c1", "c1_control", "c3", "c2", "c3_traj", "c3_depth", "teacache_flux", "teacache_qwen", "radial_full", "c3_equal", "c3_equal_single", "wan_ti2v"])
     ap.add_argument("--blocks", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--quant", nargs="+", default=["fp8", "bf16"])
     ap.add_argument("--steps", type=int, default=4, help="c3_traj: denoise steps of the 25-step schedule")
@@ -1529,6 +1614,8 @@ def main():
         gen_sdxl_full(args.quant)
     if args.what == "c1":
         gen_sdxl_c1()
+    if args.what == "c1_control":
+        gen_sdxl_c1_control()
     if args.what == "qwen_full":
         gen_qwen_full()
     if args.what == "wan_full":

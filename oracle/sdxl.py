@@ -305,3 +305,34 @@ class SDXLCore:
                 x = F.conv2d(x, sd[blk["us"] + ".weight"], sd[blk["us"] + ".bias"], 1, 1)
         x = F.silu(F.group_norm(x, 32, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], eps=1e-5))
         return [F.conv2d(x, sd["conv_out.weight"], sd["conv_out.bias"], 1, 1)]
+
+
+SDXL_TAPS = ("down0", "down1", "down2", "mid", "up0", "up1", "up2")
+
+
+def sdxl_block_taps(core, store, sub=(4, 2, 2)):
+    """Record the (sub-sampled) output of each UNet stage of one forward: down_blocks[0..2], mid_block, up_blocks[0..2] -- the same
+    attribute names in the reference's SDXLUNetModelCore and in fastdm_amd's (tests/test_sdxl_gpu.py uses this function on both).
+    Returns a restore() callable."""
+    saved = []
+
+    def wrap(obj, name):
+        orig = obj.forward
+
+        def fwd(*a, **k):
+            out = orig(*a, **k)
+            t = out[0] if isinstance(out, (tuple, list)) else out
+            store[name] = t.detach()[:, ::sub[0], ::sub[1], ::sub[2]].float().cpu().to(torch.bfloat16).contiguous()
+            return out
+        obj.forward = fwd
+        saved.append((obj, orig))
+    for i in range(3):
+        wrap(core.down_blocks[i], f"down{i}")
+    wrap(core.mid_block, "mid")
+    for i in range(3):
+        wrap(core.up_blocks[i], f"up{i}")
+
+    def restore():
+        for obj, orig in saved:
+            obj.forward = orig
+    return restore

@@ -164,6 +164,66 @@ def test_four_cfg_pairs_world8():
     latents equal the single-process two-forward loop bit for bit for all four images."""
     _run_pairs(8)
 
+def _pair_worker_k(rank, world, port, k, q):
+    """images-per-rank k under CFG pairs: a pair works through its k images in turn INSIDE every step (bench.py --images-per-rank), then one gather."""
+    import numpy as np
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from fastdm_amd import distributed as D
+    from fastdm_amd.pipeline import SyntheticQwenPipeline
+    r, w, _ = D.init_from_env(backend="gloo")
+    pair = D.make_cfg_pairs(r, w)
+    images = D.images_of_rank(r, w, k, cfg_pair=True)
+    assert images == [(r // 2) * k + j for j in range(k)]
+    pipe = SyntheticQwenPipeline(_StubTransformer(), cfg_pair=pair)
+    inps = [_qwen_like_inputs(i) for i in images]
+    lats = [x["hidden_states"].clone() for x in inps]
+    steps = 3
+    sig = np.linspace(1.0, 0.0, steps + 1).astype(np.float32)
+    for i in range(steps):                       # step-major, image-minor: the order of bench.py's one_step()
+        for j in range(k):
+            lats[j] = pipe.step(lats[j], inps[j], sig[i], sig[i + 1], 4.0)
+    full = D.gather_pair_latents(torch.cat(lats, dim=0), pair, r, w)
+    q.put((rank, full.float().tolist()))
+    torch.distributed.destroy_process_group()
+
+
+def test_config4_eight_images_on_four_cfg_pairs_world8():
+    """BASELINE.json configs[3]: batch = 8 over 8 GPUs = 4 CFG pairs x 2 images each (`bench.py --gpus 8 --cfg-pair --images-per-rank 2`).
+    Every rank ends with all 8 latents in image order, bit-identical to eight single-process two-forward loops."""
+    world, k = 8, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pair_worker_k, args=(r, world, port, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from fastdm_amd.pipeline import SyntheticQwenPipeline
+    want = torch.cat([_qwen_denoise(SyntheticQwenPipeline(_StubTransformer()), i) for i in range(world // 2 * k)], dim=0).float().tolist()
+    for rank, full in res:
+        assert len(full) == 8 and full == want, f"rank {rank}: 8-image CFG-pair batch differs from the single-process loops"
+
+
+def test_images_of_rank_covers_every_image_once():
+    from fastdm_amd import distributed as D
+    import pytest
+    for world, k in ((1, 1), (1, 3), (8, 1), (8, 2), (4, 5)):
+        owned = sorted(i for r in range(world) for i in D.images_of_rank(r, world, k))
+        assert owned == list(range(world * k))
+        for r in range(world):      # the order gather_latents restores
+            assert D.images_of_rank(r, world, k) == D.shard_indices(world * k, r, world)
+    for world, k in ((2, 1), (8, 2), (4, 3)):
+        for r in range(world):
+            assert D.images_of_rank(r, world, k, cfg_pair=True) == D.images_of_rank(r ^ 1, world, k, cfg_pair=True)      # both members of a pair
+        assert sorted(i for r in range(0, world, 2) for i in D.images_of_rank(r, world, k, cfg_pair=True)) == list(range(world // 2 * k))
+    with pytest.raises(ValueError):
+        D.images_of_rank(0, 3, 1, cfg_pair=True)
+    with pytest.raises(ValueError):
+        D.images_of_rank(0, 2, 0)
+
 
 def test_cfg_pair_guards():
     import pytest
@@ -354,3 +414,16 @@ def test_quantized_cache_of_an_older_format_is_reported_as_stale(tmp_path):
     core = BaseModelCore()
     with pytest.raises(ValueError, match="stale cache format"):
         core.weight_loading(None, quantized_cache=str(f))
+
+
+def test_bench_names_the_gemm_kernel_from_the_recorded_launches():
+    """The `roofline.kernel` of a GEMM span is what fdm_gemm_last_kernel() reported for its launches, not a static table."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    by = {"fdm::gemm_p4_kernel": {"launches": 76, "total_ms": 17.0, "work": 1.0}, "fdm::gemm_w4_kernel": {"launches": 38, "total_ms": 11.6, "work": 1.0}}
+    assert bench.span_kernel("gemm_w8a8_fp8", by) == "fdm::gemm_p4_kernel<0>"
+    assert bench.span_kernel("gemm_w8a8_fp8_res", {"fdm::gemm_w4_kernel": by["fdm::gemm_w4_kernel"]}) == "fdm::gemm_w4_kernel<0, true>"
+    assert bench.span_kernel("gemm_w8a8_int8", {"fdm::gemm_w4_kernel": by["fdm::gemm_w4_kernel"]}) == "fdm::gemm_w4_kernel<1, false>"
+    assert bench.span_kernel("gemm_bf16_res", {"fdm::gemm_kernel": by["fdm::gemm_w4_kernel"]}) == "fdm::gemm_kernel<2, true>"
+    assert bench.span_kernel("attn_fwd_bf16") == "fdm::attn_fwd64_kernel<128, false>"

@@ -124,6 +124,57 @@ def test_baseline_config1_sdxl_512x512_four_steps_against_reference(tag, qt):
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
+# measured (gpurun_out/sdxl_c1_control_<tag>.txt) + 10 %: mean|HIP - ref| / mean|control - ref| per step, where control = the reference's own
+# classes with an fp32-softmax attention (and, fp8, a float64 W8A8 accumulate): the distance between two legitimate implementations
+SDXL_C1_RATIO_LIMIT = {"bf16": (1.5, 1.5, 1.5, 1.5), "fp8": (1.5, 1.5, 1.5, 1.5)}
+
+
+@pytest.mark.parametrize("tag,qt", [("bf16", None), ("fp8", FP8)])
+def test_baseline_config1_sdxl_against_the_two_implementation_control(tag, qt):
+    """BASELINE.json configs[0] with a yardstick.  `python -m oracle.make_golden c1_control` ran the reference's core
+    once more per step from the reference's own latents with an fp32-softmax attention (fp8: plus a float64 accumulate) -- `ceps_*`.  The HIP
+    path, fed the same latents, must stay within SDXL_C1_RATIO_LIMIT x mean|control - ref| of the reference at every step, and the seven UNet
+    stage outputs of the step-0 forward (down 0-2, mid, up 0-2) are compared the same way so that a deviation can be LOCATED: a block that
+    sticks out shows as a ratio jump between two consecutive stages."""
+    from fastdm_amd.model_entry import create_model
+    from fastdm_amd.pipeline import SyntheticSDXLPipeline
+    from fastdm_amd.synthetic import SyntheticSDXLStateDict, sdxl_step_inputs
+    for path in ("sdxl_c1_512x512_4steps.npz", "sdxl_c1_control.npz"):
+        if not os.path.exists(os.path.join(GOLD, path)):
+            pytest.skip(f"{path} not generated")
+    g, c = load("sdxl_c1_512x512_4steps.npz"), load("sdxl_c1_control.npz")
+    seed, steps, hw = int(g["seed"]), int(g["steps"]), int(g["height"])
+    assert int(c["seed"]) == seed and int(c["steps"]) == steps
+    model = create_model("sdxl", ckpt_path=SyntheticSDXLStateDict(seed=seed), dtype=BF16, quant_type=qt, kernel_backend="hip").eval()
+    pipe = SyntheticSDXLPipeline(model, seed=seed)
+    ts, sig = pipe.schedule(steps)
+    inp = sdxl_step_inputs(2, hw, hw, int(g["n_txt"]), seed=seed)
+    sub = tuple(int(x) for x in c["tap_sub"])
+    lines, ratios = [], []
+    for i in range(steps):
+        prev = (inp["sample"][0:1].float() * float(sig[0])).to(BF16) if i == 0 else g[f"lat_{tag}_{i - 1}"].cuda()
+        x = (prev.float() / ((float(sig[i]) ** 2 + 1.0) ** 0.5)).to(BF16)
+        taps = {}
+        restore = OX.sdxl_block_taps(model.core_model, taps, sub) if i == 0 else (lambda: None)
+        eps = model(x.expand(2, -1, -1, -1).contiguous(), torch.tensor(float(ts[i])).cuda(), inp["encoder_hidden_states"], inp["added_cond_kwargs"])[0]
+        restore()
+        ref = g[f"eps_{tag}_{i}"].float()
+        d_hip = (eps.float().cpu() - ref).abs().mean().item()
+        d_ctl = (c[f"ceps_{tag}_{i}"].float() - ref).abs().mean().item()
+        ratios.append(d_hip / d_ctl)
+        lines.append(f"SDXL 512x512 {tag} step {i}: mean|HIP - ref| {d_hip:.5f}  mean|control - ref| {d_ctl:.5f}  ratio {ratios[-1]:.3f}  (mean|eps| {ref.abs().mean().item():.3f})")
+        if i == 0:
+            for name in OX.SDXL_TAPS:
+                r = c[f"tap_{tag}_ref_{name}"].float()
+                th, tc = (taps[name].float() - r).abs().mean().item(), (c[f"tap_{tag}_ctl_{name}"].float() - r).abs().mean().item()
+                lines.append(f"    step 0 stage {name:5s}: mean|HIP - ref| {th:.5f}  mean|control - ref| {tc:.5f}  ratio {th / tc:.3f}  (mean|ref| {r.abs().mean().item():.3f})")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/sdxl_c1_control_{tag}.txt", "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    for i, r in enumerate(ratios):
+        assert r <= SDXL_C1_RATIO_LIMIT[tag][i], lines
+
 
 def test_sdxl_blocks_keep_reference_signatures_and_errors():
     from fastdm_amd.layer.unetblock import Attention_SDXL, BasicTransformerBlock, FeedForward_SDXL

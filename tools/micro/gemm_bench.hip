@@ -260,13 +260,14 @@ int main(int argc, char** argv) {
 #ifdef FDM_GEMM_AB
       const int stride = fdm::g_gemm_use_w4 ? 8 : 4;
 #else
-      const int stride = 4;
+      const int stride = getenv("GEMM_OLD") ? 4 : 8;
 #endif
       for (int b : {0, 100, 255, 256, 700}) {
         unsigned long long* q = &st[(size_t)b * stride];
         if (q[3] == 0) continue;
         printf("   block %4d: start +%llu  prologue %llu  main %llu  epilogue(+drain) %llu", b, q[0] - st[0], q[1] - q[0], q[2] - q[1], q[3] - q[2]);
         if (stride == 8 && q[4]) printf("  [pass 1 %llu, store issue %llu, drain %llu]", q[4] - q[2], q[5] - q[4], q[3] - q[5]);
+        if (stride == 8 && q[7] > q[6]) printf("  clock %.0f MHz", (double)(q[3] - q[0]) / (double)(q[7] - q[6]) * 100.0);
         printf("\n");
       }
       hipMemset(fdm::g_gemm_stamps, 0, 2048 * 8 * 8);
