@@ -26,10 +26,13 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_TFLOPS = {"fp8": 5000.0, "bf16": 2500.0, "int8": 5000.0}   # dense MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"fp8": 5000.0, "bf16": 2500.0, "int8": 5000.0,   # dense MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+               # --attn-pv-fp8: half of the attention flops (QK^T) at the bf16 rate, half (P.V) at the fp8 rate: 1 / (0.5 / 2500 + 0.5 / 5000)
+               "bf16qk+fp8pv": 3333.3}
 IMAGE_STEPS = 25
 # timing-span name -> HIP kernel it launches (the name rocprofv3 reports; profiles/*_summary.txt)
-HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128, false>", "attn_sparse_bf16": "fdm::attn_fwd64_kernel<128, true>"}
+HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128, false>", "attn_sparse_bf16": "fdm::attn_fwd64_kernel<128, true>",
+              "attn_fwd_pvfp8": "fdm::attn_fwd64_pv8_kernel<128, false>"}
 
 
 def span_kernel(span: str, by_kernel=None) -> str:
@@ -327,6 +330,9 @@ def main():
     ap.add_argument("--images-per-rank", type=int, default=1, help="images each rank (or CFG pair) denoises, one after the other inside every step, as the "
                     "reference's per-process prompt loop does (examples/evaluation/clip_score.py:346-365); BASELINE.json configs[3] = 8 images on "
                     "4 CFG pairs: --gpus 8 --cfg-pair --images-per-rank 2.  A step still means one denoise step of EVERY image in flight")
+    ap.add_argument("--attn-pv-fp8", action="store_true", help="OPT-IN variant, reported beside -- never instead of -- the headline: dense head_dim-128 "
+                    "attention with e4m3 P and V on the fp8 matrix cores (fdm_attn_fwd_pvfp8: the reference's SageAttention class); the line "
+                    "carries \"variant\": \"attn_pv_fp8\" and says so in dtype / workload")
     ap.add_argument("--same-device", action="store_true", help="PROTOCOL TEST ONLY: every rank on cuda:0 over gloo (a 1-GPU box exercising the N-rank "
                     "sharding / CFG-pair exchange / final gather with real HIP forwards); the line says so and is not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -355,6 +361,11 @@ def main():
                  "of one image only (use one process per image for those)")
 
     claim_stdout()
+    if args.attn_pv_fp8:
+        from fastdm_amd.kernel.utils import set_attention_pv_fp8
+        set_attention_pv_fp8(True)
+    elif os.environ.get("FDM_ATT_PV_FP8", "0") not in ("", "0"):
+        sys.exit("bench.py: FDM_ATT_PV_FP8 is set: ask for the quantised-attention variant with --attn-pv-fp8 (the default line is the bf16 headline)")
     from fastdm_amd import _native
     prov = _native.provenance()          # what the LOADED binary says it was built from (fdm_source_digest / fdm_build_flags)
     if prov["lib_flags"] and not args.allow_build_flags:
@@ -622,7 +633,9 @@ def main():
         "vs_baseline": None,
         **prov, **({"experimental": True} if prov["lib_flags"] else {}),
         "device_state": smi.summary() if smi else None,
-        "dtype": {"fp8": "fp8_e4m3 W8A8 GEMM (fp32 accumulate) + bf16 attention", "int8": "int8 W8A8 + bf16 attention", "bf16": "bf16"}[args.quant],
+        "dtype": {"fp8": "fp8_e4m3 W8A8 GEMM (fp32 accumulate) + bf16 attention", "int8": "int8 W8A8 + bf16 attention", "bf16": "bf16"}[args.quant]
+                 + (" -> OPT-IN: bf16 QK^T + e4m3 P.V attention on head_dim-128 dense calls (fdm_attn_fwd_pvfp8)" if args.attn_pv_fp8 else ""),
+        **({"variant": "attn_pv_fp8 (quantised attention, the reference's SageAttention class; NOT the headline arithmetic)"} if args.attn_pv_fp8 else {}),
         "data": f"synthetic (counter-based random weights of the {ARCH_NAME[args.model]} architecture, synthetic latents/prompt embeddings)",
         "config": {"workload": workload, "global_batch": n_images, "height": args.height, "width": args.width,
                    "parallelism": (f"dp{world // 2} x cfg2 x {K_IMG} image(s) per pair (ranks 2i, 2i+1 run the conditional / unconditional forward of image i; one all-gather of the "
@@ -637,7 +650,7 @@ def main():
         summ = rec.summary()
         kernels = {}
         for name, s in summ.items():
-            dt = "bf16" if "bf16" in name else ("int8" if "int8" in name else "fp8")
+            dt = "bf16qk+fp8pv" if "pvfp8" in name else ("bf16" if "bf16" in name else ("int8" if "int8" in name else "fp8"))
             tf = s["work"] / (s["total_ms"] * 1e-3) / 1e12
             kernels[name] = {"launches_per_step": s["launches"] / args.steps, "avg_ms": s["avg_ms"], "ms_per_step": s["total_ms"] / args.steps,
                              "achieved_TFLOPs": tf, "peak_TFLOPs": PEAK_TFLOPS[dt], "frac": tf / PEAK_TFLOPS[dt]}

@@ -41,6 +41,8 @@ SIGNATURES = {
     "fdm_linear_skinny_bf16": (I32, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, P]),
     "fdm_attn_fwd": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I32, I32, P, I64, P]),
     "fdm_attn_fwd_workspace_bytes": (I64, [I32]),
+    "fdm_attn_pvfp8_workspace_bytes": (I64, [I64, I64, I32, I32]),
+    "fdm_attn_fwd_pvfp8": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I64, P, I64, P]),
     "fdm_ln_modulate": (I32, [P, P, P, P, I32, P, P, P, I64, P, P, P, I64, I32, I64, F32, I32, P]),
     "fdm_ln_modulate_f32": (I32, [P, P, P, P, I32, P, P, P, I64, I64, I32, I64, F32, P]),
     "fdm_gate_residual": (I32, [P, P, P, P, I64, I64, I32, I64, P]),
@@ -57,7 +59,7 @@ SIGNATURES = {
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
 }
 
-ABI_VERSION = 12         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
+ABI_VERSION = 13         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL, EPI_GATE_RESIDUAL_F32 = 0, 1, 2, 3, 4
 
 
@@ -236,6 +238,24 @@ def attn_workspace(device, head_dim):
         nbytes = int(lib().fdm_attn_fwd_workspace_bytes(head_dim))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _attn_ws[key] = ws
+    return ws
+
+
+_attn_vq_ws = {}
+
+
+def attn_pvfp8_workspace(device, batch, sk, kv_heads, head_dim):
+    """Per-(device, stream) buffer for fdm_attn_fwd_pvfp8's e4m3 V image (rewritten by every call; grows to the largest shape seen)."""
+    import torch
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev, int(torch.cuda.current_stream(dev).cuda_stream))
+    need = int(lib().fdm_attn_pvfp8_workspace_bytes(batch, sk, kv_heads, head_dim))
+    ws = _attn_vq_ws.get(key)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("fastdm_amd: the fp8 P.V attention workspace of this stream must be allocated before graph capture")
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _attn_vq_ws[key] = ws
     return ws
 
 

@@ -10,6 +10,7 @@ from typing import Optional, Tuple
 import torch
 
 from fastdm_amd import _native as N
+from fastdm_amd.kernel.utils import attention_pv_fp8
 
 BF16 = torch.bfloat16
 FP8 = torch.float8_e4m3fn
@@ -152,6 +153,12 @@ def _attn(query, key, value, num_q_heads, num_kv_heads, head_dim, is_causal, sca
         scale = head_dim ** -0.5
     out = torch.empty((B, Sq, num_q_heads * head_dim), device=query.device, dtype=query.dtype)
     ws = N.attn_workspace(query.device, head_dim)
+    if mask is None and head_dim == 128 and attention_pv_fp8():      # opt-in: the reference's SageAttention class (kernel/utils.py)
+        vq = N.attn_pvfp8_workspace(query.device, B, Sk, num_kv_heads, head_dim)
+        N.check(N.lib().fdm_attn_fwd_pvfp8(N.ptr(out), N.ptr(query), N.ptr(key), N.ptr(value), B, Sq, Sk, num_q_heads, num_kv_heads,
+                                           head_dim, query.stride(1), key.stride(1), value.stride(1), out.stride(1), float(scale),
+                                           N.ptr(ws), ws.numel(), N.ptr(vq), vq.numel(), N.stream()), "scaled_dot_product_attention (fp8 P.V)")
+        return out
     N.check(N.lib().fdm_attn_fwd(N.ptr(out), N.ptr(query), N.ptr(key), N.ptr(value), B, Sq, Sk, num_q_heads, num_kv_heads,
                                  head_dim, query.stride(1), key.stride(1), value.stride(1), out.stride(1), float(scale),
                                  N.ptr(mask), bq, bk, N.ptr(ws), ws.numel(), N.stream()), "scaled_dot_product_attention")

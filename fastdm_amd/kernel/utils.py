@@ -39,3 +39,21 @@ def benchmark_kernel(op_name: str, impl_func: Callable, iterations: int = 50, *a
 def kernel_output_assert_close(actual: torch.Tensor, expected: torch.Tensor, rtol: Optional[float] = None,
                                atol: Optional[float] = None) -> None:
     torch.testing.assert_close(actual, expected.to(actual.dtype), rtol=rtol, atol=atol)
+
+
+# ---- opt-in quantised attention -----------------------------------------------------------------------------------------------
+# The reference's CUDA backend PREFERS SageAttention (int8 QK^T / fp8 P.V) whenever it is importable
+# (/root/reference/fastdm/kernel/cuda/attention.py:20,35-75); its torch backend -- the pinned parity oracle -- is bf16 SDPA, which
+# is what this package computes by default.  `FDM_ATT_PV_FP8=1` (or set_attention_pv_fp8(True)) switches dense head_dim-128
+# attention calls to fdm_attn_fwd_pvfp8 (e4m3 P and V on the fp8 matrix cores); everything else (head_dim 64, block-sparse) keeps
+# the bf16 kernels.  The switch lives on the host side: the library itself reads no environment variable.
+_pv_fp8 = os.environ.get("FDM_ATT_PV_FP8", "0") not in ("", "0")
+
+
+def set_attention_pv_fp8(on: bool) -> None:
+    global _pv_fp8
+    _pv_fp8 = bool(on)
+
+
+def attention_pv_fp8() -> bool:
+    return _pv_fp8

@@ -44,7 +44,7 @@ const char* fdm_last_hip_error_string(void);
 
 /* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
  * refuse to run instead of passing arguments at the wrong positions. */
-#define FDM_ABI_VERSION 12
+#define FDM_ABI_VERSION 13
 int fdm_abi_version(void);
 
 /* Provenance the binary carries itself (no stamp file beside it): the content digest (64 hex digits) of every source the
@@ -219,6 +219,26 @@ int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v,
  * items would fill less than half the chip, those items are split along KV and merged (split-KV tail
  * balancing).  Returns the number of bytes that is always sufficient for the given head_dim.                 */
 int64_t fdm_attn_fwd_workspace_bytes(int head_dim);
+
+/* OPT-IN quantised attention: the same dense softmax(q k^T * scale) v with the P.V product on the fp8 matrix cores
+ * (v_mfma_f32_32x32x64_f8f6f4) -- the class of the reference's preferred CUDA path, SageAttention (int8 QK^T / fp8 P.V:
+ * /root/reference/fastdm/kernel/cuda/attention.py:20,35-75), which its published numbers were taken with.  Never the default:
+ * fdm_attn_fwd is the reference TORCH backend's bf16 arithmetic and stays the headline.  What is quantised: P = exp2(s - ref) to
+ * e4m3 (row reference kept so that 8 <= P_max < 2^7.7), V per (batch, kv head, channel) to e4m3 with scale absmax / 448 (a
+ * pre-pass of this call writes the image into vq_workspace); scale * log2(e) is folded into Q with one more bf16 rounding.  QK^T,
+ * the softmax state and the row sums (fp32, of the unrounded P -- as SageAttention's) are those of fdm_attn_fwd.  Error against an
+ * fp64 softmax on N(0, 1) inputs: mean 5e-4 / max 3e-3 at S = 8704, mean 1.5e-3 / max 1e-2 at S = 1000 (the reference's own
+ * tolerance for its kernels: atol 1.8e-2, tests/test_attention.py:66-100); a row dominated by ONE key inherits that key's V rounding
+ * (up to 6 % of |v|).  head_dim 128, no block mask (FDM_ERR_UNSUPPORTED otherwise).
+ * vq_workspace: 16-byte aligned, >= fdm_attn_pvfp8_workspace_bytes(batch, sk, kv_heads, head_dim) bytes, owned by the caller,
+ * rewritten by every call (reusable by consecutive calls on ONE stream).  workspace: as fdm_attn_fwd.                            */
+int64_t fdm_attn_pvfp8_workspace_bytes(int64_t batch, int64_t sk, int kv_heads, int head_dim);
+int fdm_attn_fwd_pvfp8(void* o, const void* q, const void* k, const void* v,
+                       int64_t batch, int64_t sq, int64_t sk, int q_heads, int kv_heads, int head_dim,
+                       int64_t q_tok_stride, int64_t k_tok_stride, int64_t v_tok_stride,
+                       int64_t o_tok_stride, float scale,
+                       void* workspace, int64_t workspace_bytes, void* vq_workspace, int64_t vq_workspace_bytes,
+                       fdm_stream_t stream);
 
 /* ================= fused kernels used by the FLUX block wiring (no reference export) ========== */
 

@@ -167,7 +167,7 @@ def test_baseline_config1_sdxl_against_the_two_implementation_control(tag, qt):
             for name in OX.SDXL_TAPS:
                 r = c[f"tap_{tag}_ref_{name}"].float()
                 th, tc = (taps[name].float() - r).abs().mean().item(), (c[f"tap_{tag}_ctl_{name}"].float() - r).abs().mean().item()
-                lines.append(f"    step 0 stage {name:5s}: mean|HIP - ref| {th:.5f}  mean|control - ref| {tc:.5f}  ratio {th / tc:.3f}  (mean|ref| {r.abs().mean().item():.3f})")
+                lines.append(f"    step 0 stage {name:5s}: mean|HIP - ref| {th:.5f}  mean|control - ref| {tc:.5f}  ratio {(f'{th / tc:.3f}' if tc > 0 else 'n/a (this stage has no attention / W8A8 linear: control = ref)')}  (mean|ref| {r.abs().mean().item():.3f})")
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/sdxl_c1_control_{tag}.txt", "w") as f:
         f.write("\n".join(lines) + "\n")

@@ -24,16 +24,33 @@ int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "one")) shapes = {{1, 8704, 8704, 24, 128, 0}};
   if (check) shapes = {{1, 8704, 8704, 24, 128, 0}, {1, 8704, 8704, 24, 128, 1}, {1, 1000, 1000, 8, 128, 0}, {2, 300, 300, 3, 128, 1}, {1, 50, 50, 2, 128, 0},
                        {1, 777, 2100, 5, 128, 1}, {1, 4608, 512, 24, 128, 0}, {1, 64, 64, 1, 128, 0}, {1, 257, 129, 2, 128, 1}, {2, 1111, 1111, 8, 64, 0}};
+  if (getenv("ATTN_SHAPES")) {      // "B,Sq,Sk,H,D,spike;..."
+    shapes.clear();
+    const char* c = getenv("ATTN_SHAPES");
+    while (*c) {
+      long v6[6]; int n = 0;
+      while (n < 6) { v6[n++] = strtol(c, (char**)&c, 10); if (*c == ',') ++c; }
+      shapes.push_back({v6[0], v6[1], v6[2], v6[3], v6[4], (int)v6[5]});
+      if (*c == ';') ++c;
+    }
+  }
   const int64_t maxe = 8704 * 24 * 128 * 2;
   uint16_t *q, *k, *v, *o; void* ws;
   hipMalloc(&q, maxe * 2); hipMalloc(&k, maxe * 2); hipMalloc(&v, maxe * 2); hipMalloc(&o, maxe * 2);
   const int64_t wsb = fdm_attn_fwd_workspace_bytes(128);
   hipMalloc(&ws, wsb);
+  // ATTN_PV8=1: the opt-in fp8 P.V entry point (head_dim-128 shapes only; the others run the default kernel)
+  const bool pv8 = getenv("ATTN_PV8") && atoi(getenv("ATTN_PV8")) != 0;
+  void* vqws = nullptr;
+  const int64_t vqb = fdm_attn_pvfp8_workspace_bytes(2, 8704, 24, 128);
+  if (pv8) hipMalloc(&vqws, vqb);
   std::vector<uint16_t> hq(maxe), hk(maxe), hv(maxe), ho(maxe);
   for (auto* hbuf : {&hq, &hk, &hv}) for (auto& e : *hbuf) e = f2b(nrand());
+  if (getenv("ATTN_VCONST")) for (auto& e : hv) e = f2b(1.0f);          // O must be sum(P^) / sum(P): isolates the P side
+  if (getenv("ATTN_QZERO")) for (auto& e : hq) e = 0;                     // uniform P (a power of two: exact in e4m3): isolates the V side
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   int bad = 0;
-  for (int rep = 0; rep < (check ? 1 : 2); ++rep)
+  for (int rep = 0; rep < (check ? (getenv("ATTN_TWICE") ? 2 : 1) : 2); ++rep)
   for (auto& s : shapes) {
     const int64_t C = s.H * s.D;
     std::vector<uint16_t> kq(hk.begin(), hk.begin() + s.B * s.Sk * C);
@@ -47,6 +64,8 @@ int main(int argc, char** argv) {
     hipMemcpy(v, hv.data(), s.B * s.Sk * C * 2, hipMemcpyHostToDevice);
     hipMemset(o, 0xff, s.B * s.Sq * C * 2);
     auto run = [&]() {
+      if (pv8 && s.D == 128)
+        return fdm_attn_fwd_pvfp8(o, q, k, v, s.B, s.Sq, s.Sk, (int)s.H, (int)s.H, (int)s.D, C, C, C, C, 1.0f / sqrtf((float)s.D), ws, wsb, vqws, vqb, nullptr);
       return fdm_attn_fwd(o, q, k, v, s.B, s.Sq, s.Sk, (int)s.H, (int)s.H, (int)s.D, C, C, C, C, 1.0f / sqrtf((float)s.D), nullptr, 0, 0, ws, wsb, nullptr);
     };
     for (int i = 0; i < (check ? 1 : 3); ++i) if (run() != 0) { printf("launch failed\n"); return 1; }
@@ -61,7 +80,7 @@ int main(int argc, char** argv) {
       hipEventElapsedTime(&ms, e0, e1);
       ms /= iters;
     }
-    double maxerr = 0, sumerr = 0; int64_t nchk = 0, nan = 0;
+    double maxerr = 0, sumerr = 0; int64_t nchk = 0, nan = 0; int64_t worst_r = -1, worst_d = -1, worst_h = -1; double err_db[4] = {0, 0, 0, 0};
     if (check || rep == 1) {
       hipMemcpy(ho.data(), o, s.B * s.Sq * C * 2, hipMemcpyDeviceToHost);
       std::vector<int64_t> rows = {0, 1, 31, 32, 63, 64, 255, 256, s.Sq / 2, s.Sq - 1, s.Sq - 2, s.Sq - 33, s.Sq - 65, s.Sq - 257, s.Sq / 3, 5 * s.Sq / 7};
@@ -79,15 +98,26 @@ int main(int argc, char** argv) {
         for (int d = 0; d < s.D; ++d) {
           double a = 0; for (int64_t j = 0; j < s.Sk; ++j) a += sc[j] * b2f(hv[(b * s.Sk + j) * C + hh * s.D + d]);
           const float got = b2f(ho[(b * s.Sq + r) * C + hh * s.D + d]);
-          if (!(got == got)) { ++nan; continue; }
-          const double err = fabs(a / l - got); maxerr = fmax(maxerr, err); sumerr += err; ++nchk;
+          if (!(got == got)) { if (getenv("ATTN_VERBOSE") && nan < 4) printf("    NaN at b %ld head %ld row %ld d %d\n", (long)b, (long)hh, (long)r, d); ++nan; continue; }
+          const double err = fabs(a / l - got); if (err > maxerr) { worst_r = r; worst_d = d; worst_h = hh; } maxerr = fmax(maxerr, err); sumerr += err; ++nchk;
+          err_db[d / 32] += err;
         }
       }
       if (nan || maxerr > 1.8e-2) ++bad;
     }
-    printf("attn B=%ld Sq=%ld Sk=%ld H=%ld hd=%ld spike=%d: %8.1f us %8.1f TF/s  max|err| %.3e mean %.3e nan %ld (%ld values)%s\n", (long)s.B, (long)s.Sq,
+    printf("%sattn B=%ld Sq=%ld Sk=%ld H=%ld hd=%ld spike=%d: %8.1f us %8.1f TF/s  max|err| %.3e mean %.3e nan %ld (%ld values)%s\n", (pv8 && s.D == 128) ? "[fp8 P.V] " : "", (long)s.B, (long)s.Sq,
            (long)s.Sk, (long)s.H, (long)s.D, s.spike, ms * 1e3, ms > 0 ? 4.0 * s.B * s.Sq * s.Sk * s.H * s.D / (ms * 1e-3) / 1e12 : 0.0, maxerr,
            nchk ? sumerr / nchk : 0.0, (long)nan, (long)nchk, (nan || maxerr > 1.8e-2) ? "  <-- FAIL" : "");
+    if (getenv("ATTN_DUMP")) {
+      for (int64_t r : {(int64_t)0, (int64_t)1, (int64_t)31, (int64_t)32, (int64_t)33, (int64_t)63, (int64_t)64, (int64_t)200, s.Sq - 1}) {
+        if (r >= s.Sq) continue;
+        printf("    row %5ld:", (long)r);
+        for (int d : {0, 1, 4, 8, 31, 32, 64, 96, 100, 123, 127}) printf(" d%d=%.4f", d, b2f(ho[(0 * s.Sq + r) * C + 0 * s.D + d]));
+        printf("\n");
+      }
+    }
+    if (getenv("ATTN_VERBOSE") && nchk) printf("    worst at row %ld head %ld d %ld; mean err by d block: %.2e %.2e %.2e %.2e\n", (long)worst_r, (long)worst_h, (long)worst_d,
+                                               err_db[0] * 4 / nchk, err_db[1] * 4 / nchk, err_db[2] * 4 / nchk, err_db[3] * 4 / nchk);
   }
 #ifdef FDM_ATT_STAMPS
   {   // cycle shares of the LAST launch (S = 4096 hd 64 does not run the stamped kernel: run with a single hd-128 shape last)
