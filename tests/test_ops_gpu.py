@@ -646,7 +646,9 @@ def test_attention_pv_fp8_peaked_rows_spikes_and_the_cross_half_maximum(K):
         others = [r for r in range(0, Sq, max(1, Sq // 16)) if r != row]
         ref, hsel = _attn_ref_rows(q, k, v, torch.tensor(others), [0, 1], hd)
         e = (got[:, others][:, :, hsel].float() - ref.float()).abs()
-        assert e.max().item() <= 0.12 and e.mean().item() <= 0.3 * Sk ** -0.5, (Sk, e.max().item(), e.mean().item())
+        # (the spiked key has 3 x the norm of an ordinary one: it dominates some of the OTHER rows too, which then inherit the rounding of
+        # its V row -- up to 2^-4 of |v| <= 4.5)
+        assert e.max().item() <= 0.3 and e.mean().item() <= 0.3 * Sk ** -0.5, (Sk, e.max().item(), e.mean().item())
 
 
 def test_attention_pv_fp8_split_kv_parts_ragged_tails_and_strides(K):

@@ -100,8 +100,16 @@ def test_baseline_config1_sdxl_512x512_four_steps_against_reference(tag, qt):
     inp = sdxl_step_inputs(2, hw, hw, int(g["n_txt"]), seed=seed)
     lat = (inp["sample"][0:1].float() * float(sig[0])).to(BF16)
     lines = []
-    lim_eps = {"bf16": (1.5e-1, 1.5e-2), "fp8": (5e-1, 5e-2)}[tag]
+    # per-forward limits: the two-implementation control (sdxl_c1_control.npz, see SDXL_C1_RATIO_LIMIT below) x the measured ratio + 10 %
+    # -- mean 0.0091 / 0.043 at step 0 instead of the 0.015 / 0.05 guessed in round 4; the free-running bound
+    # below propagates the same number
+    c = load("sdxl_c1_control.npz") if os.path.exists(os.path.join(GOLD, "sdxl_c1_control.npz")) else None
     for i in range(steps):
+        if c is not None:
+            ce = (c[f"ceps_{tag}_{i}"].float() - g[f"eps_{tag}_{i}"].float()).abs()
+            lim_eps = (2.0 * ce.max().item(), SDXL_C1_RATIO_LIMIT[tag][i] * ce.mean().item())
+        else:
+            lim_eps = {"bf16": (1.5e-1, 1.5e-2), "fp8": (5e-1, 5e-2)}[tag]
         # (a) one forward from the reference's own latents
         prev = (inp["sample"][0:1].float() * float(sig[0])).to(BF16) if i == 0 else g[f"lat_{tag}_{i - 1}"].cuda()
         x = (prev.float() / ((float(sig[i]) ** 2 + 1.0) ** 0.5)).to(BF16)
@@ -118,7 +126,8 @@ def test_baseline_config1_sdxl_512x512_four_steps_against_reference(tag, qt):
         # (first order, g = 5: 6.4 x; sigma runs 14.6 -> 0 over the 4 steps), so the free-running limit is that propagation of the
         # per-forward limit over the sigma already travelled -- a gross-error bound, the per-forward check above is the sharp one
         travelled = float(sig[0] - sig[i + 1])
-        assert dl.mean() <= 6.4 * lim_eps[1] * travelled, lines[-1] + f" (limit {6.4 * lim_eps[1] * travelled:.3f})"
+        lim_traj = max(lim_traj, lim_eps[1]) if i else lim_eps[1]        # the largest per-forward limit so far (step 0's: errors shrink with sigma)
+        assert dl.mean() <= 6.4 * lim_traj * travelled, lines[-1] + f" (limit {6.4 * lim_traj * travelled:.3f})"
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/sdxl_c1_parity_{tag}.txt", "w") as f:
         f.write("\n".join(lines) + "\n")
@@ -126,7 +135,12 @@ def test_baseline_config1_sdxl_512x512_four_steps_against_reference(tag, qt):
 
 # measured (gpurun_out/sdxl_c1_control_<tag>.txt) + 10 %: mean|HIP - ref| / mean|control - ref| per step, where control = the reference's own
 # classes with an fp32-softmax attention (and, fp8, a float64 W8A8 accumulate): the distance between two legitimate implementations
-SDXL_C1_RATIO_LIMIT = {"bf16": (1.5, 1.5, 1.5, 1.5), "fp8": (1.5, 1.5, 1.5, 1.5)}
+# measured (profiles/r05_sdxl_c1_control_*.txt): bf16 1.152 1.298 1.447 1.483, fp8 1.072 1.061 1.115 1.180.  What is left above 1.0 is located by
+# the stage taps: down0 -- resnets only: MIOpen convolution / group norm against the CPU's, a difference the control does not contain
+# (its convolutions ARE the reference's) -- already carries mean 0.0073 on mean|ref| 1.01 while control = ref there; from down1 on the
+# stage ratios fall from 1.66 / 1.17 to 1.2 / 1.01-1.05 (bf16 / fp8): no transformer stage sticks out.  In the later, less noisy steps that
+# constant convolution floor weighs more against a shrinking |control - ref| (bf16 ratio 1.15 -> 1.48 while |HIP - ref| falls 0.0083 -> 0.0034).
+SDXL_C1_RATIO_LIMIT = {"bf16": (1.27, 1.43, 1.59, 1.63), "fp8": (1.18, 1.17, 1.23, 1.30)}
 
 
 @pytest.mark.parametrize("tag,qt", [("bf16", None), ("fp8", FP8)])
