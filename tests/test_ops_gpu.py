@@ -699,7 +699,9 @@ def test_attention_pv_fp8_is_opt_in_and_refuses_what_it_does_not_cover(K):
     args = lambda heads, d, vqn: (N.ptr(out), N.ptr(q), N.ptr(k), N.ptr(v), 1, 384, 384, heads, heads, d, q.stride(1), k.stride(1), v.stride(1),
                                   out.stride(1), d ** -0.5, N.ptr(ws), ws.numel(), N.ptr(vq), vqn, N.stream())
     assert N.lib().fdm_attn_fwd_pvfp8(*args(2 * H, 64, vq.numel())) == -2                      # FDM_ERR_UNSUPPORTED: head_dim 64
-    assert N.lib().fdm_attn_fwd_pvfp8(*args(H, hd, vq.numel() // 2)) == -1                     # FDM_ERR_INVALID: workspace too small
+    need = int(N.lib().fdm_attn_pvfp8_workspace_bytes(1, 384, H, hd))
+    assert N.lib().fdm_attn_fwd_pvfp8(*args(H, hd, need - 1)) == -1                            # FDM_ERR_INVALID: workspace too small
+    assert N.lib().fdm_attn_fwd_pvfp8(*args(H, hd, need)) == 0
     assert N.lib().fdm_attn_pvfp8_workspace_bytes(1, 384, H, 64) == 0
     assert N.lib().fdm_attn_pvfp8_workspace_bytes(1, 384, H, 128) == H * (6 * 64 * 128 + 1024)
 
