@@ -66,6 +66,15 @@ class _AdaLNBase:
             return self._cached_mod
         return self.linear.forward(F.silu(emb))
 
+    def _plain_scale(self, folded: torch.Tensor, emb: torch.Tensor, idx: int) -> torch.Tensor:
+        """The `scale` chunk a reference-signature forward() RETURNS (the caller applies x * (1 + scale) itself, flux.py / sd35.py).  Inside a
+        ModulationTable(fold_one=True) step the cached chunk holds bf16(1 + scale): handing that out would add the 1 twice, and
+        subtracting it again is not the same bits -- so the layer's own projection is evaluated for this one chunk (an M = 1 GEMV; the only
+        in-step caller is the TeaCache probe of block 0)."""
+        if not self.scale_has_one:
+            return folded
+        return self.linear.forward(F.silu(emb)).chunk(self.chunks, dim=1)[idx]
+
     def _apply(self, x, scale, shift):
         B, S, D = x.shape
         y, _, _ = fused.ln_modulate(x.reshape(B * S, D), scale, shift, S, quant=None, eps=self.norm_eps, scale_has_one=self.scale_has_one)
@@ -78,10 +87,8 @@ class AdaLayerNormZero(_AdaLNBase):
     scale_chunks = (1, 4)
 
     def forward(self, x, emb=None):
-        # NB inside a ModulationTable(fold_one=True) step `scale_mlp` is returned as bf16(1 + scale_mlp) (`self.scale_has_one`); the only
-        # in-step caller of this reference-signature method is the TeaCache probe, which takes element [0]
         shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.modulation(emb).chunk(6, dim=1)
-        return self._apply(x, scale_msa, shift_msa), gate_msa, shift_mlp, scale_mlp, gate_mlp
+        return self._apply(x, scale_msa, shift_msa), gate_msa, shift_mlp, self._plain_scale(scale_mlp, emb, 4), gate_mlp
 
 
 class SD35AdaLayerNormZeroX(_AdaLNBase):
@@ -97,7 +104,7 @@ class SD35AdaLayerNormZeroX(_AdaLNBase):
 
     def forward(self, hidden_states, emb=None):
         shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp, shift_msa2, scale_msa2, gate_msa2 = self.modulation(emb).chunk(9, dim=1)
-        return (self._apply(hidden_states, scale_msa, shift_msa), gate_msa, shift_mlp, scale_mlp, gate_mlp,
+        return (self._apply(hidden_states, scale_msa, shift_msa), gate_msa, shift_mlp, self._plain_scale(scale_mlp, emb, 4), gate_mlp,
                 self._apply(hidden_states, scale_msa2, shift_msa2), gate_msa2)
 
 

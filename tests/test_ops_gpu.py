@@ -326,6 +326,40 @@ def test_matmul_full_matrix_at_c3_shape(K, dt):
         ref = (a.float() @ w.float().t() + bias.float()).to(BF16)
         ulp_close(out.cpu(), ref, 0.03, "bf16 full matrix")
 
+@pytest.mark.parametrize("M,Kd,Nn,epi", [(8192, 3072, 12288, "tanh"),      # FLUX double-block ff1: persistent assembly kernel, tanh-GELU drain
+                                         (8704, 3072, 12288, "erf"),       # FLUX single-block proj_mlp: gemm_w4_kernel<fp8, false>, erf-GELU
+                                         (8704, 15360, 3072, "res"),       # FLUX single-block proj_out: gemm_w4_kernel<fp8, true>, 120 K steps, 408 tiles
+                                         (8192, 3072, 3072, "res")])       # FLUX double-block to_out
+def test_fp8_gemm_fused_epilogues_full_matrix(K, M, Kd, Nn, epi):
+    """EVERY element of the fused-epilogue launches of a FLUX step against the oracle's unfused chain (the GELU and
+    gate + residual epilogues had sampled-row and 128-row comparisons only): y = bf16(acc sa sb + bias), then
+    bf16(gelu(y)) / bf16(res + bf16(gate * y)) -- layer/activations.py:38-41, model/flux.py:61,153-154.  <= 1 bf16 ulp of the activation
+    (2 of the product + 1 of the sum for gate + residual, which cancels)."""
+    from fastdm_amd import _native as N
+    g = gen(M + 3 * Kd + 7 * Nn)
+    a = torch.randn(M, Kd, generator=g).to(FP8)
+    b = torch.randn(Nn, Kd, generator=g).to(FP8)                       # [N, K] = the [K, N] weight with stride(0) == 1
+    sa, sb = torch.rand(M, 1, generator=g) * 0.02 + 0.01, torch.rand(Nn, 1, generator=g) * 0.02 + 0.01
+    bias = rbf(g, Nn)
+    gate, res = rbf(g, 1, Nn), rbf(g, M, Nn)
+    e = {"tanh": N.EPI_GELU_TANH, "erf": N.EPI_GELU_ERF, "res": N.EPI_GATE_RESIDUAL}[epi]
+    out = torch.empty(M, Nn, dtype=BF16, device="cuda")
+    ad, bd, sad, sbd, biasd, gd, rd = (t.cuda() for t in (a, b, sa, sb, bias, gate, res))
+    N.check(N.lib().fdm_gemm_w8a8_fp8(N.ptr(out), N.ptr(ad), N.ptr(bd), N.ptr(sad), N.ptr(sbd), N.ptr(biasd), M, Nn, Kd, Kd, Kd, Nn, e,
+                                      N.ptr(gd), Nn, N.ptr(rd), M, N.stream()), "fp8 gemm + epilogue")
+    kern = int(N.lib().fdm_gemm_last_kernel())
+    assert kern == (2 if epi == "tanh" else 1), kern                   # persistent assembly for tanh-GELU, gemm_w4_kernel for the others
+    got = out.cpu()
+    for r0 in range(0, M, 2176):                                       # the oracle in row chunks (memory)
+        y = O.fp8_matmul(a[r0:r0 + 2176], b.t(), sa[r0:r0 + 2176], sb, BF16, bias)
+        if epi == "tanh":
+            want = torch.nn.functional.gelu(y.float(), approximate="tanh").to(BF16)
+        elif epi == "erf":
+            want = torch.nn.functional.gelu(y.float()).to(BF16)
+        else:
+            want = (res[r0:r0 + 2176].float() + (gate.float() * y.float()).to(BF16).float()).to(BF16)
+        ulp_close(got[r0:r0 + 2176], want, 0.05, f"fp8 {M}x{Kd}x{Nn} + {epi} rows {r0}..", ulps=3 if epi == "res" else 2)
+
 
 @pytest.mark.parametrize("M,Kd,Nn", MM_SHAPES[::3] + [[130, 16, 16], [257, 48, 272]] + RAGGED_M_SHAPES)
 def test_int8_matmul_reference_shapes(K, M, Kd, Nn):
