@@ -357,8 +357,16 @@ def test_fp8_gemm_fused_epilogues_full_matrix(K, M, Kd, Nn, epi):
         elif epi == "erf":
             want = torch.nn.functional.gelu(y.float()).to(BF16)
         else:
-            want = (res[r0:r0 + 2176].float() + (gate.float() * y.float()).to(BF16).float()).to(BF16)
-        ulp_close(got[r0:r0 + 2176], want, 0.05, f"fp8 {M}x{Kd}x{Nn} + {epi} rows {r0}..", ulps=3 if epi == "res" else 2)
+            gy = (gate.float() * y.float()).to(BF16).float()
+            want = (res[r0:r0 + 2176].float() + gy).to(BF16)
+            # the sum cancels: a 1-ulp difference of y (fp32 summation order inside the MFMA) is 2 ulp of the product gate * y, however small
+            # the sum comes out -- bound the difference by the product's ulps + one rounding of the result
+            d = (got[r0:r0 + 2176].float() - want.float()).abs()
+            tol = 2.1 * 2.0 ** -7 * gy.abs() + 1.05 * 2.0 ** -7 * want.float().abs() + 2.0 ** -9 * gy.abs().mean()
+            assert (d <= tol).all(), f"fp8 {M}x{Kd}x{Nn} + res rows {r0}..: {int((d > tol).sum())} elements beyond 2 ulp of the product + 1 of the sum, max {d.max().item()}"
+            assert (d > 0).float().mean().item() <= 0.05
+            continue
+        ulp_close(got[r0:r0 + 2176], want, 0.05, f"fp8 {M}x{Kd}x{Nn} + {epi} rows {r0}..", ulps=2)
 
 
 @pytest.mark.parametrize("M,Kd,Nn", MM_SHAPES[::3] + [[130, 16, 16], [257, 48, 272]] + RAGGED_M_SHAPES)
