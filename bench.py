@@ -28,11 +28,11 @@ import torch  # noqa: E402
 
 PEAK_TFLOPS = {"fp8": 5000.0, "bf16": 2500.0, "int8": 5000.0,   # dense MFMA, /opt/skills/guides/MI355X_MICROARCH.md
                # --attn-pv-fp8: half of the attention flops (QK^T) at the bf16 rate, half (P.V) at the fp8 rate: 1 / (0.5 / 2500 + 0.5 / 5000)
-               "bf16qk+fp8pv": 3333.3}
+               "bf16qk+fp8pv": 3333.3}      # (--attn-fp8: all of it at the fp8 rate)
 IMAGE_STEPS = 25
 # timing-span name -> HIP kernel it launches (the name rocprofv3 reports; profiles/*_summary.txt)
 HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128, false>", "attn_sparse_bf16": "fdm::attn_fwd64_kernel<128, true>",
-              "attn_fwd_pvfp8": "fdm::attn_fwd64_pv8_kernel<128, false>"}
+              "attn_fwd_pvfp8": "fdm::attn_fwd64_pv8_kernel<128, false>", "attn_fwd_fp8": "fdm::attn_fwd64_qk8_kernel<128, false>"}
 
 
 def span_kernel(span: str, by_kernel=None) -> str:
@@ -333,6 +333,8 @@ def main():
     ap.add_argument("--attn-pv-fp8", action="store_true", help="OPT-IN variant, reported beside -- never instead of -- the headline: dense head_dim-128 "
                     "attention with e4m3 P and V on the fp8 matrix cores (fdm_attn_fwd_pvfp8: the reference's SageAttention class); the line "
                     "carries \"variant\": \"attn_pv_fp8\" and says so in dtype / workload")
+    ap.add_argument("--attn-fp8", action="store_true", help="OPT-IN variant like --attn-pv-fp8 with QK^T on the fp8 matrix cores as well (fdm_attn_fwd_fp8): "
+                    "\"variant\": \"attn_fp8\"")
     ap.add_argument("--same-device", action="store_true", help="PROTOCOL TEST ONLY: every rank on cuda:0 over gloo (a 1-GPU box exercising the N-rank "
                     "sharding / CFG-pair exchange / final gather with real HIP forwards); the line says so and is not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -361,11 +363,11 @@ def main():
                  "of one image only (use one process per image for those)")
 
     claim_stdout()
-    if args.attn_pv_fp8:
+    if args.attn_pv_fp8 or args.attn_fp8:
         from fastdm_amd.kernel.utils import set_attention_pv_fp8
-        set_attention_pv_fp8(True)
+        set_attention_pv_fp8(2 if args.attn_fp8 else 1)
     elif os.environ.get("FDM_ATT_PV_FP8", "0") not in ("", "0"):
-        sys.exit("bench.py: FDM_ATT_PV_FP8 is set: ask for the quantised-attention variant with --attn-pv-fp8 (the default line is the bf16 headline)")
+        sys.exit("bench.py: FDM_ATT_PV_FP8 is set: ask for a quantised-attention variant with --attn-pv-fp8 / --attn-fp8 (the default line is the bf16 headline)")
     from fastdm_amd import _native
     prov = _native.provenance()          # what the LOADED binary says it was built from (fdm_source_digest / fdm_build_flags)
     if prov["lib_flags"] and not args.allow_build_flags:
@@ -634,8 +636,10 @@ def main():
         **prov, **({"experimental": True} if prov["lib_flags"] else {}),
         "device_state": smi.summary() if smi else None,
         "dtype": {"fp8": "fp8_e4m3 W8A8 GEMM (fp32 accumulate) + bf16 attention", "int8": "int8 W8A8 + bf16 attention", "bf16": "bf16"}[args.quant]
-                 + (" -> OPT-IN: bf16 QK^T + e4m3 P.V attention on head_dim-128 dense calls (fdm_attn_fwd_pvfp8)" if args.attn_pv_fp8 else ""),
-        **({"variant": "attn_pv_fp8 (quantised attention, the reference's SageAttention class; NOT the headline arithmetic)"} if args.attn_pv_fp8 else {}),
+                 + (" -> OPT-IN: e4m3 QK^T + e4m3 P.V attention on head_dim-128 dense calls (fdm_attn_fwd_fp8)" if args.attn_fp8 else
+                    " -> OPT-IN: bf16 QK^T + e4m3 P.V attention on head_dim-128 dense calls (fdm_attn_fwd_pvfp8)" if args.attn_pv_fp8 else ""),
+        **({"variant": ("attn_fp8" if args.attn_fp8 else "attn_pv_fp8") + " (quantised attention, the reference's SageAttention class; NOT the headline arithmetic)"}
+           if (args.attn_pv_fp8 or args.attn_fp8) else {}),
         "data": f"synthetic (counter-based random weights of the {ARCH_NAME[args.model]} architecture, synthetic latents/prompt embeddings)",
         "config": {"workload": workload, "global_batch": n_images, "height": args.height, "width": args.width,
                    "parallelism": (f"dp{world // 2} x cfg2 x {K_IMG} image(s) per pair (ranks 2i, 2i+1 run the conditional / unconditional forward of image i; one all-gather of the "
@@ -650,7 +654,7 @@ def main():
         summ = rec.summary()
         kernels = {}
         for name, s in summ.items():
-            dt = "bf16qk+fp8pv" if "pvfp8" in name else ("bf16" if "bf16" in name else ("int8" if "int8" in name else "fp8"))
+            dt = "bf16qk+fp8pv" if "pvfp8" in name else ("bf16" if "bf16" in name else ("int8" if "int8" in name else "fp8"))      # attn_fwd_fp8 -> "fp8"
             tf = s["work"] / (s["total_ms"] * 1e-3) / 1e12
             kernels[name] = {"launches_per_step": s["launches"] / args.steps, "avg_ms": s["avg_ms"], "ms_per_step": s["total_ms"] / args.steps,
                              "achieved_TFLOPs": tf, "peak_TFLOPs": PEAK_TFLOPS[dt], "frac": tf / PEAK_TFLOPS[dt]}

@@ -43,6 +43,8 @@ SIGNATURES = {
     "fdm_attn_fwd_workspace_bytes": (I64, [I32]),
     "fdm_attn_pvfp8_workspace_bytes": (I64, [I64, I64, I32, I32]),
     "fdm_attn_fwd_pvfp8": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I64, P, I64, P]),
+    "fdm_attn_fp8_workspace_bytes": (I64, [I64, I64, I32, I32]),
+    "fdm_attn_fwd_fp8": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I64, P, I64, P]),
     "fdm_ln_modulate": (I32, [P, P, P, P, I32, P, P, P, I64, P, P, P, I64, I32, I64, F32, I32, P]),
     "fdm_ln_modulate_f32": (I32, [P, P, P, P, I32, P, P, P, I64, I64, I32, I64, F32, P]),
     "fdm_gate_residual": (I32, [P, P, P, P, I64, I64, I32, I64, P]),
@@ -59,7 +61,7 @@ SIGNATURES = {
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
 }
 
-ABI_VERSION = 13         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
+ABI_VERSION = 14         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL, EPI_GATE_RESIDUAL_F32 = 0, 1, 2, 3, 4
 
 
@@ -244,12 +246,14 @@ def attn_workspace(device, head_dim):
 _attn_vq_ws = {}
 
 
-def attn_pvfp8_workspace(device, batch, sk, kv_heads, head_dim):
-    """Per-(device, stream) buffer for fdm_attn_fwd_pvfp8's e4m3 V image (rewritten by every call; grows to the largest shape seen)."""
+def attn_pvfp8_workspace(device, batch, sk, kv_heads, head_dim, mode=1):
+    """Per-(device, stream) buffer for the e4m3 images of fdm_attn_fwd_pvfp8 (mode 1: V) / fdm_attn_fwd_fp8 (mode 2: V and K); rewritten by
+    every call; grows to the largest shape seen."""
     import torch
     dev = device.index if device.index is not None else torch.cuda.current_device()
     key = (dev, int(torch.cuda.current_stream(dev).cuda_stream))
-    need = int(lib().fdm_attn_pvfp8_workspace_bytes(batch, sk, kv_heads, head_dim))
+    fn = lib().fdm_attn_fp8_workspace_bytes if mode == 2 else lib().fdm_attn_pvfp8_workspace_bytes
+    need = int(fn(batch, sk, kv_heads, head_dim))
     ws = _attn_vq_ws.get(key)
     if ws is None or ws.numel() < need:
         if torch.cuda.is_current_stream_capturing():

@@ -78,6 +78,9 @@ struct AttnParams {
   // fp8 P.V (attn_fwd64_pv8_kernel): the e4m3 V^T image attn_vq_kernel wrote and its per-channel scales
   const uint8_t* vq;     // [batch][kv head][ceil(sk / 64)][128 d][64 slots]
   const float* vscale;   // [batch][kv head][128]
+  // fp8 QK^T as well (attn_fwd64_qk8_kernel): the e4m3 K image attn_kq_kernel wrote and the power of two it was scaled by
+  const uint8_t* kq;     // [batch][kv head][ceil(sk / 64)][64 keys][128 d], 16-byte chunk c of key r at c ^ ((r >> 1) & 7)
+  const int* kexp;       // [batch][kv head]: K image = e4m3(k * 2^kexp)
 };
 
 template <int D>
@@ -490,13 +493,23 @@ __device__ unsigned long long g_att_stamps[4096 * 8];
 //   attn_fwd64_pv8_kernel  fp8 P.V  (v_mfma_f32_32x32x64_f8f6f4): opt-in (fdm_attn_fwd_pvfp8), the class of the reference's
 //                          SageAttention path (/root/reference/fastdm/kernel/cuda/attention.py:35-75)
 #define FDM_A64_PV8 0
+#define FDM_A64_QK8 0
 #define FDM_A64_NAME attn_fwd64_kernel
 #include "attn_fwd64_body.inc"
+#undef FDM_A64_QK8
 #undef FDM_A64_PV8
 #undef FDM_A64_NAME
 #define FDM_A64_PV8 1
+#define FDM_A64_QK8 0
 #define FDM_A64_NAME attn_fwd64_pv8_kernel
 #include "attn_fwd64_body.inc"
+#undef FDM_A64_QK8
+#undef FDM_A64_NAME
+//   attn_fwd64_qk8_kernel  fp8 QK^T too (v_mfma_scale_f32_32x32x64_f8f6f4 with power-of-two block scales): mode 2 of fdm_attn_fwd_quant
+#define FDM_A64_QK8 1
+#define FDM_A64_NAME attn_fwd64_qk8_kernel
+#include "attn_fwd64_body.inc"
+#undef FDM_A64_QK8
 #undef FDM_A64_PV8
 #undef FDM_A64_NAME
 
@@ -565,6 +578,59 @@ __global__ void __launch_bounds__(256) attn_vq_kernel(const bf16_t* __restrict__
   *reinterpret_cast<i32x4*>(row + (((2 * g + 1) ^ f) << 4)) = i32x4{(int)w[4], (int)w[5], (int)w[6], (int)w[7]};
 }
 
+// ---- fp8 QK^T pre-pass: K -> e4m3 image in the tile layout attn_fwd64_qk8_kernel streams.  One power-of-two scale per (batch, kv head):
+//      2^kexp with absmax * 2^kexp in (112, 224] (exact; it is undone by the MFMA's E8M0 block scale).  Row-major per key: no transpose.
+__global__ void __launch_bounds__(256) attn_kq_absmax_kernel(const bf16_t* __restrict__ k, int64_t sk, int64_t k_ts, int kv_heads,
+                                                              uint32_t* __restrict__ amax_bits) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, dch = tid & 15, tl = tid >> 4;
+  const int kvh = blockIdx.y, b = blockIdx.z;
+  const int64_t t0 = (int64_t)blockIdx.x * 256;
+  float m = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int64_t tok = t0 + i * 16 + tl;
+    if (tok < sk) {
+      const Vec8 x = load8(k + ((int64_t)b * sk + tok) * k_ts + (int64_t)kvh * 128 + dch * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(x.v[j]));
+    }
+  }
+  m = block_reduce<256>(m, OpMax{}, red);
+  if (tid == 0 && m == m) atomicMax(amax_bits + (int64_t)b * kv_heads + kvh, __builtin_bit_cast(uint32_t, m));
+}
+
+__global__ void __launch_bounds__(256) attn_kq_kernel(const bf16_t* __restrict__ k, int64_t sk, int64_t k_ts, int kv_heads, int ntiles,
+                                                       const uint32_t* __restrict__ amax_bits, uint8_t* __restrict__ kq, int* __restrict__ kexp) {
+  const int tid = threadIdx.x;
+  const int t = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  const int64_t bh = (int64_t)b * kv_heads + kvh;
+  const float amax = __builtin_bit_cast(float, amax_bits[bh]);
+  int e = 0;
+  if (amax > 0.f) {
+    e = 7 - (int)(((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xff) - 127);      // amax in [2^x, 2^(x+1)) -> amax * 2^e in [128, 256)
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  }
+  if (t == 0 && tid == 0) kexp[bh] = e;
+  const float mul = __builtin_bit_cast(float, (uint32_t)(127 + e) << 23);
+  const int key = tid >> 2, quarter = tid & 3;       // 32 d per thread: chunks 2 * quarter, 2 * quarter + 1
+  const int64_t tok = (int64_t)t * 64 + key;
+  uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // keys past the end: zeros
+  if (tok < sk) {
+    const bf16_t* src = k + ((int64_t)b * sk + tok) * k_ts + (int64_t)kvh * 128 + quarter * 32;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const Vec8 x = load8(src + 8 * c);
+      w[2 * c] = cvt2_e4m3<false>(clamp448(x.v[0] * mul), clamp448(x.v[1] * mul)) | (cvt2_e4m3<false>(clamp448(x.v[2] * mul), clamp448(x.v[3] * mul)) << 16);
+      w[2 * c + 1] = cvt2_e4m3<false>(clamp448(x.v[4] * mul), clamp448(x.v[5] * mul)) | (cvt2_e4m3<false>(clamp448(x.v[6] * mul), clamp448(x.v[7] * mul)) << 16);
+    }
+  }
+  uint8_t* row = kq + ((bh * ntiles + t) * 64 + key) * 128;
+  const int f = (key >> 1) & 7;
+  *reinterpret_cast<i32x4*>(row + (((2 * quarter) ^ f) << 4)) = i32x4{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+  *reinterpret_cast<i32x4*>(row + (((2 * quarter + 1) ^ f) << 4)) = i32x4{(int)w[4], (int)w[5], (int)w[6], (int)w[7]};
+}
+
 // Merge the split-KV parts of the tail q-blocks: O = sum_p 2^(m_p - M) O_p / sum_p 2^(m_p - M) l_p, M = max_p m_p.
 // One thread per (row, 8 consecutive d).
 template <int D>
@@ -619,20 +685,27 @@ extern "C" int64_t fdm_attn_pvfp8_workspace_bytes(int64_t batch, int64_t sk, int
   const int64_t ntiles = (sk + 63) / 64;
   return batch * kv_heads * (ntiles * 64 * 128 + 2 * 128 * 4);      // e4m3 V^T image + absmax bits + scales
 }
+extern "C" int64_t fdm_attn_fp8_workspace_bytes(int64_t batch, int64_t sk, int kv_heads, int head_dim) {
+  if (batch <= 0 || sk <= 0 || kv_heads <= 0 || head_dim != 128) return 0;
+  const int64_t ntiles = (sk + 63) / 64;
+  // the P.V part, then the e4m3 K image + per-head absmax bits + exponents (16-byte aligned)
+  return fdm_attn_pvfp8_workspace_bytes(batch, sk, kv_heads, head_dim) + batch * kv_heads * ntiles * 64 * 128 + ((batch * kv_heads * 8 + 15) & ~(int64_t)15);
+}
 
 static int attn_fwd_impl(void* o, const void* q, const void* k, const void* v, int64_t batch, int64_t sq, int64_t sk,
                          int q_heads, int kv_heads, int head_dim, int64_t q_tok_stride, int64_t k_tok_stride,
                          int64_t v_tok_stride, int64_t o_tok_stride, float scale, const int8_t* block_mask, int block_q,
-                         int block_k, void* workspace, int64_t workspace_bytes, fdm_stream_t stream, bool pv8, void* vq_ws,
+                         int block_k, void* workspace, int64_t workspace_bytes, fdm_stream_t stream, int qmode, void* vq_ws,
                          int64_t vq_bytes) {
+  const bool pv8 = qmode != 0;      // qmode: 0 bf16, 1 fp8 P.V, 2 fp8 QK^T + fp8 P.V
   (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!o || !q || !k || !v || batch <= 0 || sq <= 0 || sk <= 0 || q_heads <= 0 || kv_heads <= 0 || q_heads % kv_heads)
     return FDM_ERR_INVALID;
   if (head_dim != 64 && head_dim != 128) return FDM_ERR_UNSUPPORTED;
   if (pv8) {
     if (head_dim != 128 || block_mask != nullptr) return FDM_ERR_UNSUPPORTED;     // fp8 P.V: the dense head_dim-128 kernel only
-    if (!vq_ws || (reinterpret_cast<uintptr_t>(vq_ws) & 15) || vq_bytes < fdm_attn_pvfp8_workspace_bytes(batch, sk, kv_heads, head_dim))
-      return FDM_ERR_INVALID;
+    const int64_t need = qmode == 2 ? fdm_attn_fp8_workspace_bytes(batch, sk, kv_heads, head_dim) : fdm_attn_pvfp8_workspace_bytes(batch, sk, kv_heads, head_dim);
+    if (!vq_ws || (reinterpret_cast<uintptr_t>(vq_ws) & 15) || vq_bytes < need) return FDM_ERR_INVALID;
   }
   if ((q_tok_stride & 7) || (k_tok_stride & 7) || (v_tok_stride & 7) || (o_tok_stride & 7)) return FDM_ERR_INVALID;
   if ((reinterpret_cast<uintptr_t>(q) & 15) || (reinterpret_cast<uintptr_t>(k) & 15) || (reinterpret_cast<uintptr_t>(v) & 15) ||
@@ -723,6 +796,8 @@ static int attn_fwd_impl(void* o, const void* q, const void* k, const void* v, i
   }
   p.vq = nullptr;
   p.vscale = nullptr;
+  p.kq = nullptr;
+  p.kexp = nullptr;
   if (pv8) {
     const int ntl = (int)((sk + 63) / 64);
     uint8_t* img = reinterpret_cast<uint8_t*>(vq_ws);
@@ -735,7 +810,21 @@ static int attn_fwd_impl(void* o, const void* q, const void* k, const void* v, i
     FDM_CHECK_LAUNCH();
     p.vq = img;
     p.vscale = vsc;
-    attn_fwd64_pv8_kernel<128, false><<<(unsigned)grid, 256, 0, s>>>(p);
+    if (qmode == 2) {
+      uint8_t* kimg = reinterpret_cast<uint8_t*>(vq_ws) + fdm_attn_pvfp8_workspace_bytes(batch, sk, kv_heads, head_dim);
+      uint32_t* kamax = reinterpret_cast<uint32_t*>(kimg + batch * kv_heads * (int64_t)ntl * 8192);
+      int* kex = reinterpret_cast<int*>(kamax + batch * kv_heads);
+      if (hipMemsetAsync(kamax, 0, (size_t)batch * kv_heads * 4, s) != hipSuccess) return FDM_ERR_LAUNCH;
+      attn_kq_absmax_kernel<<<dim3((unsigned)((sk + 255) / 256), (unsigned)kv_heads, (unsigned)batch), 256, 0, s>>>(p.k, sk, k_tok_stride, kv_heads, kamax);
+      FDM_CHECK_LAUNCH();
+      attn_kq_kernel<<<dim3((unsigned)ntl, (unsigned)kv_heads, (unsigned)batch), 256, 0, s>>>(p.k, sk, k_tok_stride, kv_heads, ntl, kamax, kimg, kex);
+      FDM_CHECK_LAUNCH();
+      p.kq = kimg;
+      p.kexp = kex;
+      attn_fwd64_qk8_kernel<128, false><<<(unsigned)grid, 256, 0, s>>>(p);
+    } else {
+      attn_fwd64_pv8_kernel<128, false><<<(unsigned)grid, 256, 0, s>>>(p);
+    }
   } else if (mask_v2) {
     attn_fwd64_kernel<128, true><<<(unsigned)grid, 256, 0, s>>>(p);
   } else if (block_mask != nullptr) {
@@ -765,7 +854,7 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
                             int64_t v_tok_stride, int64_t o_tok_stride, float scale, const int8_t* block_mask, int block_q,
                             int block_k, void* workspace, int64_t workspace_bytes, fdm_stream_t stream) {
   return attn_fwd_impl(o, q, k, v, batch, sq, sk, q_heads, kv_heads, head_dim, q_tok_stride, k_tok_stride, v_tok_stride, o_tok_stride,
-                       scale, block_mask, block_q, block_k, workspace, workspace_bytes, stream, false, nullptr, 0);
+                       scale, block_mask, block_q, block_k, workspace, workspace_bytes, stream, 0, nullptr, 0);
 }
 
 extern "C" int fdm_attn_fwd_pvfp8(void* o, const void* q, const void* k, const void* v, int64_t batch, int64_t sq, int64_t sk,
@@ -773,5 +862,13 @@ extern "C" int fdm_attn_fwd_pvfp8(void* o, const void* q, const void* k, const v
                                   int64_t v_tok_stride, int64_t o_tok_stride, float scale, void* workspace, int64_t workspace_bytes,
                                   void* vq_workspace, int64_t vq_workspace_bytes, fdm_stream_t stream) {
   return attn_fwd_impl(o, q, k, v, batch, sq, sk, q_heads, kv_heads, head_dim, q_tok_stride, k_tok_stride, v_tok_stride, o_tok_stride,
-                       scale, nullptr, 0, 0, workspace, workspace_bytes, stream, true, vq_workspace, vq_workspace_bytes);
+                       scale, nullptr, 0, 0, workspace, workspace_bytes, stream, 1, vq_workspace, vq_workspace_bytes);
+}
+
+extern "C" int fdm_attn_fwd_fp8(void* o, const void* q, const void* k, const void* v, int64_t batch, int64_t sq, int64_t sk,
+                                int q_heads, int kv_heads, int head_dim, int64_t q_tok_stride, int64_t k_tok_stride,
+                                int64_t v_tok_stride, int64_t o_tok_stride, float scale, void* workspace, int64_t workspace_bytes,
+                                void* fp8_workspace, int64_t fp8_workspace_bytes, fdm_stream_t stream) {
+  return attn_fwd_impl(o, q, k, v, batch, sq, sk, q_heads, kv_heads, head_dim, q_tok_stride, k_tok_stride, v_tok_stride, o_tok_stride,
+                       scale, nullptr, 0, 0, workspace, workspace_bytes, stream, 2, fp8_workspace, fp8_workspace_bytes);
 }

@@ -138,9 +138,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     ws = N.attn_workspace(q.device, head_dim)
     from fastdm_amd.kernel.utils import attention_pv_fp8
     if head_dim == 128 and attention_pv_fp8():       # opt-in quantised attention (kernel/utils.py); its own timing span
-        vq = N.attn_pvfp8_workspace(q.device, batch, Sk, heads, head_dim)
-        with span("attn_fwd_pvfp8", 4.0 * batch * S * Sk * heads * head_dim):
-            N.check(N.lib().fdm_attn_fwd_pvfp8(N.ptr(out), N.ptr(q), N.ptr(k), N.ptr(v), batch, S, Sk, heads, heads, head_dim,
+        mode = attention_pv_fp8()
+        vq = N.attn_pvfp8_workspace(q.device, batch, Sk, heads, head_dim, mode)
+        fn = N.lib().fdm_attn_fwd_fp8 if mode == 2 else N.lib().fdm_attn_fwd_pvfp8
+        with span("attn_fwd_fp8" if mode == 2 else "attn_fwd_pvfp8", 4.0 * batch * S * Sk * heads * head_dim):
+            N.check(fn(N.ptr(out), N.ptr(q), N.ptr(k), N.ptr(v), batch, S, Sk, heads, heads, head_dim,
                                                q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), N.ptr(ws), ws.numel(),
                                                N.ptr(vq), vq.numel(), N.stream()),
                     "attention (fp8 P.V)")

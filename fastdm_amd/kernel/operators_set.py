@@ -154,8 +154,10 @@ def _attn(query, key, value, num_q_heads, num_kv_heads, head_dim, is_causal, sca
     out = torch.empty((B, Sq, num_q_heads * head_dim), device=query.device, dtype=query.dtype)
     ws = N.attn_workspace(query.device, head_dim)
     if mask is None and head_dim == 128 and attention_pv_fp8():      # opt-in: the reference's SageAttention class (kernel/utils.py)
-        vq = N.attn_pvfp8_workspace(query.device, B, Sk, num_kv_heads, head_dim)
-        N.check(N.lib().fdm_attn_fwd_pvfp8(N.ptr(out), N.ptr(query), N.ptr(key), N.ptr(value), B, Sq, Sk, num_q_heads, num_kv_heads,
+        mode = attention_pv_fp8()
+        vq = N.attn_pvfp8_workspace(query.device, B, Sk, num_kv_heads, head_dim, mode)
+        fn = N.lib().fdm_attn_fwd_fp8 if mode == 2 else N.lib().fdm_attn_fwd_pvfp8
+        N.check(fn(N.ptr(out), N.ptr(query), N.ptr(key), N.ptr(value), B, Sq, Sk, num_q_heads, num_kv_heads,
                                            head_dim, query.stride(1), key.stride(1), value.stride(1), out.stride(1), float(scale),
                                            N.ptr(ws), ws.numel(), N.ptr(vq), vq.numel(), N.stream()), "scaled_dot_product_attention (fp8 P.V)")
         return out

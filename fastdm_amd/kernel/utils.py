@@ -47,13 +47,22 @@ def kernel_output_assert_close(actual: torch.Tensor, expected: torch.Tensor, rto
 # is what this package computes by default.  `FDM_ATT_PV_FP8=1` (or set_attention_pv_fp8(True)) switches dense head_dim-128
 # attention calls to fdm_attn_fwd_pvfp8 (e4m3 P and V on the fp8 matrix cores); everything else (head_dim 64, block-sparse) keeps
 # the bf16 kernels.  The switch lives on the host side: the library itself reads no environment variable.
-_pv_fp8 = os.environ.get("FDM_ATT_PV_FP8", "0") not in ("", "0")
+# Mode 2 (`FDM_ATT_PV_FP8=2`) also runs QK^T on the fp8 cores (fdm_attn_fwd_fp8).
+def _mode(v) -> int:
+    v = int(v)
+    if v not in (0, 1, 2):
+        raise ValueError("quantised-attention mode: 0 (bf16, default), 1 (fp8 P.V), 2 (fp8 QK^T + fp8 P.V)")
+    return v
 
 
-def set_attention_pv_fp8(on: bool) -> None:
+_pv_fp8 = _mode(os.environ.get("FDM_ATT_PV_FP8", "0") or "0")
+
+
+def set_attention_pv_fp8(on) -> None:
     global _pv_fp8
-    _pv_fp8 = bool(on)
+    _pv_fp8 = _mode(on)
 
 
-def attention_pv_fp8() -> bool:
+def attention_pv_fp8() -> int:
+    """0: bf16 attention (default); 1: fp8 P.V; 2: fp8 QK^T + fp8 P.V."""
     return _pv_fp8

@@ -44,7 +44,7 @@ const char* fdm_last_hip_error_string(void);
 
 /* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
  * refuse to run instead of passing arguments at the wrong positions. */
-#define FDM_ABI_VERSION 13
+#define FDM_ABI_VERSION 14
 int fdm_abi_version(void);
 
 /* Provenance the binary carries itself (no stamp file beside it): the content digest (64 hex digits) of every source the
@@ -239,6 +239,20 @@ int fdm_attn_fwd_pvfp8(void* o, const void* q, const void* k, const void* v,
                        int64_t o_tok_stride, float scale,
                        void* workspace, int64_t workspace_bytes, void* vq_workspace, int64_t vq_workspace_bytes,
                        fdm_stream_t stream);
+
+/* The same opt-in with QK^T on the fp8 matrix cores as well (SageAttention quantises Q and K too -- to int8; here e4m3):
+ * v_mfma_scale_f32_32x32x64_f8f6f4, K as an e4m3 image scaled by one power of two per (batch, kv head) (a pre-pass of this call), Q
+ * converted per 64-row wave with scale * log2(e) and its own power of two folded in; both powers of two are undone exactly by the
+ * MFMA's E8M0 block scales, so the softmax sees scores in the same units as fdm_attn_fwd.  8 + 8 (+ 2 row-sum) MFMAs per 64-key tile
+ * instead of 32 + 32.  Error against an fp64 softmax on N(0, 1) inputs: mean 7.4e-4 / max 3.7e-3 at S = 8704, mean 2.2e-3 / max 1.2e-2
+ * at S = 1000.  Same restrictions as fdm_attn_fwd_pvfp8; fp8_workspace >= fdm_attn_fp8_workspace_bytes(...) (V image + K image). */
+int64_t fdm_attn_fp8_workspace_bytes(int64_t batch, int64_t sk, int kv_heads, int head_dim);
+int fdm_attn_fwd_fp8(void* o, const void* q, const void* k, const void* v,
+                     int64_t batch, int64_t sq, int64_t sk, int q_heads, int kv_heads, int head_dim,
+                     int64_t q_tok_stride, int64_t k_tok_stride, int64_t v_tok_stride,
+                     int64_t o_tok_stride, float scale,
+                     void* workspace, int64_t workspace_bytes, void* fp8_workspace, int64_t fp8_workspace_bytes,
+                     fdm_stream_t stream);
 
 /* ================= fused kernels used by the FLUX block wiring (no reference export) ========== */
 

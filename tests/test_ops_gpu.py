@@ -618,14 +618,15 @@ def test_attention_reference_shapes(K, B, Sq, Sk, H, hd):
     assert rel <= 1.0e-2, rel                                                         # bf16 P and bf16 output rounding
 
 # ------------------------------------------------------------------ opt-in quantised attention (fdm_attn_fwd_pvfp8; VERDICT r4 missing item 2)
-def _pv8(q, k, v, H, hd, ws=True):
-    """fdm_attn_fwd_pvfp8 through the C ABI on [B, S, H*hd] CUDA tensors."""
+def _pv8(q, k, v, H, hd, ws=True, mode=1):
+    """fdm_attn_fwd_pvfp8 (mode 1) / fdm_attn_fwd_fp8 (mode 2: fp8 QK^T too) through the C ABI on [B, S, H*hd] CUDA tensors."""
     from fastdm_amd import _native as N
     B, Sq, Sk = q.shape[0], q.shape[1], k.shape[1]
     out = torch.empty_like(q)
     w = N.attn_workspace(q.device, hd) if ws else None
-    vq = N.attn_pvfp8_workspace(q.device, B, Sk, H, hd)
-    N.check(N.lib().fdm_attn_fwd_pvfp8(N.ptr(out), N.ptr(q), N.ptr(k), N.ptr(v), B, Sq, Sk, H, H, hd, q.stride(1), k.stride(1), v.stride(1),
+    vq = N.attn_pvfp8_workspace(q.device, B, Sk, H, hd, mode)
+    fn = N.lib().fdm_attn_fwd_fp8 if mode == 2 else N.lib().fdm_attn_fwd_pvfp8
+    N.check(fn(N.ptr(out), N.ptr(q), N.ptr(k), N.ptr(v), B, Sq, Sk, H, H, hd, q.stride(1), k.stride(1), v.stride(1),
                                        out.stride(1), hd ** -0.5, N.ptr(w), w.numel() if ws else 0, N.ptr(vq), vq.numel(), N.stream()), "pvfp8")
     return out
 
@@ -637,30 +638,32 @@ def _attn_ref_rows(q, k, v, rows, heads, hd):
     return ref, hsel
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("B,Sq,Sk,H,hd", [s_ for s_ in ATT_SHAPES if s_[4] == 128] + [(1, 1000, 1000, 8, 128), (2, 700, 2100, 5, 128)])
-def test_attention_pv_fp8_reference_protocol(K, B, Sq, Sk, H, hd):
+def test_attention_pv_fp8_reference_protocol(K, B, Sq, Sk, H, hd, mode):
     """The reference's own accuracy protocol for its CUDA attention kernels (flash / Sage / Sparge): N(0, 1) q, k, v, fp32-softmax
     reference, atol 1.8e-2 (/root/reference/tests/test_attention.py:66-100) -- on its head_dim-128 shapes, FLUX's C3 shape and two ragged
     ones.  Inherent error of e4m3 P and V (CPU emulation of the arithmetic, profiles/r05_experiments.md): mean 0.1 / sqrt(Sk)-ish,
     max ~ 10 x mean; the bf16 kernel's is ~ 20 x smaller, so the test also proves the fp8 kernel ran."""
     g = gen(Sq + Sk + H + 8)
     q, k, v = rbf(g, B, Sq, H * hd), rbf(g, B, Sk, H * hd), rbf(g, B, Sk, H * hd)
-    got = _pv8(q.cuda(), k.cuda(), v.cuda(), H, hd).cpu()
+    got = _pv8(q.cuda(), k.cuda(), v.cuda(), H, hd, mode=mode).cpu()
     assert torch.isfinite(got.float()).all()
     rows = sample_rows(Sq, 24)
     heads = sorted({0, H - 1, H // 2})
     ref, hsel = _attn_ref_rows(q, k, v, rows, heads, hd)
     sub = got[:, rows][:, :, hsel]
     err = (sub.float() - ref.float()).abs()
-    print(f"fp8 P.V attention B={B} Sq={Sq} Sk={Sk} H={H}: max|err| {err.max().item():.4f} mean {err.mean().item():.5f}")
+    print(f"fp8 attention (mode {mode}) B={B} Sq={Sq} Sk={Sk} H={H}: max|err| {err.max().item():.4f} mean {err.mean().item():.5f}")
     torch.testing.assert_close(sub, ref, rtol=0.0, atol=1.8e-2)
-    assert err.mean().item() <= 0.15 * Sk ** -0.5, err.mean().item()
+    assert err.mean().item() <= (0.15 if mode == 1 else 0.2) * Sk ** -0.5, err.mean().item()
     base = K.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5).cpu()
     berr = (base[:, rows][:, :, hsel].float() - ref.float()).abs().mean().item()
     assert err.mean().item() > 3.0 * berr, "the quantised kernel is as exact as the bf16 one: did it run?"
 
 
-def test_attention_pv_fp8_peaked_rows_spikes_and_the_cross_half_maximum(K):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_attention_pv_fp8_peaked_rows_spikes_and_the_cross_half_maximum(K, mode):
     """(a) peaked softmax (q ~ N(0, 16)): a row dominated by few keys inherits their e4m3 roundings -- relative L2 <= 5 % (bf16: 1 %).
     (b) a key that beats every other logit of ONE row by ~34 sigma in the MIDDLE of the sequence: the row reference must move before
     that tile's exp2 (e4m3 has no room for P = 2^50: the conversion gives NaN).  Positions 21 / 22 / 12 of their 64-key tile sit in the
@@ -669,18 +672,18 @@ def test_attention_pv_fp8_peaked_rows_spikes_and_the_cross_half_maximum(K):
     H, hd = 2, 128
     g = gen(4242)
     q, k, v = rbf(g, 1, 1500, H * hd, scale=4.0), rbf(g, 1, 1500, H * hd), rbf(g, 1, 1500, H * hd)
-    got = _pv8(q.cuda(), k.cuda(), v.cuda(), H, hd).cpu()
+    got = _pv8(q.cuda(), k.cuda(), v.cuda(), H, hd, mode=mode).cpu()
     rows = sample_rows(1500, 32)
     ref, hsel = _attn_ref_rows(q, k, v, rows, [0, 1], hd)
     sub = got[:, rows][:, :, hsel]
     rel = ((sub.float() - ref.float()).norm() / ref.float().norm()).item()
-    assert torch.isfinite(got.float()).all() and rel <= 5e-2, rel
+    assert torch.isfinite(got.float()).all() and rel <= (5e-2 if mode == 1 else 1.2e-1), rel      # (mode 2: e4m3 q . k of a peaked softmax: ~5 % per weight)
     for Sk, Sq in ((128, 257), (129, 257), (126, 257), (114, 257), (320, 256), (2100, 777), (8704, 512)):
         g = gen(Sk)
         q, k, v = rbf(g, 1, Sq, H * hd), rbf(g, 1, Sk, H * hd), rbf(g, 1, Sk, H * hd)
         key, row = Sk * 2 // 3, Sq // 2
         k[0, key] = (3.0 * q[0, row].float()).to(BF16)
-        got = _pv8(q.cuda(), k.cuda(), v.cuda(), H, hd).cpu()
+        got = _pv8(q.cuda(), k.cuda(), v.cuda(), H, hd, mode=mode).cpu()
         assert torch.isfinite(got.float()).all(), f"non-finite output with a spiked key at {key} of {Sk} (tile position {key % 64})"
         # the spiked row is (almost) V[key]: within the e4m3 rounding of that row of V (2^-4 relative per element, per-channel scale)
         d = (got[0, row].float() - v[0, key].float()).abs()
@@ -690,10 +693,11 @@ def test_attention_pv_fp8_peaked_rows_spikes_and_the_cross_half_maximum(K):
         e = (got[:, others][:, :, hsel].float() - ref.float()).abs()
         # (the spiked key has 3 x the norm of an ordinary one: it dominates some of the OTHER rows too, which then inherit the rounding of
         # its V row -- up to 2^-4 of |v| <= 4.5)
-        assert e.max().item() <= 0.3 and e.mean().item() <= 0.3 * Sk ** -0.5, (Sk, e.max().item(), e.mean().item())
+        assert e.max().item() <= 0.3 and e.mean().item() <= (0.3 if mode == 1 else 0.45) * Sk ** -0.5, (Sk, e.max().item(), e.mean().item())
 
 
-def test_attention_pv_fp8_split_kv_parts_ragged_tails_and_strides(K):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_attention_pv_fp8_split_kv_parts_ragged_tails_and_strides(K, mode):
     """Split-KV parts (S = 8704: 816 work items, the last 48 split along KV and merged), a ragged last tile, Sk < 64, strided q / k / v
     views (the fused qkv planes of the models): with and without the split workspace the outputs agree within the quantisation noise,
     and the quantised V image of one call never leaks into the next (a smaller call after a larger one on the same workspace)."""
@@ -701,7 +705,7 @@ def test_attention_pv_fp8_split_kv_parts_ragged_tails_and_strides(K):
     H, hd = 24, 128
     g = gen(99)
     q, k, v = (rbf(g, 1, 8704, H * hd).cuda() for _ in range(3))
-    a, b = _pv8(q, k, v, H, hd, ws=True), _pv8(q, k, v, H, hd, ws=False)
+    a, b = _pv8(q, k, v, H, hd, ws=True, mode=mode), _pv8(q, k, v, H, hd, ws=False, mode=mode)
     d = (a.float() - b.float()).abs()
     assert torch.isfinite(a.float()).all() and d.max().item() <= 2e-2 and d.mean().item() <= 1e-4, (d.max().item(), d.mean().item())
     assert not torch.equal(a[:, 7168:, 16 * hd:], b[:, 7168:, 16 * hd:]), "split path did not run"
@@ -709,13 +713,13 @@ def test_attention_pv_fp8_split_kv_parts_ragged_tails_and_strides(K):
         g = gen(Sq * 7 + Sk)
         qkv = rbf(g, 1, max(Sq, Sk), 3 * Hh * hd).cuda()
         qv, kv, vv = qkv[:, :Sq, :Hh * hd], qkv[:, :Sk, Hh * hd:2 * Hh * hd], qkv[:, :Sk, 2 * Hh * hd:]      # strided views of one buffer
-        got = _pv8(qv, kv, vv, Hh, hd)
-        again = _pv8(qv.contiguous(), kv.contiguous(), vv.contiguous(), Hh, hd)
+        got = _pv8(qv, kv, vv, Hh, hd, mode=mode)
+        again = _pv8(qv.contiguous(), kv.contiguous(), vv.contiguous(), Hh, hd, mode=mode)
         assert torch.equal(got, again), "strided and contiguous inputs must give the same bits"
         ref = O.scaled_dot_product_attention(qv.cpu().contiguous(), kv.cpu().contiguous(), vv.cpu().contiguous(), Hh, Hh, hd, scale=hd ** -0.5)
         e = (got.cpu().float() - ref.float()).abs()
         # (Sk = 1: the output IS the one key's e4m3-rounded V row: up to 2^-4 relative per element)
-        lim = (0.12, 0.012) if Sk >= 50 else (0.3, 0.05)
+        lim = ((0.12, 0.012) if mode == 1 else (0.15, 0.016)) if Sk >= 50 else (0.3, 0.05)
         assert torch.isfinite(got.float()).all() and e.max().item() <= lim[0] and e.mean().item() <= lim[1], (Sq, Sk, e.max().item(), e.mean().item())
 
 
@@ -734,6 +738,15 @@ def test_attention_pv_fp8_is_opt_in_and_refuses_what_it_does_not_cover(K):
     finally:
         U.set_attention_pv_fp8(False)
     assert torch.equal(quant, _pv8(q, k, v, H, hd)) and not torch.equal(quant, base)
+    U.set_attention_pv_fp8(2)
+    try:
+        quant2 = K.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5)
+    finally:
+        U.set_attention_pv_fp8(0)
+    assert torch.equal(quant2, _pv8(q, k, v, H, hd, mode=2)) and not torch.equal(quant2, quant)
+    with pytest.raises(ValueError):
+        U.set_attention_pv_fp8(3)
+    assert N.lib().fdm_attn_fp8_workspace_bytes(1, 384, H, 128) == H * (6 * 64 * 128 + 1024) + H * 6 * 64 * 128 + 32
     assert torch.equal(base, K.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5))
     assert torch.equal(q64, K.scaled_dot_product_attention(q, k, v, 2 * H, 2 * H, 64, scale=0.125))
     out = torch.empty_like(q)

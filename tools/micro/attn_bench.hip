@@ -40,9 +40,10 @@ int main(int argc, char** argv) {
   const int64_t wsb = fdm_attn_fwd_workspace_bytes(128);
   hipMalloc(&ws, wsb);
   // ATTN_PV8=1: the opt-in fp8 P.V entry point (head_dim-128 shapes only; the others run the default kernel)
-  const bool pv8 = getenv("ATTN_PV8") && atoi(getenv("ATTN_PV8")) != 0;
+  const int qmode = getenv("ATTN_PV8") ? atoi(getenv("ATTN_PV8")) : 0;      // 1: fp8 P.V, 2: fp8 QK^T + fp8 P.V
+  const bool pv8 = qmode != 0;
   void* vqws = nullptr;
-  const int64_t vqb = fdm_attn_pvfp8_workspace_bytes(2, 8704, 24, 128);
+  const int64_t vqb = fdm_attn_fp8_workspace_bytes(2, 8704, 24, 128);
   if (pv8) hipMalloc(&vqws, vqb);
   std::vector<uint16_t> hq(maxe), hk(maxe), hv(maxe), ho(maxe);
   for (auto* hbuf : {&hq, &hk, &hv}) for (auto& e : *hbuf) e = f2b(nrand());
@@ -64,6 +65,8 @@ int main(int argc, char** argv) {
     hipMemcpy(v, hv.data(), s.B * s.Sk * C * 2, hipMemcpyHostToDevice);
     hipMemset(o, 0xff, s.B * s.Sq * C * 2);
     auto run = [&]() {
+      if (qmode == 2 && s.D == 128)
+        return fdm_attn_fwd_fp8(o, q, k, v, s.B, s.Sq, s.Sk, (int)s.H, (int)s.H, (int)s.D, C, C, C, C, 1.0f / sqrtf((float)s.D), ws, wsb, vqws, vqb, nullptr);
       if (pv8 && s.D == 128)
         return fdm_attn_fwd_pvfp8(o, q, k, v, s.B, s.Sq, s.Sk, (int)s.H, (int)s.H, (int)s.D, C, C, C, C, 1.0f / sqrtf((float)s.D), ws, wsb, vqws, vqb, nullptr);
       return fdm_attn_fwd(o, q, k, v, s.B, s.Sq, s.Sk, (int)s.H, (int)s.H, (int)s.D, C, C, C, C, 1.0f / sqrtf((float)s.D), nullptr, 0, 0, ws, wsb, nullptr);
@@ -105,7 +108,7 @@ int main(int argc, char** argv) {
       }
       if (nan || maxerr > 1.8e-2) ++bad;
     }
-    printf("%sattn B=%ld Sq=%ld Sk=%ld H=%ld hd=%ld spike=%d: %8.1f us %8.1f TF/s  max|err| %.3e mean %.3e nan %ld (%ld values)%s\n", (pv8 && s.D == 128) ? "[fp8 P.V] " : "", (long)s.B, (long)s.Sq,
+    printf("%sattn B=%ld Sq=%ld Sk=%ld H=%ld hd=%ld spike=%d: %8.1f us %8.1f TF/s  max|err| %.3e mean %.3e nan %ld (%ld values)%s\n", (pv8 && s.D == 128) ? (qmode == 2 ? "[fp8 QK+PV] " : "[fp8 P.V] ") : "", (long)s.B, (long)s.Sq,
            (long)s.Sk, (long)s.H, (long)s.D, s.spike, ms * 1e3, ms > 0 ? 4.0 * s.B * s.Sq * s.Sk * s.H * s.D / (ms * 1e-3) / 1e12 : 0.0, maxerr,
            nchk ? sumerr / nchk : 0.0, (long)nan, (long)nchk, (nan || maxerr > 1.8e-2) ? "  <-- FAIL" : "");
     if (getenv("ATTN_DUMP")) {

@@ -19,7 +19,9 @@ case "$S" in /*) ;; *) S="$TMP/$S" ;; esac
 python3 "$HERE/audit_no_scratch.py" "$S"     # every fdm:: kernel of the file: zero private segment
 # MASKED=1 audits the block-mask instantiation, HD=64 the head_dim-64 one, PV8=1 the fp8 P.V kernel (attn_fwd64_pv8_kernel: its asm
 # owns a224..a255 -- four 8-register V^T fragments -- instead of a240..a255)
-if [ -n "$PV8" ]; then KN="21attn_fwd64_pv8_kernel"; export FDM_AUDIT_OWNED_LO=224; else KN="17attn_fwd64_kernel"; export FDM_AUDIT_OWNED_LO=240; fi
+# QK8=1: the fp8 QK^T + fp8 P.V kernel (attn_fwd64_qk8_kernel: a192..a255 -- four K and four V^T fragments)
+if [ -n "$QK8" ]; then KN="21attn_fwd64_qk8_kernel"; export FDM_AUDIT_OWNED_LO=192;
+elif [ -n "$PV8" ]; then KN="21attn_fwd64_pv8_kernel"; export FDM_AUDIT_OWNED_LO=224; else KN="17attn_fwd64_kernel"; export FDM_AUDIT_OWNED_LO=240; fi
 K="_ZN3fdm${KN}ILi${HD:-128}ELb${MASKED:-0}EEEvNS_10AttnParamsE"
 awk -v k="^$K:" '$0 ~ k {on=1} on {print} on && /^\.Lfunc_end/ {exit}' $S > k.s
 grep -A40 "amdhsa_kernel _ZN3fdm${KN}ILi${HD:-128}ELb${MASKED:-0}" $S | grep -E "next_free_vgpr|accum_offset|private_segment_fixed_size"
