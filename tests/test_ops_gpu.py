@@ -760,6 +760,26 @@ def test_attention_pv_fp8_is_opt_in_and_refuses_what_it_does_not_cover(K):
     assert N.lib().fdm_attn_pvfp8_workspace_bytes(1, 384, H, 64) == 0
     assert N.lib().fdm_attn_pvfp8_workspace_bytes(1, 384, H, 128) == H * (6 * 64 * 128 + 1024)
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_attention_grouped_query_heads_all_modes(K, mode):
+    """num_kv_heads < num_q_heads (the operator's contract, operators_set.py:154-179): every q head of a group reads its kv head's K / V --
+    in the quantised modes its kv head's e4m3 images and scales.  Compared with the same call on K / V repeated per q head."""
+    Hq, Hkv, hd, Sq, Sk = 8, 2, 128, 300, 457
+    g = gen(77 + mode)
+    q, k, v = rbf(g, 1, Sq, Hq * hd).cuda(), rbf(g, 1, Sk, Hkv * hd).cuda(), rbf(g, 1, Sk, Hkv * hd).cuda()
+    rep = lambda t: t.view(1, Sk, Hkv, 1, hd).expand(1, Sk, Hkv, Hq // Hkv, hd).reshape(1, Sk, Hq * hd).contiguous()
+    from fastdm_amd.kernel import utils as U
+    U.set_attention_pv_fp8(mode)
+    try:
+        got = K.scaled_dot_product_attention(q, k, v, Hq, Hkv, hd, scale=hd ** -0.5)
+        want = K.scaled_dot_product_attention(q, rep(k), rep(v), Hq, Hq, hd, scale=hd ** -0.5)
+    finally:
+        U.set_attention_pv_fp8(0)
+    assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()
+    ref = O.scaled_dot_product_attention(q.cpu(), k.cpu(), v.cpu(), Hq, Hkv, hd, scale=hd ** -0.5)
+    e = (got.cpu().float() - ref.float()).abs()
+    assert e.max().item() <= (1.8e-2 if mode == 0 else 6e-2) and e.mean().item() <= (1e-3 if mode == 0 else 8e-3), (e.max().item(), e.mean().item())
+
 
 @pytest.mark.parametrize("S", [8704, 8650])
 def test_attention_split_kv_tail(K, S):
