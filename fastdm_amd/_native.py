@@ -45,6 +45,7 @@ SIGNATURES = {
     "fdm_attn_fwd_pvfp8": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I64, P, I64, P]),
     "fdm_attn_fp8_workspace_bytes": (I64, [I64, I64, I32, I32]),
     "fdm_attn_fwd_fp8": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I64, P, I64, P]),
+    "fdm_attn_fwd_quant_masked": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I32, I32, I32, P, I64, P]),
     "fdm_ln_modulate": (I32, [P, P, P, P, I32, P, P, P, I64, P, P, P, I64, I32, I64, F32, I32, P]),
     "fdm_ln_modulate_f32": (I32, [P, P, P, P, I32, P, P, P, I64, I64, I32, I64, F32, P]),
     "fdm_gate_residual": (I32, [P, P, P, P, I64, I64, I32, I64, P]),
@@ -61,7 +62,7 @@ SIGNATURES = {
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
 }
 
-ABI_VERSION = 14         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
+ABI_VERSION = 15         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL, EPI_GATE_RESIDUAL_F32 = 0, 1, 2, 3, 4
 
 
@@ -152,11 +153,27 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+_lib_error = None
+
+
 def lib():
-    """Load (once) and return the ctypes handle; raises NativeLibraryError if unavailable."""
-    global _lib
+    """Load (once) and return the ctypes handle; raises NativeLibraryError if unavailable.  A failed attempt is remembered: the next call
+    raises the same error at once instead of compiling for minutes again (a test suite on a box with a stale library would otherwise
+    rebuild once per test)."""
+    global _lib, _lib_error
     if _lib is not None:
         return _lib
+    if _lib_error is not None:
+        raise _lib_error
+    try:
+        return _load()
+    except NativeLibraryError as e:
+        _lib_error = e
+        raise
+
+
+def _load():
+    global _lib
     with _lock:
         if _lib is not None:
             return _lib

@@ -78,6 +78,7 @@ struct AttnParams {
   // fp8 P.V (attn_fwd64_pv8_kernel): the e4m3 V^T image attn_vq_kernel wrote and its per-channel scales
   const uint8_t* vq;     // [batch][kv head][ceil(sk / 64)][128 d][64 slots]
   const float* vscale;   // [batch][kv head][128]
+  const float* vmean;    // [batch][kv head][128]: the channel offset the V image was centred on, added back to the output
   // fp8 QK^T as well (attn_fwd64_qk8_kernel): the e4m3 K image attn_kq_kernel wrote and the power of two it was scaled by
   const uint8_t* kq;     // [batch][kv head][ceil(sk / 64)][64 keys][128 d], 16-byte chunk c of key r at c ^ ((r >> 1) & 7)
   const int* kexp;       // [batch][kv head]: K image = e4m3(k * 2^kexp)
@@ -513,40 +514,73 @@ __device__ unsigned long long g_att_stamps[4096 * 8];
 #undef FDM_A64_PV8
 #undef FDM_A64_NAME
 
-// ---- fp8 P.V pre-pass: V -> the e4m3 V^T image attn_fwd64_pv8_kernel streams (layout: attn_fwd64_body.inc), one per-channel scale
-//      per (batch, kv head, d): vscale[d] = absmax over the tokens / 448 (SageAttention quantises V per channel the same way:
-//      /root/reference/fastdm/kernel/cuda/attention.py:35-75 calls sageattn with its default fp8 P.V).  HBM-bound: reads V twice
-//      (2 x 2 B per element), writes 1 B per element.
-__global__ void __launch_bounds__(256) attn_vq_absmax_kernel(const bf16_t* __restrict__ v, int64_t sk, int64_t v_ts, int kv_heads,
-                                                              uint32_t* __restrict__ amax_bits) {
-  __shared__ float red[16][128];
+// ---- pre-pass of the quantised modes: per-channel statistics, then the e4m3 images the fp8 kernels stream (layouts: attn_fwd64_body.inc).
+// Both tensors are SMOOTHED the way SageAttention does it (/root/reference/fastdm/kernel/cuda/attention.py:35-75 calls sageattn with its
+// defaults smooth_k / per-channel V): a per-channel offset c[d] (the mean over the tokens) is subtracted before quantisation --
+//   K: softmax(q . (k - c)) = softmax(q . k - q . c) = softmax(q . k): a per-row constant, exact whatever c is;
+//   V: sum_j p_j (v_j - c) + c = sum_j p_j v_j because the weights sum to 1 (the kernel divides by the sum of the SAME rounded weights):
+//      exact whatever c is; c is added back in the epilogue.
+// so e4m3's three mantissa bits are spent on the deviations, not on a common offset (K = -8 +- 0.25 has no information left otherwise).
+// One statistics record per (batch, kv head): deterministic (the channel sums are order-free 64-bit fixed-point atomics, min / max atomics
+// on monotone integer keys), zeroed by a memset of the call.  HBM-bound: each tensor is read twice, its image written once.
+struct AttnChanStats {
+  long long sum[128];      // sum over the tokens of round(x * 2^16)
+  uint32_t maxk[128];      // max over the tokens of key(x)   (key: monotone float -> uint)
+  uint32_t nminK[128];     // max over the tokens of key(-x)
+};
+__device__ __forceinline__ uint32_t fkey(float f) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, f);
+  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) { return __builtin_bit_cast(float, (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+
+__global__ void __launch_bounds__(256) attn_chan_stats_kernel(const bf16_t* __restrict__ x, int64_t sk, int64_t ts, int kv_heads,
+                                                               AttnChanStats* __restrict__ st) {
+  __shared__ float rs[16][128], rmx[16][128], rmn[16][128];
   const int tid = threadIdx.x, dch = tid & 15, tl = tid >> 4;
   const int kvh = blockIdx.y, b = blockIdx.z;
   const int64_t t0 = (int64_t)blockIdx.x * 256;
-  float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float sm[8], mx[8], mn[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sm[j] = 0.f; mx[j] = -3.0e38f; mn[j] = 3.0e38f; }
 #pragma unroll 4
   for (int i = 0; i < 16; ++i) {
     const int64_t tok = t0 + i * 16 + tl;
     if (tok < sk) {
-      const Vec8 x = load8(v + ((int64_t)b * sk + tok) * v_ts + (int64_t)kvh * 128 + dch * 8);
+      const Vec8 v = load8(x + ((int64_t)b * sk + tok) * ts + (int64_t)kvh * 128 + dch * 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], fabsf(x.v[j]));
+      for (int j = 0; j < 8; ++j) {
+        const float c = fminf(fmaxf(v.v[j], -1.0e6f), 1.0e6f);      // (NaN -> -1e6 by fmaxf / fminf: any finite offset is valid; the quantiser saturates)
+        sm[j] += c; mx[j] = fmaxf(mx[j], c); mn[j] = fminf(mn[j], c);
+      }
     }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) red[tl][dch * 8 + j] = m[j];
+  for (int j = 0; j < 8; ++j) { rs[tl][dch * 8 + j] = sm[j]; rmx[tl][dch * 8 + j] = mx[j]; rmn[tl][dch * 8 + j] = mn[j]; }
   __syncthreads();
   if (tid < 128) {
-    float r = red[0][tid];
+    float a = rs[0][tid], hi = rmx[0][tid], lo = rmn[0][tid];
 #pragma unroll
-    for (int i = 1; i < 16; ++i) r = fmaxf(r, red[i][tid]);
-    if (r == r) atomicMax(amax_bits + ((int64_t)b * kv_heads + kvh) * 128 + tid, __builtin_bit_cast(uint32_t, r));   // non-negative floats order as their bits
+    for (int i = 1; i < 16; ++i) { a += rs[i][tid]; hi = fmaxf(hi, rmx[i][tid]); lo = fminf(lo, rmn[i][tid]); }      // fixed order: deterministic
+    AttnChanStats* r = st + ((int64_t)b * kv_heads + kvh);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&r->sum[tid]), (unsigned long long)(long long)__builtin_llrint((double)a * 65536.0));
+    if (hi >= lo) {
+      atomicMax(&r->maxk[tid], fkey(hi));
+      atomicMax(&r->nminK[tid], fkey(-lo));
+    }
   }
+}
+// channel offset and the largest |x - offset| of a channel, from its record
+__device__ __forceinline__ void chan_center(const AttnChanStats& r, int d, int64_t sk, float& c, float& dev) {
+  c = (float)((double)r.sum[d] * (1.0 / 65536.0) / (double)sk);
+  const float hi = fkey_inv(r.maxk[d]), lo = -fkey_inv(r.nminK[d]);
+  dev = fmaxf(hi - c, c - lo);
+  if (!(dev > 0.f)) dev = 0.f;
 }
 
 __global__ void __launch_bounds__(256) attn_vq_kernel(const bf16_t* __restrict__ v, int64_t sk, int64_t v_ts, int kv_heads, int ntiles,
-                                                       const uint32_t* __restrict__ amax_bits, uint8_t* __restrict__ vq,
-                                                       float* __restrict__ vscale) {
+                                                       const AttnChanStats* __restrict__ st, uint8_t* __restrict__ vq,
+                                                       float* __restrict__ vscale, float* __restrict__ vmean) {
   __shared__ __attribute__((aligned(16))) bf16_t tile[64][128 + 8];
   const int tid = threadIdx.x;
   const int t = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
@@ -554,23 +588,29 @@ __global__ void __launch_bounds__(256) attn_vq_kernel(const bf16_t* __restrict__
   for (int i = 0; i < 4; ++i) {
     const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
     const int64_t tok = (int64_t)t * 64 + row;
-    i32x4 x = {0, 0, 0, 0};      // keys past the end: zeros (their P is 0, and 0 x garbage could be NaN)
+    i32x4 x = {0, 0, 0, 0};
     if (tok < sk) x = *reinterpret_cast<const i32x4*>(v + ((int64_t)b * sk + tok) * v_ts + (int64_t)kvh * 128 + ch * 8);
     *reinterpret_cast<i32x4*>(&tile[row][ch * 8]) = x;
   }
   __syncthreads();
   const int d = tid >> 1, g = tid & 1;
   const int64_t bh = (int64_t)b * kv_heads + kvh;
-  const float amax = __builtin_bit_cast(float, amax_bits[bh * 128 + d]);
-  const float inv = amax > 0.f ? 448.0f / amax : 0.f;
-  if (t == 0 && g == 0) vscale[bh * 128 + d] = amax > 0.f ? amax / 448.0f : 1.0f;
+  float cen, dev;
+  chan_center(st[bh], d, sk, cen, dev);
+  const float inv = dev > 0.f ? 448.0f / dev : 0.f;
+  if (t == 0 && g == 0) {
+    vscale[bh * 128 + d] = dev > 0.f ? dev / 448.0f : 1.0f;
+    vmean[bh * 128 + d] = cen;
+  }
+  const int valid = (int)min((int64_t)64, sk - (int64_t)t * 64);      // keys past the end: zeros (their P is 0)
   uint32_t w[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {          // register r = 4 kb + m holds slots 4 r .. 4 r + 3 of this lane group: keys 32 kb + 8 m + 4 g + c
     const int kb = r >> 2, m = r & 3, key = 32 * kb + 8 * m + 4 * g;
-    const float x0 = clamp448(bf2f(tile[key][d]) * inv), x1 = clamp448(bf2f(tile[key + 1][d]) * inv);
-    const float x2 = clamp448(bf2f(tile[key + 2][d]) * inv), x3 = clamp448(bf2f(tile[key + 3][d]) * inv);
-    w[r] = cvt2_e4m3<false>(x0, x1) | (cvt2_e4m3<false>(x2, x3) << 16);
+    float x[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x[c] = key + c < valid ? clamp448((bf2f(tile[key + c][d]) - cen) * inv) : 0.f;
+    w[r] = cvt2_e4m3<false>(x[0], x[1]) | (cvt2_e4m3<false>(x[2], x[3]) << 16);
   }
   uint8_t* row = vq + ((bh * ntiles + t) * 128 + d) * 64;
   const int f = (d >> 2) & 3;
@@ -578,34 +618,22 @@ __global__ void __launch_bounds__(256) attn_vq_kernel(const bf16_t* __restrict__
   *reinterpret_cast<i32x4*>(row + (((2 * g + 1) ^ f) << 4)) = i32x4{(int)w[4], (int)w[5], (int)w[6], (int)w[7]};
 }
 
-// ---- fp8 QK^T pre-pass: K -> e4m3 image in the tile layout attn_fwd64_qk8_kernel streams.  One power-of-two scale per (batch, kv head):
-//      2^kexp with absmax * 2^kexp in (112, 224] (exact; it is undone by the MFMA's E8M0 block scale).  Row-major per key: no transpose.
-__global__ void __launch_bounds__(256) attn_kq_absmax_kernel(const bf16_t* __restrict__ k, int64_t sk, int64_t k_ts, int kv_heads,
-                                                              uint32_t* __restrict__ amax_bits) {
-  __shared__ float red[4];
-  const int tid = threadIdx.x, dch = tid & 15, tl = tid >> 4;
-  const int kvh = blockIdx.y, b = blockIdx.z;
-  const int64_t t0 = (int64_t)blockIdx.x * 256;
-  float m = 0.f;
-#pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
-    const int64_t tok = t0 + i * 16 + tl;
-    if (tok < sk) {
-      const Vec8 x = load8(k + ((int64_t)b * sk + tok) * k_ts + (int64_t)kvh * 128 + dch * 8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(x.v[j]));
-    }
-  }
-  m = block_reduce<256>(m, OpMax{}, red);
-  if (tid == 0 && m == m) atomicMax(amax_bits + (int64_t)b * kv_heads + kvh, __builtin_bit_cast(uint32_t, m));
-}
-
+// K image: e4m3((k - c) * 2^kexp), one power of two per (batch, kv head) with max |k - c| * 2^kexp in [128, 256) (exact; undone by the MFMA's
+// E8M0 block scale).  Row-major per key, no transpose.
 __global__ void __launch_bounds__(256) attn_kq_kernel(const bf16_t* __restrict__ k, int64_t sk, int64_t k_ts, int kv_heads, int ntiles,
-                                                       const uint32_t* __restrict__ amax_bits, uint8_t* __restrict__ kq, int* __restrict__ kexp) {
+                                                       const AttnChanStats* __restrict__ st, uint8_t* __restrict__ kq, int* __restrict__ kexp) {
+  __shared__ float cen_s[128];
+  __shared__ float red[4];
   const int tid = threadIdx.x;
   const int t = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
   const int64_t bh = (int64_t)b * kv_heads + kvh;
-  const float amax = __builtin_bit_cast(float, amax_bits[bh]);
+  float dev = 0.f;
+  if (tid < 128) {
+    float c;
+    chan_center(st[bh], tid, sk, c, dev);
+    cen_s[tid] = c;
+  }
+  const float amax = block_reduce<256>(dev, OpMax{}, red);      // (also the barrier that publishes cen_s)
   int e = 0;
   if (amax > 0.f) {
     e = 7 - (int)(((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xff) - 127);      // amax in [2^x, 2^(x+1)) -> amax * 2^e in [128, 256)
@@ -621,8 +649,11 @@ __global__ void __launch_bounds__(256) attn_kq_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const Vec8 x = load8(src + 8 * c);
-      w[2 * c] = cvt2_e4m3<false>(clamp448(x.v[0] * mul), clamp448(x.v[1] * mul)) | (cvt2_e4m3<false>(clamp448(x.v[2] * mul), clamp448(x.v[3] * mul)) << 16);
-      w[2 * c + 1] = cvt2_e4m3<false>(clamp448(x.v[4] * mul), clamp448(x.v[5] * mul)) | (cvt2_e4m3<false>(clamp448(x.v[6] * mul), clamp448(x.v[7] * mul)) << 16);
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = clamp448((x.v[j] - cen_s[quarter * 32 + 8 * c + j]) * mul);
+      w[2 * c] = cvt2_e4m3<false>(y[0], y[1]) | (cvt2_e4m3<false>(y[2], y[3]) << 16);
+      w[2 * c + 1] = cvt2_e4m3<false>(y[4], y[5]) | (cvt2_e4m3<false>(y[6], y[7]) << 16);
     }
   }
   uint8_t* row = kq + ((bh * ntiles + t) * 64 + key) * 128;
@@ -665,9 +696,15 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const AttnParams p, i
     }
   }
   const float inv = L > 0.f ? 1.0f / L : 0.f;
+  float off[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p.vmean != nullptr && L > 0.f) {      // quantised modes: the V image was centred per channel; the weights sum to 1
+    const float* vm = p.vmean + (int64_t)(b * p.kv_heads + head / (p.heads / p.kv_heads)) * D + ch * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) off[i] = vm[i];
+  }
   i32x4 o;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = (int)pack2bf(acc[2 * i] * inv, acc[2 * i + 1] * inv);
+  for (int i = 0; i < 4; ++i) o[i] = (int)pack2bf(acc[2 * i] * inv + off[2 * i], acc[2 * i + 1] * inv + off[2 * i + 1]);
   *reinterpret_cast<i32x4*>(p.o + ((int64_t)b * p.sq + qrow) * p.o_ts + (int64_t)head * D + ch * 8) = o;
 }
 
@@ -683,13 +720,14 @@ extern "C" int64_t fdm_attn_fwd_workspace_bytes(int head_dim) {
 extern "C" int64_t fdm_attn_pvfp8_workspace_bytes(int64_t batch, int64_t sk, int kv_heads, int head_dim) {
   if (batch <= 0 || sk <= 0 || kv_heads <= 0 || head_dim != 128) return 0;
   const int64_t ntiles = (sk + 63) / 64;
-  return batch * kv_heads * (ntiles * 64 * 128 + 2 * 128 * 4);      // e4m3 V^T image + absmax bits + scales
+  return batch * kv_heads * (ntiles * 64 * 128 + (int64_t)sizeof(AttnChanStats) + 2 * 128 * 4);      // e4m3 V^T image + channel statistics + scales + offsets
 }
 extern "C" int64_t fdm_attn_fp8_workspace_bytes(int64_t batch, int64_t sk, int kv_heads, int head_dim) {
   if (batch <= 0 || sk <= 0 || kv_heads <= 0 || head_dim != 128) return 0;
   const int64_t ntiles = (sk + 63) / 64;
   // the P.V part, then the e4m3 K image + per-head absmax bits + exponents (16-byte aligned)
-  return fdm_attn_pvfp8_workspace_bytes(batch, sk, kv_heads, head_dim) + batch * kv_heads * ntiles * 64 * 128 + ((batch * kv_heads * 8 + 15) & ~(int64_t)15);
+  return fdm_attn_pvfp8_workspace_bytes(batch, sk, kv_heads, head_dim) + batch * kv_heads * (ntiles * 64 * 128 + (int64_t)sizeof(AttnChanStats)) +
+         ((batch * kv_heads * 4 + 15) & ~(int64_t)15);
 }
 
 static int attn_fwd_impl(void* o, const void* q, const void* k, const void* v, int64_t batch, int64_t sq, int64_t sk,
@@ -703,7 +741,8 @@ static int attn_fwd_impl(void* o, const void* q, const void* k, const void* v, i
     return FDM_ERR_INVALID;
   if (head_dim != 64 && head_dim != 128) return FDM_ERR_UNSUPPORTED;
   if (pv8) {
-    if (head_dim != 128 || block_mask != nullptr) return FDM_ERR_UNSUPPORTED;     // fp8 P.V: the dense head_dim-128 kernel only
+    if (head_dim != 128) return FDM_ERR_UNSUPPORTED;                       // quantised modes: the head_dim-128 64-row kernels only
+    if (block_mask != nullptr && (sk + 63) / 64 > 4096) return FDM_ERR_UNSUPPORTED;
     const int64_t need = qmode == 2 ? fdm_attn_fp8_workspace_bytes(batch, sk, kv_heads, head_dim) : fdm_attn_pvfp8_workspace_bytes(batch, sk, kv_heads, head_dim);
     if (!vq_ws || (reinterpret_cast<uintptr_t>(vq_ws) & 15) || vq_bytes < need) return FDM_ERR_INVALID;
   }
@@ -796,32 +835,38 @@ static int attn_fwd_impl(void* o, const void* q, const void* k, const void* v, i
   }
   p.vq = nullptr;
   p.vscale = nullptr;
+  p.vmean = nullptr;
   p.kq = nullptr;
   p.kexp = nullptr;
   if (pv8) {
     const int ntl = (int)((sk + 63) / 64);
     uint8_t* img = reinterpret_cast<uint8_t*>(vq_ws);
-    uint32_t* amax = reinterpret_cast<uint32_t*>(img + batch * kv_heads * (int64_t)ntl * 8192);
-    float* vsc = reinterpret_cast<float*>(amax + batch * kv_heads * 128);
-    if (hipMemsetAsync(amax, 0, (size_t)batch * kv_heads * 128 * 4, s) != hipSuccess) return FDM_ERR_LAUNCH;
-    attn_vq_absmax_kernel<<<dim3((unsigned)((sk + 255) / 256), (unsigned)kv_heads, (unsigned)batch), 256, 0, s>>>(p.v, sk, v_tok_stride, kv_heads, amax);
+    AttnChanStats* vst = reinterpret_cast<AttnChanStats*>(img + batch * kv_heads * (int64_t)ntl * 8192);
+    float* vsc = reinterpret_cast<float*>(vst + batch * kv_heads);
+    float* vmn = vsc + batch * kv_heads * 128;
+    if (hipMemsetAsync(vst, 0, (size_t)batch * kv_heads * sizeof(AttnChanStats), s) != hipSuccess) return FDM_ERR_LAUNCH;
+    attn_chan_stats_kernel<<<dim3((unsigned)((sk + 255) / 256), (unsigned)kv_heads, (unsigned)batch), 256, 0, s>>>(p.v, sk, v_tok_stride, kv_heads, vst);
     FDM_CHECK_LAUNCH();
-    attn_vq_kernel<<<dim3((unsigned)ntl, (unsigned)kv_heads, (unsigned)batch), 256, 0, s>>>(p.v, sk, v_tok_stride, kv_heads, ntl, amax, img, vsc);
+    attn_vq_kernel<<<dim3((unsigned)ntl, (unsigned)kv_heads, (unsigned)batch), 256, 0, s>>>(p.v, sk, v_tok_stride, kv_heads, ntl, vst, img, vsc, vmn);
     FDM_CHECK_LAUNCH();
     p.vq = img;
     p.vscale = vsc;
+    p.vmean = vmn;
     if (qmode == 2) {
       uint8_t* kimg = reinterpret_cast<uint8_t*>(vq_ws) + fdm_attn_pvfp8_workspace_bytes(batch, sk, kv_heads, head_dim);
-      uint32_t* kamax = reinterpret_cast<uint32_t*>(kimg + batch * kv_heads * (int64_t)ntl * 8192);
-      int* kex = reinterpret_cast<int*>(kamax + batch * kv_heads);
-      if (hipMemsetAsync(kamax, 0, (size_t)batch * kv_heads * 4, s) != hipSuccess) return FDM_ERR_LAUNCH;
-      attn_kq_absmax_kernel<<<dim3((unsigned)((sk + 255) / 256), (unsigned)kv_heads, (unsigned)batch), 256, 0, s>>>(p.k, sk, k_tok_stride, kv_heads, kamax);
+      AttnChanStats* kst = reinterpret_cast<AttnChanStats*>(kimg + batch * kv_heads * (int64_t)ntl * 8192);
+      int* kex = reinterpret_cast<int*>(kst + batch * kv_heads);
+      if (hipMemsetAsync(kst, 0, (size_t)batch * kv_heads * sizeof(AttnChanStats), s) != hipSuccess) return FDM_ERR_LAUNCH;
+      attn_chan_stats_kernel<<<dim3((unsigned)((sk + 255) / 256), (unsigned)kv_heads, (unsigned)batch), 256, 0, s>>>(p.k, sk, k_tok_stride, kv_heads, kst);
       FDM_CHECK_LAUNCH();
-      attn_kq_kernel<<<dim3((unsigned)ntl, (unsigned)kv_heads, (unsigned)batch), 256, 0, s>>>(p.k, sk, k_tok_stride, kv_heads, ntl, kamax, kimg, kex);
+      attn_kq_kernel<<<dim3((unsigned)ntl, (unsigned)kv_heads, (unsigned)batch), 256, 0, s>>>(p.k, sk, k_tok_stride, kv_heads, ntl, kst, kimg, kex);
       FDM_CHECK_LAUNCH();
       p.kq = kimg;
       p.kexp = kex;
-      attn_fwd64_qk8_kernel<128, false><<<(unsigned)grid, 256, 0, s>>>(p);
+      if (mask_v2) attn_fwd64_qk8_kernel<128, true><<<(unsigned)grid, 256, 0, s>>>(p);
+      else attn_fwd64_qk8_kernel<128, false><<<(unsigned)grid, 256, 0, s>>>(p);
+    } else if (mask_v2) {
+      attn_fwd64_pv8_kernel<128, true><<<(unsigned)grid, 256, 0, s>>>(p);
     } else {
       attn_fwd64_pv8_kernel<128, false><<<(unsigned)grid, 256, 0, s>>>(p);
     }
@@ -863,6 +908,16 @@ extern "C" int fdm_attn_fwd_pvfp8(void* o, const void* q, const void* k, const v
                                   void* vq_workspace, int64_t vq_workspace_bytes, fdm_stream_t stream) {
   return attn_fwd_impl(o, q, k, v, batch, sq, sk, q_heads, kv_heads, head_dim, q_tok_stride, k_tok_stride, v_tok_stride, o_tok_stride,
                        scale, nullptr, 0, 0, workspace, workspace_bytes, stream, 1, vq_workspace, vq_workspace_bytes);
+}
+
+extern "C" int fdm_attn_fwd_quant_masked(void* o, const void* q, const void* k, const void* v, int64_t batch, int64_t sq, int64_t sk,
+                                         int q_heads, int kv_heads, int head_dim, int64_t q_tok_stride, int64_t k_tok_stride,
+                                         int64_t v_tok_stride, int64_t o_tok_stride, float scale, const int8_t* block_mask, int block_q,
+                                         int block_k, int mode, void* fp8_workspace, int64_t fp8_workspace_bytes, fdm_stream_t stream) {
+  if (mode != 1 && mode != 2) return FDM_ERR_INVALID;
+  if (block_mask == nullptr) return FDM_ERR_INVALID;
+  return attn_fwd_impl(o, q, k, v, batch, sq, sk, q_heads, kv_heads, head_dim, q_tok_stride, k_tok_stride, v_tok_stride, o_tok_stride,
+                       scale, block_mask, block_q, block_k, nullptr, 0, stream, mode, fp8_workspace, fp8_workspace_bytes);
 }
 
 extern "C" int fdm_attn_fwd_fp8(void* o, const void* q, const void* k, const void* v, int64_t batch, int64_t sq, int64_t sk,

@@ -153,6 +153,14 @@ def _attn(query, key, value, num_q_heads, num_kv_heads, head_dim, is_causal, sca
         scale = head_dim ** -0.5
     out = torch.empty((B, Sq, num_q_heads * head_dim), device=query.device, dtype=query.dtype)
     ws = N.attn_workspace(query.device, head_dim)
+    if mask is not None and head_dim == 128 and attention_pv_fp8() and -(-Sk // 64) <= 4096:      # opt-in: the reference's SpargeAttn class
+        mode = attention_pv_fp8()
+        vq = N.attn_pvfp8_workspace(query.device, B, Sk, num_kv_heads, head_dim, mode)
+        N.check(N.lib().fdm_attn_fwd_quant_masked(N.ptr(out), N.ptr(query), N.ptr(key), N.ptr(value), B, Sq, Sk, num_q_heads, num_kv_heads,
+                                                  head_dim, query.stride(1), key.stride(1), value.stride(1), out.stride(1), float(scale),
+                                                  N.ptr(mask), bq, bk, mode, N.ptr(vq), vq.numel(), N.stream()),
+                "sparse_scaled_dot_product_attention (fp8)")
+        return out
     if mask is None and head_dim == 128 and attention_pv_fp8():      # opt-in: the reference's SageAttention class (kernel/utils.py)
         mode = attention_pv_fp8()
         vq = N.attn_pvfp8_workspace(query.device, B, Sk, num_kv_heads, head_dim, mode)

@@ -44,7 +44,7 @@ const char* fdm_last_hip_error_string(void);
 
 /* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
  * refuse to run instead of passing arguments at the wrong positions. */
-#define FDM_ABI_VERSION 14
+#define FDM_ABI_VERSION 15
 int fdm_abi_version(void);
 
 /* Provenance the binary carries itself (no stamp file beside it): the content digest (64 hex digits) of every source the
@@ -253,6 +253,17 @@ int fdm_attn_fwd_fp8(void* o, const void* q, const void* k, const void* v,
                      int64_t o_tok_stride, float scale,
                      void* workspace, int64_t workspace_bytes, void* fp8_workspace, int64_t fp8_workspace_bytes,
                      fdm_stream_t stream);
+
+/* The block-sparse form of the two quantised modes (mode 1: fp8 P.V, mode 2: fp8 QK^T + fp8 P.V) -- the class of the reference's sparse
+ * CUDA path, SpargeAttn = block-sparse SageAttention (/root/reference/fastdm/kernel/cuda/attention.py:77-147).  block_mask as in
+ * fdm_attn_fwd (int8 [B,Hq,ceil(Sq/block_q),ceil(Sk/block_k)], block_q % 128 == 0, block_k % 64 == 0, at most 4096 64-key tiles);
+ * fp8_workspace as fdm_attn_fwd_pvfp8 (mode 1) / fdm_attn_fwd_fp8 (mode 2).  Opt-in like the dense forms.                             */
+int fdm_attn_fwd_quant_masked(void* o, const void* q, const void* k, const void* v,
+                              int64_t batch, int64_t sq, int64_t sk, int q_heads, int kv_heads, int head_dim,
+                              int64_t q_tok_stride, int64_t k_tok_stride, int64_t v_tok_stride,
+                              int64_t o_tok_stride, float scale,
+                              const int8_t* block_mask, int block_q, int block_k, int mode,
+                              void* fp8_workspace, int64_t fp8_workspace_bytes, fdm_stream_t stream);
 
 /* ================= fused kernels used by the FLUX block wiring (no reference export) ========== */
 

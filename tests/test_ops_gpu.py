@@ -746,7 +746,7 @@ def test_attention_pv_fp8_is_opt_in_and_refuses_what_it_does_not_cover(K):
     assert torch.equal(quant2, _pv8(q, k, v, H, hd, mode=2)) and not torch.equal(quant2, quant)
     with pytest.raises(ValueError):
         U.set_attention_pv_fp8(3)
-    assert N.lib().fdm_attn_fp8_workspace_bytes(1, 384, H, 128) == H * (6 * 64 * 128 + 1024) + H * 6 * 64 * 128 + 32
+    assert N.lib().fdm_attn_fp8_workspace_bytes(1, 384, H, 128) == H * (6 * 64 * 128 + 2048 + 1024) + H * (6 * 64 * 128 + 2048) + 16
     assert torch.equal(base, K.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5))
     assert torch.equal(q64, K.scaled_dot_product_attention(q, k, v, 2 * H, 2 * H, 64, scale=0.125))
     out = torch.empty_like(q)
@@ -758,7 +758,29 @@ def test_attention_pv_fp8_is_opt_in_and_refuses_what_it_does_not_cover(K):
     assert N.lib().fdm_attn_fwd_pvfp8(*args(H, hd, need - 1)) == -1                            # FDM_ERR_INVALID: workspace too small
     assert N.lib().fdm_attn_fwd_pvfp8(*args(H, hd, need)) == 0
     assert N.lib().fdm_attn_pvfp8_workspace_bytes(1, 384, H, 64) == 0
-    assert N.lib().fdm_attn_pvfp8_workspace_bytes(1, 384, H, 128) == H * (6 * 64 * 128 + 1024)
+    assert N.lib().fdm_attn_pvfp8_workspace_bytes(1, 384, H, 128) == H * (6 * 64 * 128 + 2048 + 1024)      # image + channel statistics + scales + offsets
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_attention_quantised_modes_are_invariant_to_channel_offsets(K, mode):
+    """The quantised modes centre K and V per channel before the e4m3 conversion (SageAttention's smoothing): softmax(q . (k - c)) = softmax(q . k)
+    and sum p (v - c) + c = sum p v exactly, so a large common offset costs no precision.  K = -8 + small noise (all information in the
+    deviations: without centring e4m3 keeps none of it) and V = 30 + N(0, 1): errors must stay at the level of the offset-free problem."""
+    H, hd, S = 2, 128, 1024
+    g = gen(31 + mode)
+    q = rbf(g, 1, S, H * hd)
+    k0, v0 = rbf(g, 1, S, H * hd, scale=0.25), rbf(g, 1, S, H * hd)
+    koff = (torch.randn(1, 1, H * hd, generator=g) * 4.0 - 8.0)
+    k, v = (k0.float() + koff).to(BF16), (v0.float() + 30.0).to(BF16)
+    got = _pv8(q.cuda(), k.cuda(), v.cuda(), H, hd, mode=mode).cpu()
+    ref = O.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5)
+    e = (got.float() - ref.float()).abs()
+    # the bf16 rounding of the shifted INPUTS (k near 8: ulp 2^-5; v near 30: ulp 2^-3) and of the output (near 30: 2^-3) is in the reference too;
+    # what the quantised kernel adds is the e4m3 noise of the deviations: ~ 0.1 / sqrt(S) of |v - 30| ~ 1
+    assert torch.isfinite(got.float()).all() and e.max().item() <= 0.13 and e.mean().item() <= 0.035, (e.max().item(), e.mean().item())
+    base = K.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5).cpu()
+    eb = (base.float() - ref.float()).abs()
+    assert e.mean().item() <= eb.mean().item() + 0.01, (e.mean().item(), eb.mean().item())
+
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_attention_grouped_query_heads_all_modes(K, mode):
@@ -870,6 +892,28 @@ def test_attention_rescale_branch_forced(K):
     torch.testing.assert_close(got, ref, rtol=0.0, atol=1.8e-2)
 
 
+class _attn_mode:
+    """with _attn_mode(m): the opt-in quantised-attention mode (0 bf16 default, 1 fp8 P.V, 2 fp8 QK^T + P.V) for the calls inside."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        from fastdm_amd.kernel import utils as U
+        self.was = U.attention_pv_fp8()
+        U.set_attention_pv_fp8(self.mode)
+
+    def __exit__(self, *exc):
+        from fastdm_amd.kernel import utils as U
+        U.set_attention_pv_fp8(self.was)
+        return False
+
+
+# absolute / mean tolerances of a sparse-attention comparison per mode (kept keys >= 64: the quantised modes' noise ~ 0.1 / sqrt(keys), and
+# a row dominated by one key inherits that key's e4m3 V rounding)
+SPARSE_TOL = {0: (1.8e-2, 1e-3), 1: (1.5e-1, 1.2e-2), 2: (2.0e-1, 1.6e-2)}
+
+
 def test_sparse_attention_masks(K):
     """All-ones mask == dense (the reference's only sparse test, tests/test_sparge_attention.py:81);
     a banded mask against the oracle's -inf definition."""
@@ -892,10 +936,16 @@ def test_sparse_attention_masks(K):
     got = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=band.cuda()).cpu()
     ref = O.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5, block_mask=band)
     torch.testing.assert_close(got, ref, rtol=0.0, atol=1.8e-2)
+    for mode in (1, 2):      # the quantised block-sparse kernels with an all-ones mask against their dense twins (same images, same arithmetic per tile)
+        with _attn_mode(mode):
+            dq = K.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5)
+            sq_ = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=ones.cuda())
+        assert torch.equal(dq, sq_), (mode, (dq.float() - sq_.float()).abs().max().item())
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("S,seed,density", [(2500, 1, 0.3), (1536, 2, 0.3), (700, 3, 0.3), (900, 4, 0.0), (64, 5, 0.0), (2500, 6, 0.9)])
-def test_sparse_attention_random_masks(K, S, seed, density):
+def test_sparse_attention_random_masks(K, S, seed, density, mode):
     """Random block masks whose rows differ inside a 256-row kernel block: the kernel walks the union of its waves' mask rows
     and a wave overwrites the tiles its own row drops (first tile of the union dropped for some waves, tail tile kept
     or dropped, lists longer than several 4-step groups).  Every mask row keeps at least one tile (a row without keys is
@@ -914,14 +964,19 @@ def test_sparse_attention_random_masks(K, S, seed, density):
         m[:, 0, :, nk - 1] = 1                            # head 0: every row keeps the (partial) last tile
         m[:, 1, 1::2, nk - 1] = 0
         m.scatter_(3, keep[..., None], 1)
-    got = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=m.cuda()).cpu()
+    with _attn_mode(mode):
+        got = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=m.cuda()).cpu()
     ref = O.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5, block_mask=m)
     assert torch.isfinite(got.float()).all()
-    torch.testing.assert_close(got, ref, rtol=0.0, atol=1.8e-2)
-    assert (got.float() - ref.float()).abs().mean().item() < 1e-3
+    torch.testing.assert_close(got, ref, rtol=0.0, atol=SPARSE_TOL[mode][0])
+    assert (got.float() - ref.float()).abs().mean().item() < SPARSE_TOL[mode][1]
+    if mode:
+        base = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=m.cuda()).cpu()
+        assert not torch.equal(base, got), "the quantised block-sparse kernel did not run"
 
 
-def test_sparse_attention_wave_pair_stretches(K):
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_sparse_attention_wave_pair_stretches(K, mode):
     """The masked kernel orders a block's union list [pair 0 only | both | pair 1 only] and a wave pair computes only on its own
     stretch (pair 1 starts at nA rounded down to a multiple of 4, pair 0 stops at nA + nAB; outside it a wave only keeps the K / V ring
     going).  One 256-row kernel block per case (nA, nAB, nB), several per launch: late starts with and without a rounded-down head,
@@ -947,7 +1002,8 @@ def test_sparse_attention_wave_pair_stretches(K):
             m[0, hh, 2 * i, ab] = 1
             m[0, hh, 2 * i + 1, ab] = 1
             m[0, hh, 2 * i + 1, bb] = 1
-    got = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=m.cuda()).cpu()
+    with _attn_mode(mode):
+        got = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=m.cuda()).cpu()
     ref = O.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5, block_mask=m)
     assert torch.isfinite(got.float()).all()
     live = m.sum(-1).bool()[0]                             # [H, mask rows]: rows with no key at all are undefined upstream (the kernel writes 0)
@@ -955,13 +1011,14 @@ def test_sparse_attention_wave_pair_stretches(K):
         for r in range(Sq // 128):
             blk = (slice(None), slice(128 * r, 128 * r + 128), slice(hh * hd, (hh + 1) * hd))
             if live[hh, r]:
-                torch.testing.assert_close(got[blk], ref[blk], rtol=0.0, atol=1.8e-2, msg=lambda s_: f"case {cases[r // 2]} head {hh} mask row {r}: {s_}")
-                assert (got[blk].float() - ref[blk].float()).abs().mean().item() < 1.5e-3
+                torch.testing.assert_close(got[blk], ref[blk], rtol=0.0, atol=SPARSE_TOL[mode][0], msg=lambda s_: f"case {cases[r // 2]} head {hh} mask row {r}: {s_}")
+                assert (got[blk].float() - ref[blk].float()).abs().mean().item() < 1.5 * SPARSE_TOL[mode][1]
             else:
                 assert (got[blk] == 0).all(), f"case {cases[r // 2]} head {hh} mask row {r}: a row without keys must come out as zeros"
 
 
-def test_sparse_attention_negative_logits_with_dropped_first_union_tile(K):
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_sparse_attention_negative_logits_with_dropped_first_union_tile(K, mode):
     """inside a 256-row kernel block the second mask row drops the first tile of the union list, and every kept logit of
     those rows is far below -126 in the exp2 domain (q . k = -40 per element pair: scale * 128 * -40 * log2 e = -650).  A wave that
     keeps reference 0 across its dropped first tile underflows to P = 0, l = 0 and writes zeros; the softmax is perfectly defined
@@ -977,11 +1034,12 @@ def test_sparse_attention_negative_logits_with_dropped_first_union_tile(K):
     m[:, :, 0::2, 5] = 1
     m[:, :, 1::2, 3] = 1            # ... the second one starts at tile 3: dead first union tile for waves 2, 3
     m[:, :, 1::2, 7] = 1
-    got = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=m.cuda()).cpu()
+    with _attn_mode(mode):
+        got = K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, scale=hd ** -0.5, sparse_mask=m.cuda()).cpu()
     ref = O.scaled_dot_product_attention(q, k, v, H, H, hd, scale=hd ** -0.5, block_mask=m)
     assert torch.isfinite(got.float()).all()
     assert ref.float().abs().mean().item() > 0.05
-    torch.testing.assert_close(got, ref, rtol=0.0, atol=1.8e-2)
+    torch.testing.assert_close(got, ref, rtol=0.0, atol=SPARSE_TOL[mode][0])
 
 
 @pytest.mark.parametrize("rows,d", [(8192, 5120), (2048, 10240), (7, 8)])
