@@ -469,6 +469,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef FDM_A64_LSUM_MFMA
 #define FDM_A64_LSUM_MFMA 0
 #endif
+// 1: packed fp32 in the bf16 kernel's softmax: the exact-Q scale multiply and the row sums take two scores per instruction
+// (v_pk_mul_f32 / v_pk_add_f32: 64 fewer of ~500 VALU instructions per tile step).  Measured in round 5 (profiles/r05_experiments.md):
+// same results bit for bit and 12 % SLOWER (865 -> 975 us at S = 8704): beside a busy matrix core the packed fp32 forms cost more issue
+// time than the two scalar instructions they replace.  Kept for the record.
+#ifndef FDM_A64_PK
+#define FDM_A64_PK 0
+#endif
 // 1: the VALU work sits in the odd MFMA gaps (no fragment read + wait there); 0: spread evenly
 #ifndef FDM_A64_BAL
 #define FDM_A64_BAL 0      // measured in one process (tools/micro/attn_ab): 762 vs 756 us, kept for the record

@@ -792,6 +792,135 @@ __global__ void debug_cvt_fp8_kernel(uint8_t* out, const float* in, int64_t n) {
   if (i < n) out[i] = (uint8_t)(cvt2_e4m3<SW>(clamp448(in[i]), 0.f) & 0xff);
 }
 
+
+// ------------------------------------------------------------------------------------ GroupNorm (+ addend in front, + SiLU behind), NCHW
+// The UNet's F.group_norm / F.silu call sites (reference layer/resnetblock.py:29-47, layer/unetblock.py:315, model/sdxl.py:469):
+//   v = bf16(x + addend[b, c])                       (optional: the time-embedding offset added in front of norm2)
+//   y = bf16(a * v + b'),  a = rstd * gamma[c],  b' = beta[c] - a * mean      (torch's fused-parameter form; fp32, statistics over a group)
+//   out = bf16(y / (1 + exp(-y)))                    (optional SiLU on the rounded y, as the separate F.silu call does)
+// A group (b, g) is ONE contiguous run of L = C/G * HW elements.  With 2 x 32 groups per tensor a block per group would leave 3/4 of the
+// chip idle, so a group is cut into P slices: the statistics kernel keeps its slice in registers (exact two-pass mean / M2 per slice, no
+// E[x^2] - mean^2 cancellation) and writes (n, mean, M2); the apply kernel merges a group's P partials (Chan's formula, in double), re-reads
+// its slice -- same block -> same XCD: the slice is still in that L2 -- and writes the output.  Each byte crosses HBM once per direction.
+constexpr int GN_THREADS = 256;
+template <int NV>      // 16-byte vectors per thread (slice <= NV * 256 vectors)
+__global__ void __launch_bounds__(GN_THREADS) group_norm_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ addend, float* __restrict__ part,
+                                                                      int64_t group_elems, int hw, int hw_shift, int cpg, int channels, int groups, int P) {
+  __shared__ float smem[GN_THREADS / 64 + 1];
+  const int slice = blockIdx.x, bg = blockIdx.y;      // bg = b * groups + g
+  const int b = bg / groups, g = bg - b * groups;
+  const int64_t nvec = group_elems >> 3;
+  const int v0 = (int)(nvec * slice / P), v1 = (int)(nvec * (slice + 1) / P);      // (group_elems < 2^31: checked by the host)
+  const bf16_t* src = x + (int64_t)bg * group_elems;
+  auto chan_of = [&](int v) { return hw_shift >= 0 ? (int)(((uint32_t)v << 3) >> hw_shift) : (int)(((uint32_t)v << 3) / (uint32_t)hw); };
+  i32x4 raw[NV];      // the slice as loaded (4 registers per vector); with an addend the sum is formed again in the second pass
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = v0 + (int)threadIdx.x + i * GN_THREADS;
+    if (v < v1) raw[i] = *reinterpret_cast<const i32x4*>(src + (int64_t)v * 8);
+  }
+  auto value = [&](int i, int v) {
+    Vec8 xv = unpack8(raw[i]);
+    if (addend != nullptr) {      // hw % 8 == 0: a vector lies inside one channel
+      const float ad = bf2f(addend[(int64_t)b * channels + g * cpg + chan_of(v)]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xv.v[j] = rbf(xv.v[j] + ad);
+    }
+    return xv;
+  };
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = v0 + (int)threadIdx.x + i * GN_THREADS;
+    if (v < v1) {
+      const Vec8 xv = value(i, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += xv.v[j];
+    }
+  }
+  const float n = (float)((v1 - v0) * 8);
+  const float mean = block_reduce<GN_THREADS>(s, OpSum(), smem) / n;
+  float m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = v0 + (int)threadIdx.x + i * GN_THREADS;
+    if (v < v1) {
+      const Vec8 xv = value(i, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = xv.v[j] - mean;
+        m2 += d * d;
+      }
+    }
+  }
+  m2 = block_reduce<GN_THREADS>(m2, OpSum(), smem);
+  if (threadIdx.x == 0) {
+    float* o = part + ((int64_t)bg * P + slice) * 4;
+    o[0] = n;
+    o[1] = mean;
+    o[2] = m2;
+  }
+}
+
+template <int NV, bool SILU>
+__global__ void __launch_bounds__(GN_THREADS) group_norm_apply_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ x, const bf16_t* __restrict__ addend,
+                                                                      const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                                                      const float* __restrict__ part, int64_t group_elems, int hw, int hw_shift, int cpg,
+                                                                      int channels, int groups, int P, float eps) {
+  __shared__ float stat[2];
+  const int slice = blockIdx.x, bg = blockIdx.y;
+  const int b = bg / groups, g = bg - b * groups;
+  const int64_t nvec = group_elems >> 3;
+  const int v0 = (int)(nvec * slice / P), v1 = (int)(nvec * (slice + 1) / P);
+  auto chan_of = [&](int v) { return hw_shift >= 0 ? (int)(((uint32_t)v << 3) >> hw_shift) : (int)(((uint32_t)v << 3) / (uint32_t)hw); };
+  const bf16_t* src = x + (int64_t)bg * group_elems;
+  bf16_t* dst = out + (int64_t)bg * group_elems;
+  i32x4 raw[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {      // the slice is requested before the partials are merged
+    const int v = v0 + (int)threadIdx.x + i * GN_THREADS;
+    if (v < v1) raw[i] = *reinterpret_cast<const i32x4*>(src + (int64_t)v * 8);
+  }
+  if (threadIdx.x == 0) {
+    const float* pp = part + (int64_t)bg * P * 4;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int i = 0; i < P; ++i) {      // Chan et al.: pairwise update of (n, mean, M2), fixed order
+      const double ni = pp[4 * i], mi = pp[4 * i + 1], qi = pp[4 * i + 2];
+      const double nt = n + ni, d = mi - mean;
+      mean += d * (ni / nt);
+      m2 += qi + d * d * (n * ni / nt);
+      n = nt;
+    }
+    const float var = (float)(m2 / n);      // biased, as F.group_norm
+    stat[0] = (float)mean;
+    stat[1] = 1.0f / sqrtf(var + eps);
+  }
+  __syncthreads();
+  const float mean = stat[0], rstd = stat[1];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = v0 + (int)threadIdx.x + i * GN_THREADS;
+    if (v < v1) {
+      const int c = g * cpg + chan_of(v);
+      const float a = rstd * bf2f(gamma[c]);
+      const float bb = bf2f(beta[c]) - a * mean;
+      Vec8 xv = unpack8(raw[i]);
+      if (addend != nullptr) {
+        const float ad = bf2f(addend[(int64_t)b * channels + c]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv.v[j] = rbf(xv.v[j] + ad);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float y = rbf(__builtin_fmaf(a, xv.v[j], bb));
+        if constexpr (SILU) y = y / (1.0f + expf(-y));
+        xv.v[j] = y;
+      }
+      store8(dst + (int64_t)v * 8, xv);
+    }
+  }
+}
+
 }  // namespace fdm
 
 using namespace fdm;
@@ -1021,6 +1150,62 @@ int fdm_gelu_and_mul(void* out, const void* in, int64_t rows, int d, fdm_stream_
   if (!out || !in || rows < 0 || d <= 0 || (d & 7) || !aligned16(out) || !aligned16(in)) return FDM_ERR_INVALID;
   if (rows == 0) return FDM_OK;
   gelu_and_mul_kernel<<<grid_for(rows * (d / 8), 256), 256, 0, to_stream(stream)>>>((bf16_t*)out, (const bf16_t*)in, rows, d);
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+// slices per group: enough blocks for ~4 per CU, at most 8 vectors of a slice per thread
+static int gn_slices(int64_t batch, int groups, int64_t group_elems) {
+  const int64_t nvec = group_elems >> 3;
+  int64_t P = (1024 + batch * groups - 1) / (batch * groups);
+  const int64_t pmin = (nvec + 8 * GN_THREADS - 1) / (8 * GN_THREADS);
+  if (P < pmin) P = pmin;
+  const int64_t pmax = (nvec + GN_THREADS - 1) / GN_THREADS;      // at least one vector per thread
+  if (P > pmax) P = pmax;
+  return (int)(P < 1 ? 1 : P);
+}
+
+int64_t fdm_group_norm_workspace_bytes(int64_t batch, int64_t channels, int64_t hw, int groups) {
+  if (batch <= 0 || channels <= 0 || hw <= 0 || groups <= 0 || channels % groups) return 0;
+  return batch * groups * (int64_t)gn_slices(batch, groups, channels / groups * hw) * 16;
+}
+
+int fdm_group_norm(void* out, const void* x, const void* gamma, const void* beta, const void* addend, int64_t batch, int64_t channels, int64_t hw,
+                   int groups, float eps, int act, void* workspace, int64_t workspace_bytes, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (!out || !x || !gamma || !beta || batch < 0 || channels <= 0 || hw <= 0 || groups <= 0 || channels % groups) return FDM_ERR_INVALID;
+  if (!aligned16(out) || !aligned16(x)) return FDM_ERR_INVALID;
+  if (act != 0 && act != 1) return FDM_ERR_UNSUPPORTED;
+  if (hw & 7) return FDM_ERR_UNSUPPORTED;      // 16-byte vectors must not straddle channels
+  if (batch == 0) return FDM_OK;
+  if (batch * groups > 65535) return FDM_ERR_UNSUPPORTED;
+  const int cpg = (int)(channels / groups);
+  const int64_t group_elems = (int64_t)cpg * hw;
+  if (group_elems >= ((int64_t)1 << 31)) return FDM_ERR_UNSUPPORTED;
+  const int hw_shift = (hw & (hw - 1)) == 0 ? __builtin_ctzll((unsigned long long)hw) : -1;
+  const int P = gn_slices(batch, groups, group_elems);
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15) || workspace_bytes < batch * groups * (int64_t)P * 16) return FDM_ERR_INVALID;
+  const int64_t nvec = group_elems >> 3;
+  const int64_t per_thread = ((nvec + P - 1) / P + GN_THREADS - 1) / GN_THREADS;      // the largest slice of the floor partition has ceil(nvec / P) vectors
+  if (per_thread > 8) return FDM_ERR_UNSUPPORTED;      // (cannot happen: gn_slices)
+  const dim3 grid((unsigned)P, (unsigned)(batch * groups));
+  hipStream_t s = to_stream(stream);
+  float* part = reinterpret_cast<float*>(workspace);
+#define FDM_GN_LAUNCH(NV)                                                                                                                              \
+  do {                                                                                                                                                 \
+    group_norm_stats_kernel<NV><<<grid, GN_THREADS, 0, s>>>((const bf16_t*)x, (const bf16_t*)addend, part, group_elems, (int)hw, hw_shift, cpg,         \
+                                                            (int)channels, groups, P);                                                                                \
+    FDM_CHECK_LAUNCH();                                                                                                                                \
+    if (act) group_norm_apply_kernel<NV, true><<<grid, GN_THREADS, 0, s>>>((bf16_t*)out, (const bf16_t*)x, (const bf16_t*)addend, (const bf16_t*)gamma, \
+                                                                           (const bf16_t*)beta, part, group_elems, (int)hw, hw_shift, cpg, (int)channels, \
+                                                                           groups, P, eps);                                                                     \
+    else group_norm_apply_kernel<NV, false><<<grid, GN_THREADS, 0, s>>>((bf16_t*)out, (const bf16_t*)x, (const bf16_t*)addend, (const bf16_t*)gamma,    \
+                                                                        (const bf16_t*)beta, part, group_elems, (int)hw, hw_shift, cpg, (int)channels,  \
+                                                                        groups, P, eps);                                                                           \
+  } while (0)
+  if (per_thread <= 4) FDM_GN_LAUNCH(4);
+  else FDM_GN_LAUNCH(8);
+#undef FDM_GN_LAUNCH
   FDM_CHECK_LAUNCH();
   return FDM_OK;
 }

@@ -3,6 +3,7 @@
 Activations are 2-D row-major bf16 matrices [rows, width]; `rows_per_batch` tells a kernel which
 row of a per-batch modulation vector applies.  Nothing here computes on the host.
 """
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -88,6 +89,34 @@ def gate_residual(res: torch.Tensor, y: torch.Tensor, gate: torch.Tensor, rows_p
     out = torch.empty_like(res)
     N.check(N.lib().fdm_gate_residual(N.ptr(out), N.ptr(res), N.ptr(y), N.ptr(gate), gate.stride(0), rows, width, rows_per_batch,
                                       N.stream()), "gate_residual")
+    return out
+
+
+_gn_ws = {}
+
+
+def group_norm(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float, addend: Optional[torch.Tensor] = None,
+               silu: bool = False) -> torch.Tensor:
+    """F.group_norm(x [+ addend[:, :, None, None]], groups, gamma, beta, eps) [-> F.silu] on an NCHW-contiguous bf16 tensor in two
+    kernels (statistics per slice, merge + apply) instead of torch's add / moments / fused-parameters / apply / SiLU passes
+    (the UNet's call sites: layer/resnetblock.py, layer/unetblock.py, model/sdxl.py).  Channels-last tensors, spatial sizes that are not
+    a multiple of 8 and FDM_GN_TORCH=1 (A/B runs) take the torch calls -- the same library ops the reference makes there."""
+    B, C, H, W = x.shape
+    hw = H * W
+    if x.dtype != BF16 or not x.is_contiguous() or (hw & 7) or os.environ.get("FDM_GN_TORCH", "0") == "1":
+        import torch.nn.functional as F
+        y = F.group_norm(x if addend is None else x + addend[:, :, None, None], groups, gamma, beta, eps)
+        return F.silu(y) if silu else y
+    need = N.lib().fdm_group_norm_workspace_bytes(B, C, hw, groups)
+    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _gn_ws[key] = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=x.device)
+    out = torch.empty_like(x)
+    if addend is not None:
+        assert addend.shape == (B, C) and addend.dtype == BF16 and addend.is_contiguous()
+    N.check(N.lib().fdm_group_norm(N.ptr(out), N.ptr(x), N.ptr(gamma), N.ptr(beta), N.ptr(addend), B, C, hw, groups, eps, 1 if silu else 0,
+                                   N.ptr(ws), ws.numel(), N.stream()), "group_norm")
     return out
 
 

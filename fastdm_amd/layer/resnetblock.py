@@ -1,12 +1,13 @@
 """SDXL's ResNet block (reference fastdm/layer/resnetblock.py:9-50).
 
-Convolutions and group-norm are library calls in the reference too (`F.conv2d`, `F.group_norm`); here they go to MIOpen
-through PyTorch-ROCm.  The time-embedding projection (M = batch rows) is the bf16 QLinear, i.e. the HBM-streaming GEMV
+Convolutions are library calls in the reference too (`F.conv2d`); here they go to MIOpen through PyTorch-ROCm.  The
+add / GroupNorm / SiLU chain around them is one fused HIP op (`fdm_group_norm`).  The time-embedding projection (M = batch rows) is the bf16 QLinear, i.e. the HBM-streaming GEMV
 kernel.
 """
 import torch
 import torch.nn.functional as F
 
+from fastdm_amd.kernel import fused
 from fastdm_amd.layer.qlinear import QLinear
 
 BF16 = torch.bfloat16
@@ -24,13 +25,14 @@ class ResnetBlock2D:
         self.convshortcut_weight = self.convshortcut_bias = None
 
     @staticmethod
-    def _gn_silu_conv3(x, gamma, beta, weight, bias):
-        """GroupNorm(32, eps 1e-5) -> SiLU -> 3x3 convolution (stride 1, padding 1)."""
-        return F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, 1e-05)), weight, bias, 1, 1)
+    def _gn_silu_conv3(x, gamma, beta, weight, bias, addend=None):
+        """[x + addend[:, :, None, None] ->] GroupNorm(32, eps 1e-5) -> SiLU -> 3x3 convolution (stride 1, padding 1).  The element-wise
+        part is one fused HIP op (kernel/fused.py:group_norm, NCHW); the convolution is MIOpen."""
+        return F.conv2d(fused.group_norm(x, 32, gamma, beta, 1e-05, addend=addend, silu=True), weight, bias, 1, 1)
 
     def forward(self, input_tensor, temb):
         h = self._gn_silu_conv3(input_tensor, self.norm1_gamma, self.norm1_beta, self.conv1_weight, self.conv1_bias)
         shift = self.time_emb_proj.forward(F.silu(temb))                   # [B, C_out]: per-channel offset from the time embedding
-        h = self._gn_silu_conv3(h + shift[:, :, None, None], self.norm2_gamma, self.norm2_beta, self.conv2_weight, self.conv2_bias)
+        h = self._gn_silu_conv3(h, self.norm2_gamma, self.norm2_beta, self.conv2_weight, self.conv2_bias, addend=shift.contiguous())
         skip = input_tensor if not self.conv_shortcut else F.conv2d(input_tensor, self.convshortcut_weight, self.convshortcut_bias, 1)
         return skip + h

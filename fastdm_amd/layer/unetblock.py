@@ -155,7 +155,7 @@ class Transformer2DModel:
     def forward(self, hidden_states, encoder_hidden_states=None, transformer_options={}):
         batch, inner_dim, height, width = hidden_states.shape
         res = hidden_states
-        t = F.group_norm(hidden_states, 32, self.norm_gamma, self.norm_beta, eps=1e-06)
+        t = fused.group_norm(hidden_states, 32, self.norm_gamma, self.norm_beta, 1e-06)
         t = t.permute(0, 2, 3, 1).reshape(batch * height * width, inner_dim)      # a view when the tensor is channels-last
         t = self.proj_in.forward_q(_quant_in(self.proj_in, t.contiguous()))
         enc = encoder_hidden_states
@@ -164,7 +164,9 @@ class Transformer2DModel:
         for block in self.transformer_blocks:
             t = block.forward(t, enc, batch, transformer_options)
         t = self.proj_out.forward_q(_quant_in(self.proj_out, t))
-        return t.reshape(batch, height, width, inner_dim).permute(0, 3, 1, 2) + res
+        # (written into a tensor laid out like `res`: the bare sum takes the permuted operand's strides, which sends the next ResNet's
+        # GroupNorm down torch's strided path instead of the fused NCHW kernel)
+        return torch.add(t.reshape(batch, height, width, inner_dim).permute(0, 3, 1, 2), res, out=torch.empty_like(res))
 
 
 class DownBlock2D:

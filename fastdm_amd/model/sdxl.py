@@ -14,6 +14,7 @@ from typing import Any, Dict, Tuple
 import torch
 import torch.nn.functional as F
 
+from fastdm_amd.kernel import fused
 from fastdm_amd.layer.embeddings import Timesteps, TimestepEmbedding
 from fastdm_amd.layer.unetblock import (CrossAttnDownBlock2D, CrossAttnUpBlock2D, DownBlock2D, EncoderStates, UNetMidBlock2DCrossAttn,
                                         UpBlock2D)
@@ -154,6 +155,6 @@ class SDXLUNetModelCore(BaseModelCore):
         sample = self.up_blocks[0].forward(hidden_states=sample, temb=emb, res_hidden_states_tuple=[s6, s7, s8], encoder_hidden_states=enc)
         sample = self.up_blocks[1].forward(hidden_states=sample, temb=emb, res_hidden_states_tuple=[s3, s4, s5], encoder_hidden_states=enc)
         sample = self.up_blocks[2].forward(hidden_states=sample, temb=emb, res_hidden_states_tuple=[s0, s1, s2])
-        sample = F.silu(F.group_norm(sample, 32, self.conv_norm_out_gemma, self.conv_norm_out_beta, eps=1e-05))
+        sample = fused.group_norm(sample, 32, self.conv_norm_out_gemma, self.conv_norm_out_beta, 1e-05, silu=True)
         sample = F.conv2d(sample, self.conv_out_weight, self.conv_out_bias, 1, 1)
         return [sample.contiguous()]

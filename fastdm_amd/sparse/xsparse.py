@@ -144,7 +144,9 @@ class RadialAttn(SparseAttn):
             self._masks[ck] = (km[None, None].expand(1, h, -1, -1).contiguous(), float(km.float().mean().item()))
         mask, density = self._masks[ck]
         v = self.video_token_num
-        with span("attn_sparse_bf16", 4.0 * v * v * h * d * density):     # algorithmic work = the kept blocks only
+        from fastdm_amd.kernel.utils import attention_pv_fp8
+        mode = attention_pv_fp8() if d == 128 else 0      # the span names the kernel that runs (operators_set._attn routes on the same rule)
+        with span(("attn_sparse_bf16", "attn_sparse_pvfp8", "attn_sparse_fp8")[mode], 4.0 * v * v * h * d * density):     # algorithmic work = the kept blocks only
             out = sparse_scaled_dot_product_attention(query[:v].reshape(1, v, h * d), key[:v].reshape(1, v, h * d),
                                                       value[:v].reshape(1, v, h * d), num_q_heads=h, num_kv_heads=h, head_dim=d,
                                                       is_causal=False, scale=1.0 / (d ** 0.5), sparse_mask=mask)

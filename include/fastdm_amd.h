@@ -44,7 +44,7 @@ const char* fdm_last_hip_error_string(void);
 
 /* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
  * refuse to run instead of passing arguments at the wrong positions. */
-#define FDM_ABI_VERSION 15
+#define FDM_ABI_VERSION 16
 int fdm_abi_version(void);
 
 /* Provenance the binary carries itself (no stamp file beside it): the content digest (64 hex digits) of every source the
@@ -224,12 +224,15 @@ int64_t fdm_attn_fwd_workspace_bytes(int head_dim);
  * (v_mfma_f32_32x32x64_f8f6f4) -- the class of the reference's preferred CUDA path, SageAttention (int8 QK^T / fp8 P.V:
  * /root/reference/fastdm/kernel/cuda/attention.py:20,35-75), which its published numbers were taken with.  Never the default:
  * fdm_attn_fwd is the reference TORCH backend's bf16 arithmetic and stays the headline.  What is quantised: P = exp2(s - ref) to
- * e4m3 (row reference kept so that 8 <= P_max < 2^7.7), V per (batch, kv head, channel) to e4m3 with scale absmax / 448 (a
- * pre-pass of this call writes the image into vq_workspace); scale * log2(e) is folded into Q with one more bf16 rounding.  QK^T,
- * the softmax state and the row sums (fp32, of the unrounded P -- as SageAttention's) are those of fdm_attn_fwd.  Error against an
+ * e4m3 (row reference kept so that 8 <= P_max < 2^7.7); V to e4m3 per (batch, kv head, channel): centred on the channel's mean
+ * c over the keys, scale = max|v - c| / 448 (a pre-pass of this call writes the image into vq_workspace; c is added
+ * back in the epilogue -- sum_j p_j (v_j - c) / l + c = sum_j p_j v_j / l because the weights sum to 1 -- so a common offset of V costs
+ * no precision: the "smoothing" of SageAttention 2); scale * log2(e) is folded into Q with one more bf16 rounding.  QK^T and the softmax
+ * state are those of fdm_attn_fwd; the row sums are taken from the ROUNDED weights (on the matrix core), so numerator and denominator see
+ * the same P and uniform attention is exact.  Error against an
  * fp64 softmax on N(0, 1) inputs: mean 5e-4 / max 3e-3 at S = 8704, mean 1.5e-3 / max 1e-2 at S = 1000 (the reference's own
  * tolerance for its kernels: atol 1.8e-2, tests/test_attention.py:66-100); a row dominated by ONE key inherits that key's V rounding
- * (up to 6 % of |v|).  head_dim 128, no block mask (FDM_ERR_UNSUPPORTED otherwise).
+ * (up to 6 % of |v - c|).  head_dim 128, no block mask (FDM_ERR_UNSUPPORTED otherwise).
  * vq_workspace: 16-byte aligned, >= fdm_attn_pvfp8_workspace_bytes(batch, sk, kv_heads, head_dim) bytes, owned by the caller,
  * rewritten by every call (reusable by consecutive calls on ONE stream).  workspace: as fdm_attn_fwd.                            */
 int64_t fdm_attn_pvfp8_workspace_bytes(int64_t batch, int64_t sk, int kv_heads, int head_dim);
@@ -241,7 +244,9 @@ int fdm_attn_fwd_pvfp8(void* o, const void* q, const void* k, const void* v,
                        fdm_stream_t stream);
 
 /* The same opt-in with QK^T on the fp8 matrix cores as well (SageAttention quantises Q and K too -- to int8; here e4m3):
- * v_mfma_scale_f32_32x32x64_f8f6f4, K as an e4m3 image scaled by one power of two per (batch, kv head) (a pre-pass of this call), Q
+ * v_mfma_scale_f32_32x32x64_f8f6f4, K as an e4m3 image -- centred per channel on its mean over the keys (q.(k_j - c) = q.k_j - q.c
+ * shifts every score of a row by the same amount: the softmax does not change) and scaled by one power of two per (batch, kv head) (a
+ * pre-pass of this call) --, Q
  * converted per 64-row wave with scale * log2(e) and its own power of two folded in; both powers of two are undone exactly by the
  * MFMA's E8M0 block scales, so the softmax sees scores in the same units as fdm_attn_fwd.  8 + 8 (+ 2 row-sum) MFMAs per 64-key tile
  * instead of 32 + 32.  Error against an fp64 softmax on N(0, 1) inputs: mean 7.4e-4 / max 3.7e-3 at S = 8704, mean 2.2e-3 / max 1.2e-2
@@ -293,6 +298,20 @@ int fdm_ln_modulate(void* out_bf16, void* out_q, float* out_scale, int32_t* out_
 int fdm_gate_residual(void* out, const void* res, const void* y, const void* gate,
                       int64_t gate_batch_stride, int64_t rows, int hidden, int64_t rows_per_batch,
                       fdm_stream_t stream);
+
+/* GroupNorm of an NCHW-contiguous bf16 tensor [batch, channels, hw] with the element-wise neighbours of its call sites fused in -- the
+ * F.group_norm / F.silu pairs of the UNet (/root/reference/fastdm/layer/resnetblock.py:29-47, fastdm/model/sdxl.py:469) and the
+ * spatial transformer's F.group_norm (fastdm/layer/unetblock.py:315).  Rounding order of the separate torch calls:
+ *   v   = addend ? bf16(x + addend[b, c]) : x              (addend: bf16 [batch, channels], the time-embedding offset; may be NULL)
+ *   y   = bf16(a * v + (beta[c] - a * mean)),  a = rstd * gamma[c]      (fp32; biased variance over the group's channels/groups * hw values)
+ *   out = act == 1 ? bf16(y / (1 + exp(-y))) : y           (act 1 = SiLU)
+ * hw % 8 == 0 (FDM_ERR_UNSUPPORTED otherwise); x / out 16-byte aligned; out must not alias x (a slice is read by two kernels).
+ * workspace: 16-byte aligned, >= fdm_group_norm_workspace_bytes(batch, channels, hw, groups) bytes (per-slice statistics), rewritten by
+ * every call.                                                                                                                         */
+int64_t fdm_group_norm_workspace_bytes(int64_t batch, int64_t channels, int64_t hw, int groups);
+int fdm_group_norm(void* out, const void* x, const void* gamma, const void* beta, const void* addend,
+                   int64_t batch, int64_t channels, int64_t hw, int groups, float eps, int act,
+                   void* workspace, int64_t workspace_bytes, fdm_stream_t stream);
 
 /* Element-wise GELU on bf16 (mode 1 = tanh approximation, 2 = erf), F.gelu semantics. */
 int fdm_gelu(void* out, const void* in, int64_t n, int mode, fdm_stream_t stream);

@@ -1042,6 +1042,52 @@ def test_sparse_attention_negative_logits_with_dropped_first_union_tile(K, mode)
     torch.testing.assert_close(got, ref, rtol=0.0, atol=SPARSE_TOL[mode][0])
 
 
+# every GroupNorm shape of the SDXL UNet at 1024^2 (batch 2 = CFG; incl. the up blocks' concatenated inputs) + small / odd ones:
+# a group of one vector per thread, a spatial size that is not a power of two, one slice per group
+GN_SHAPES = [(2, 320, 128, 128), (2, 960, 128, 128), (2, 640, 64, 64), (2, 1920, 64, 64), (2, 1280, 32, 32), (2, 2560, 32, 32),
+             (1, 64, 8, 8), (3, 96, 24, 28), (2, 32, 16, 16)]
+
+
+@pytest.mark.parametrize("shape", GN_SHAPES)
+@pytest.mark.parametrize("addend,silu,eps", [(False, True, 1e-5), (True, True, 1e-5), (False, False, 1e-6)])
+def test_group_norm_fused_matches_the_reference_torch_calls(K, shape, addend, silu, eps):
+    """fdm_group_norm against the calls the reference makes (layer/resnetblock.py:29-47: `hidden_states + temb` -> F.group_norm -> F.silu, all
+    bf16 tensors; unetblock.py:315 without SiLU, eps 1e-6) evaluated by torch on the CPU.  fp32 statistics in another summation order and a
+    fused multiply-add flip a bf16 rounding here and there (<= 1 ulp of y, which SiLU can stretch to 2 ulp of the output); a mean far from 0
+    (offset 3, std 0.5) makes the variance a cancellation if it is computed as E[x^2] - mean^2."""
+    import torch.nn.functional as F
+    from fastdm_amd.kernel import fused
+    B, C, H, W = shape
+    g = gen(B * C + H)
+    x = (rbf(g, B, C, H, W, scale=0.5).float() + 3.0 * torch.randn(1, C, 1, 1, generator=g)).to(BF16)
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(BF16), (0.3 * torch.randn(C, generator=g)).to(BF16)
+    ad = rbf(g, B, C, scale=0.7) if addend else None
+    ref = F.group_norm(x if ad is None else x + ad[:, :, None, None], 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    got = fused.group_norm(x.cuda(), 32, gamma.cuda(), beta.cuda(), eps, addend=dev(ad), silu=silu)
+    ulp_close(got, ref, 0.03, f"group_norm {shape}", ulps=2 if silu else 1)
+    assert (got.float().cpu() - ref.float()).abs().mean().item() < 2e-4 * ref.float().abs().mean().item() + 1e-6
+
+
+def test_group_norm_rejects_what_it_cannot_do(K):
+    from fastdm_amd import _native as N
+    x = torch.zeros(1, 32, 3, 5, dtype=BF16, device="cuda")      # hw = 15: a 16-byte vector would straddle channels
+    w = torch.ones(32, dtype=BF16, device="cuda")
+    ws = torch.empty(1 << 16, dtype=torch.uint8, device="cuda")
+    out = torch.empty_like(x)
+    call = lambda hw, act, wsb: N.lib().fdm_group_norm(N.ptr(out), N.ptr(x), N.ptr(w), N.ptr(w), None, 1, 32, hw, 32, 1e-5, act, N.ptr(ws), wsb, N.stream())
+    assert call(15, 1, ws.numel()) == -2        # FDM_ERR_UNSUPPORTED
+    assert call(8, 2, ws.numel()) == -2
+    assert call(8, 1, 8) == -1                                       # FDM_ERR_INVALID: workspace too small
+    assert N.lib().fdm_group_norm_workspace_bytes(2, 320, 16384, 32) == 2 * 32 * 16 * 16
+    # the Python wrapper takes torch's ops for such a tensor instead (same calls as the reference)
+    from fastdm_amd.kernel import fused
+    import torch.nn.functional as F
+    xx = torch.randn(1, 32, 3, 5, device="cuda").to(BF16)
+    assert torch.equal(fused.group_norm(xx, 32, w, w, 1e-5, silu=True), F.silu(F.group_norm(xx, 32, w, w, 1e-5)))
+
+
 @pytest.mark.parametrize("rows,d", [(8192, 5120), (2048, 10240), (7, 8)])
 def test_gelu_and_mul_shapes(K, rows, d):
     g = gen(rows + d)
