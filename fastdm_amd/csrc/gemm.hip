@@ -846,6 +846,10 @@ __device__ __forceinline__ void acc_set(const i32x4& v) {
                : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "n"(4 * IDX), "n"(4 * IDX + 1), "n"(4 * IDX + 2), "n"(4 * IDX + 3));
 }
 
+// 1: int8 / bf16 spread the fragment reads of a group behind its first MFMAs instead of issuing them in one burst (A/B switch)
+#ifndef FDM_W4_SPREAD_READS
+#define FDM_W4_SPREAD_READS 1
+#endif
 constexpr int W4_THREADS = 256;
 constexpr int W4_STAGE = (BM + BN) * 128;   // 64 KiB
 
@@ -986,6 +990,12 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
 #else
   const int f8_0 = (((fq ^ fg) << 1) | (fq & 1)) * 16, f8_1 = f8_0 ^ 16;
 #endif
+  // int8 / bf16 (two k-slices per step): k-slice s of block blk alone
+  auto read_frag_slice = [&](const uint8_t* st_row, int blk, int s) {
+    const int c = s * 4 + fq;
+    return lds_frag<Frag>(st_row + blk * 16 * 128 + ((((c >> 1) ^ fg) << 1) | (c & 1)) * 16, nullptr);
+  };
+  constexpr bool SPREAD_READS = FDM_W4_SPREAD_READS && NS == 2;
   auto read_frag = [&](Frag (&f)[NS], const uint8_t* st_row, int blk) {
     const uint8_t* rp = st_row + blk * 16 * 128;
     if constexpr (M::KS == 128) {
@@ -1089,16 +1099,30 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
           constexpr int cnt = (g >= 1 && g <= 4) ? 4 : 0;
           __builtin_amdgcn_s_waitcnt(0xC07F | (cnt << 8));    // lgkmcnt(cnt) only
           __builtin_amdgcn_sched_barrier(0);
-          read_frag(fa[(g + 1) & 1], sa_cur, g + 1);
-          if constexpr (g < 4) {
-            read_b_blk(bn, nxt, 2 * g);
-            read_b_blk(bn, nxt, 2 * g + 1);
+          if constexpr (!SPREAD_READS) {
+            read_frag(fa[(g + 1) & 1], sa_cur, g + 1);
+            if constexpr (g < 4) {
+              read_b_blk(bn, nxt, 2 * g);
+              read_b_blk(bn, nxt, 2 * g + 1);
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
         static_for<NS * 8>([&](auto jc) {
           constexpr int s = decltype(jc)::value / 8, nb = decltype(jc)::value % 8;
           M::template run<g * 8 + nb, decltype(first_c)::value && s == 0>(bc[s][nb], fa[g & 1][s]);   // swapped operands: MFMA rows = n, columns = m
+          if constexpr (SPREAD_READS && g < 7) {
+            // int8 / bf16: an MFMA lasts 16 cycles, the group's 2 + 4 fragment reads in one burst in front of it are 28 cycles of issue
+            // with the matrix core idle for half of them.  One read behind each of the group's first MFMAs instead, in the same order
+            // (A block g + 1 first, then the B blocks of step t + 1), so the counted lgkmcnt waits above still mean what they say.
+            constexpr int q = decltype(jc)::value;
+            if constexpr (q < NS) fa[(g + 1) & 1][q] = read_frag_slice(sa_cur, g + 1, q);
+            else if constexpr (g < 4 && q < NS + 2 * NS) {
+              constexpr int k = q - NS, blk = 2 * g + k / NS, sl = k % NS;
+              bn[sl][blk] = read_frag_slice(smem + nxt * W4_STAGE + b_row, blk, sl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
           // The 16 DMAs that follow step t's barrier are spread thinly: a burst from all four waves queues on the CU's one
           // load path and the waves then meet skewed at the next barrier (21 % of the loop, measured).  4 in group 7 of step t,
           // 3 in each of groups 0..3 of step t + 1 -- all land well before that step's barrier.
