@@ -14,4 +14,12 @@ python3 bench.py --model sdxl --graph > "$out/${tag}_sdxl_graph_bench.json" 2> "
 python3 bench.py --model sdxl --height 512 --width 512 --steps 4 --warmup 1 > "$out/${tag}_sdxl_512_bench.json" 2> "$out/${tag}_sdxl_512.err"
 python3 bench.py --model wan > "$out/${tag}_wan_dense_bench.json" 2> "$out/${tag}_wan_dense.err"
 python3 bench.py --model wan --start-step 11 --sparse-config examples/sparse/radial_attn_wan.json > "$out/${tag}_wan_sparse_bench.json" 2> "$out/${tag}_wan_sparse.err"
-for f in qwen qwen_batchcfg flux_bf16_1024 flux_int8 sd35 sdxl sdxl_graph sdxl_512 wan_dense wan_sparse; do echo "$f: $(tail -1 $out/${tag}_${f}_bench.json | cut -c1-60) ... $(tail -1 $out/${tag}_${f}_bench.json | grep -o '"ms_per_step": [0-9.]*')"; done
+# OPT-IN quantised attention (the reference's SageAttention / SpargeAttn class; never the headline): the same workloads, other attention arithmetic
+python3 bench.py --attn-pv-fp8 --no-cpu-baseline > "$out/${tag}_flux_pvfp8_bench.json" 2> "$out/${tag}_flux_pvfp8.err"
+python3 bench.py --attn-fp8 --no-cpu-baseline > "$out/${tag}_flux_attnfp8_bench.json" 2> "$out/${tag}_flux_attnfp8.err"
+python3 bench.py --model qwen --attn-fp8 --no-cpu-baseline > "$out/${tag}_qwen_attnfp8_bench.json" 2> "$out/${tag}_qwen_attnfp8.err"
+python3 bench.py --model qwen --batch-cfg --attn-fp8 --no-cpu-baseline > "$out/${tag}_qwen_batchcfg_attnfp8_bench.json" 2> "$out/${tag}_qwen_batchcfg_attnfp8.err"
+python3 bench.py --model wan --attn-fp8 --no-cpu-baseline > "$out/${tag}_wan_dense_attnfp8_bench.json" 2> "$out/${tag}_wan_dense_attnfp8.err"
+python3 bench.py --model wan --start-step 11 --sparse-config examples/sparse/radial_attn_wan.json --attn-pv-fp8 --no-cpu-baseline > "$out/${tag}_wan_sparse_pvfp8_bench.json" 2> "$out/${tag}_wan_sparse_pvfp8.err"
+python3 bench.py --model wan --start-step 11 --sparse-config examples/sparse/radial_attn_wan.json --attn-fp8 --no-cpu-baseline > "$out/${tag}_wan_sparse_attnfp8_bench.json" 2> "$out/${tag}_wan_sparse_attnfp8.err"
+for f in flux_pvfp8 flux_attnfp8 qwen_attnfp8 qwen_batchcfg_attnfp8 wan_dense_attnfp8 wan_sparse_pvfp8 wan_sparse_attnfp8 qwen qwen_batchcfg flux_bf16_1024 flux_int8 sd35 sdxl sdxl_graph sdxl_512 wan_dense wan_sparse; do echo "$f: $(tail -1 $out/${tag}_${f}_bench.json | cut -c1-60) ... $(tail -1 $out/${tag}_${f}_bench.json | grep -o '"ms_per_step": [0-9.]*')"; done
