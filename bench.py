@@ -32,6 +32,7 @@ PEAK_TFLOPS = {"fp8": 5000.0, "bf16": 2500.0, "int8": 5000.0,   # dense MFMA, /o
 IMAGE_STEPS = 25
 # timing-span name -> HIP kernel it launches (the name rocprofv3 reports; profiles/*_summary.txt)
 HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128, false>", "attn_sparse_bf16": "fdm::attn_fwd64_kernel<128, true>",
+              "attn_fwd_bf16_hd64": "fdm::attn_fwd_kernel<64, 512, 64>",
               "attn_fwd_pvfp8": "fdm::attn_fwd64_pv8_kernel<128, false>", "attn_fwd_fp8": "fdm::attn_fwd64_qk8_kernel<128, false>",
               "attn_sparse_pvfp8": "fdm::attn_fwd64_pv8_kernel<128, true>", "attn_sparse_fp8": "fdm::attn_fwd64_qk8_kernel<128, true>"}
 

@@ -176,7 +176,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
                                                N.ptr(vq), vq.numel(), N.stream()),
                     "attention (fp8 P.V)")
         return out
-    with span("attn_fwd_bf16", 4.0 * batch * S * Sk * heads * head_dim):
+    with span("attn_fwd_bf16" if head_dim == 128 else "attn_fwd_bf16_hd64", 4.0 * batch * S * Sk * heads * head_dim):      # (two kernels: bench.py HIP_KERNEL)
         N.check(N.lib().fdm_attn_fwd(N.ptr(out), N.ptr(q), N.ptr(k), N.ptr(v), batch, S, Sk, heads, heads, head_dim,
                                      q.stride(0), k.stride(0), v.stride(0), out.stride(0), float(scale), None, 0, 0, N.ptr(ws), ws.numel(),
                                      N.stream()),

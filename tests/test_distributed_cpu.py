@@ -427,3 +427,5 @@ def test_bench_names_the_gemm_kernel_from_the_recorded_launches():
     assert bench.span_kernel("gemm_w8a8_int8", {"fdm::gemm_w4_kernel": by["fdm::gemm_w4_kernel"]}) == "fdm::gemm_w4_kernel<1, false>"
     assert bench.span_kernel("gemm_bf16_res", {"fdm::gemm_kernel": by["fdm::gemm_w4_kernel"]}) == "fdm::gemm_kernel<2, true>"
     assert bench.span_kernel("attn_fwd_bf16") == "fdm::attn_fwd64_kernel<128, false>"
+    assert bench.span_kernel("attn_fwd_bf16_hd64") == "fdm::attn_fwd_kernel<64, 512, 64>"      # SD3.5 / SDXL: the round-1 kernel
+    assert bench.span_kernel("attn_sparse_fp8") == "fdm::attn_fwd64_qk8_kernel<128, true>"
