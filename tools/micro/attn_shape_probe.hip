@@ -23,7 +23,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int SHAPE, bool FILL>   // SHAPE 32: 64 MFMAs of 32x32x16 per step; 16: 128 MFMAs of 16x16x32
+// Round 5 (head_dim 64 with TWO heads per wave): FILLX = 2 carries the softmax work of two 64 x 64 score tiles (128 scores per
+// lane) beside the same 64 MFMAs -- two 64-wide heads fill the 128-wide P.V / O layout, their K / V bytes equal one head_dim-128 tile's, but every
+// score still needs its exp2 / scale / sum / max / pack.  NMFMA = 32 with FILLX = 1 is one head_dim-64 head per wave in the 64-row layout.
+template <int SHAPE, bool FILL, int FILLX = 1, int NMFMA = 64>   // SHAPE 32: 64 MFMAs of 32x32x16 per step; 16: 128 MFMAs of 16x16x32
 __global__ void __launch_bounds__(256, 1) probe(const uint8_t* __restrict__ src, float* __restrict__ out, unsigned long long* __restrict__ cyc, int steps) {
   __shared__ __attribute__((aligned(1024))) uint8_t smem[128 * 1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -38,22 +41,24 @@ __global__ void __launch_bounds__(256, 1) probe(const uint8_t* __restrict__ src,
     for (int e = 0; e < 4; ++e) acc16[i][e] = 0.f;
   i32x4 frag[4];                      // fragments in flight (three ahead, as the kernel)
   for (int i = 0; i < 4; ++i) frag[i] = i32x4{0x3c003c00 + lane, 0x3c003c00, 0x3c003c00, 0x3c003c00 + i};
-  float sv[64], lsum[2] = {0.f, 0.f}, mx[4] = {0.f, 0.f, 0.f, 0.f};
-  int pk[32];
-  for (int i = 0; i < 64; ++i) sv[i] = -1.0f - 0.01f * (float)((lane + i) & 31);
-  for (int i = 0; i < 32; ++i) pk[i] = 0;
+  float sv[64 * FILLX], lsum[2] = {0.f, 0.f}, mx[4] = {0.f, 0.f, 0.f, 0.f};
+  int pk[32 * FILLX];
+  for (int i = 0; i < 64 * FILLX; ++i) sv[i] = -1.0f - 0.01f * (float)((lane + i) & 31);
+  for (int i = 0; i < 32 * FILLX; ++i) pk[i] = 0;
+  const float exp_r = out[0] + 1.0009765625f;      // (the exact-Q form's per-score multiply, an SGPR the compiler cannot fold)
   const uint8_t* gsrc = src + (size_t)(blockIdx.x & 63) * 65536 + wave * 1024 + lane * 16;   // 4 MiB of source: L2 / MALL resident
   unsigned long long t0 = 0, t1 = 0;
   for (int st = 0; st < steps; ++st) {
     if (st == 2) t0 = __builtin_readcyclecounter();
-    constexpr int G = SHAPE == 32 ? 64 : 128;     // MFMA gaps per tile step
+    constexpr int G = SHAPE == 32 ? 64 : 128;     // gaps per tile step (NMFMA < 64: only every (64 / NMFMA)-th gap holds an MFMA)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       // ---- the gap's MFMA
       // (inline asm with the accumulators pinned in AGPRs: through the builtins hipcc rotates them with 240 / 400 v_accvgpr moves per
       // step, the very thing the real kernels' asm MFMAs avoid)
       if constexpr (SHAPE == 32) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc32[g % 12]) : "v"(frag[(g >> 1) & 3]), "v"(frag[(g + 1) & 3]));
+        if (g % (64 / NMFMA) == 0)
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc32[g % 12]) : "v"(frag[(g >> 1) & 3]), "v"(frag[(g + 1) & 3]));
       } else {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc16[g % 48]) : "v"(frag[(g >> 2) & 3]), "v"(frag[(g + 1) & 3]));
       }
@@ -67,22 +72,26 @@ __global__ void __launch_bounds__(256, 1) probe(const uint8_t* __restrict__ src,
       }
       if constexpr (FILL) {
         if (slot) {
-          sv[e] = __builtin_amdgcn_exp2f(sv[e]);
-          asm volatile("" : "+v"(sv[e]));
-          if (e >= 1) {
-            lsum[e & 1] += sv[e - 1];
-            asm volatile("" : "+v"(lsum[e & 1]));
-          }
-          if ((e & 1) && e >= 3) {
-            typedef float f2 __attribute__((ext_vector_type(2)));
-            typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-            f2 v = {sv[e - 3], sv[e - 2]};
-            pk[e >> 1] = __builtin_bit_cast(int, __builtin_convertvector(v, b2));
-            asm volatile("" : "+v"(pk[e >> 1]));
-          }
-          if ((e & 1) == 0) {
-            mx[(e >> 4) & 3] = __builtin_amdgcn_fmed3f(mx[(e >> 4) & 3], sv[(e + 17) & 63], sv[(e + 33) & 63]);
-            asm volatile("" : "+v"(mx[(e >> 4) & 3]));
+#pragma unroll
+          for (int x = 0; x < FILLX; ++x) {
+            float* svx = sv + 64 * x;
+            svx[e] = __builtin_amdgcn_exp2f(svx[e] * exp_r);
+            asm volatile("" : "+v"(svx[e]));
+            if (e >= 1) {
+              lsum[e & 1] += svx[e - 1];
+              asm volatile("" : "+v"(lsum[e & 1]));
+            }
+            if ((e & 1) && e >= 3) {
+              typedef float f2 __attribute__((ext_vector_type(2)));
+              typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+              f2 v = {svx[e - 3], svx[e - 2]};
+              pk[32 * x + (e >> 1)] = __builtin_bit_cast(int, __builtin_convertvector(v, b2));
+              asm volatile("" : "+v"(pk[32 * x + (e >> 1)]));
+            }
+            if ((e & 1) == 0) {
+              mx[(e >> 4) & 3] = __builtin_amdgcn_fmed3f(mx[(e >> 4) & 3], svx[(e + 17) & 63], svx[(e + 33) & 63]);
+              asm volatile("" : "+v"(mx[(e >> 4) & 3]));
+            }
           }
           if ((e & 7) == 4)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (e >> 3) * 4096),
@@ -95,28 +104,28 @@ __global__ void __launch_bounds__(256, 1) probe(const uint8_t* __restrict__ src,
     __builtin_amdgcn_s_barrier();
     // keep the softmax values in range for the next step (one cheap op per element, outside the gaps' accounting: both variants pay it)
 #pragma unroll
-    for (int i = 0; i < 64; ++i) sv[i] = sv[i] * 0.5f - 1.0f;
+    for (int i = 0; i < 64 * FILLX; ++i) sv[i] = sv[i] * 0.5f - 1.0f;
   }
   t1 = __builtin_readcyclecounter();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   float r = lsum[0] + lsum[1] + mx[0] + mx[1] + mx[2] + mx[3];
-  for (int i = 0; i < 32; ++i) r += (float)pk[i];
+  for (int i = 0; i < 32 * FILLX; ++i) r += (float)pk[i];
   for (int i = 0; i < (SHAPE == 32 ? 12 : 1); ++i) r += acc32[i][0] + acc32[i][5];
   for (int i = 0; i < (SHAPE == 16 ? 48 : 1); ++i) r += acc16[i][0] + acc16[i][3];
   out[blockIdx.x * 256 + tid] = r;
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int SHAPE, bool FILL>
+template <int SHAPE, bool FILL, int FILLX = 1, int NMFMA = 64>
 static void run(const char* name, const uint8_t* src, float* out, unsigned long long* cyc, int steps) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  for (int w = 0; w < 3; ++w) probe<SHAPE, FILL><<<256, 256>>>(src, out, cyc, steps);
+  for (int w = 0; w < 3; ++w) probe<SHAPE, FILL, FILLX, NMFMA><<<256, 256>>>(src, out, cyc, steps);
   hipDeviceSynchronize();
   const int iters = 20;
   hipEventRecord(e0, 0);
-  for (int i = 0; i < iters; ++i) probe<SHAPE, FILL><<<256, 256>>>(src, out, cyc, steps);
+  for (int i = 0; i < iters; ++i) probe<SHAPE, FILL, FILLX, NMFMA><<<256, 256>>>(src, out, cyc, steps);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms;
@@ -127,8 +136,8 @@ static void run(const char* name, const uint8_t* src, float* out, unsigned long 
   for (auto v : h) c += (double)v;
   c /= 256.0 * (steps - 2);
   // flops per tile step and wave: 64 keys x 64 rows x 128 dims x 2 (QK^T) + the same for P.V = 64 MFMAs of 32x32x16 x 32768 flop
-  const double flop = 256.0 * 4 * steps * 64.0 * 32768.0;
-  printf("%-34s %8.0f cycles / tile step   %7.1f us / launch   %7.1f TF/s\n", name, c, ms / iters * 1e3, flop / (ms / iters * 1e-3) / 1e12);
+  const double flop = 256.0 * 4 * steps * (double)(SHAPE == 32 ? NMFMA : 64) * 32768.0;
+  printf("%-52s %8.0f cycles / tile step   %7.1f us / launch   %7.1f TF/s\n", name, c, ms / iters * 1e3, flop / (ms / iters * 1e-3) / 1e12);
 }
 
 int main() {
@@ -138,6 +147,7 @@ int main() {
   hipMalloc(&src, 64 * 65536 + 65536);
   hipMemset(src, 0x3c, 64 * 65536 + 65536);
   hipMalloc(&out, 256 * 256 * 4);
+  hipMemset(out, 0, 256 * 256 * 4);
   hipMalloc(&cyc, 256 * 8);
   const int steps = 600;
   for (int rep = 0; rep < 2; ++rep) {
@@ -145,6 +155,8 @@ int main() {
     run<16, true>("16x16x32, full tile-step mix", src, out, cyc, steps);
     run<32, false>("32x32x16, MFMA + fragment reads", src, out, cyc, steps);
     run<16, false>("16x16x32, MFMA + fragment reads", src, out, cyc, steps);
+    run<32, true, 2, 64>("hd 64, TWO heads per wave (64 MFMA, 2x softmax)", src, out, cyc, steps);
+    run<32, true, 1, 32>("hd 64, one head per wave (32 MFMA, 1x softmax)", src, out, cyc, steps);
   }
   return 0;
 }
