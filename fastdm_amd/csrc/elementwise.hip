@@ -587,6 +587,28 @@ __global__ void __launch_bounds__(256) gelu_and_mul_kernel(bf16_t* __restrict__ 
   }
 }
 
+// GEGLU + per-token quantisation of its output in one pass (the UNet's feed-forward: proj1 -> a * gelu(g) -> quantise -> proj2): the row of
+// bf16(a * bf16(gelu_erf(g))) stays in registers between the product and the quantiser, so the [rows, d] bf16 tensor never exists.
+template <int MODE>
+__global__ void __launch_bounds__(256) gelu_and_mul_quant_kernel(uint8_t* __restrict__ q, float* __restrict__ scale, int32_t* __restrict__ azp,
+                                                                 const bf16_t* __restrict__ in, int d) {
+  __shared__ float smem[256 / 64 + 1];
+  const int64_t row = blockIdx.x;
+  const int nvec = d >> 3;
+  const bf16_t* src = in + row * 2 * (int64_t)d;
+  Vec8 x[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = threadIdx.x + i * 256;
+    if (v < nvec) {
+      const Vec8 a = load8(src + (size_t)v * 8), g = load8(src + d + (size_t)v * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[i].v[j] = rbf(a.v[j] * rbf(gelu_erf_f(g.v[j])));
+    }
+  }
+  quant_row_cached<256, MODE, false, 0>(x, nvec, q + row * (int64_t)d, scale, azp, row, smem);
+}
+
 // ------------------------------------------------------------------------------------ q/k norm + rope + scatter
 // x: 8 consecutive elements of one head (lane `sub` of the head's HD/8 lanes); wv: the norm weight's 8 elements; cr / sr: this
 // lane's 4 cos / 4 sin factors of the row's position (ignored without a cache)
@@ -1150,6 +1172,19 @@ int fdm_gelu_and_mul(void* out, const void* in, int64_t rows, int d, fdm_stream_
   if (!out || !in || rows < 0 || d <= 0 || (d & 7) || !aligned16(out) || !aligned16(in)) return FDM_ERR_INVALID;
   if (rows == 0) return FDM_OK;
   gelu_and_mul_kernel<<<grid_for(rows * (d / 8), 256), 256, 0, to_stream(stream)>>>((bf16_t*)out, (const bf16_t*)in, rows, d);
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+int fdm_gelu_and_mul_quant(void* q_out, float* scale_out, int32_t* azp_out, int quant_mode, const void* in, int64_t rows, int d, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (!q_out || !scale_out || !in || rows < 0 || d <= 0 || (d & 7) || !aligned16(in) || (reinterpret_cast<uintptr_t>(q_out) & 7)) return FDM_ERR_INVALID;
+  if (quant_mode != 1 && quant_mode != 2) return FDM_ERR_UNSUPPORTED;
+  if (quant_mode == 2 && !azp_out) return FDM_ERR_INVALID;
+  if (d > MAXV * 256 * 8) return FDM_ERR_UNSUPPORTED;      // a row lives in the registers of one block
+  if (rows == 0) return FDM_OK;
+  if (quant_mode == 1) gelu_and_mul_quant_kernel<1><<<(unsigned)rows, 256, 0, to_stream(stream)>>>((uint8_t*)q_out, scale_out, azp_out, (const bf16_t*)in, d);
+  else gelu_and_mul_quant_kernel<2><<<(unsigned)rows, 256, 0, to_stream(stream)>>>((uint8_t*)q_out, scale_out, azp_out, (const bf16_t*)in, d);
   FDM_CHECK_LAUNCH();
   return FDM_OK;
 }

@@ -92,6 +92,16 @@ def gate_residual(res: torch.Tensor, y: torch.Tensor, gate: torch.Tensor, rows_p
     return out
 
 
+def gelu_and_mul_quant(x: torch.Tensor, quant) -> Quantized:
+    """gelu_and_mul(x) quantised per token in one pass (the GEGLU feed-forward's proj2 input); bit-identical to the two operators."""
+    rows, d2 = x.shape
+    assert x.is_contiguous() and x.dtype == BF16 and d2 % 16 == 0
+    qz = _alloc_q(rows, d2 // 2, quant, x.device)
+    N.check(N.lib().fdm_gelu_and_mul_quant(N.ptr(qz.q), N.ptr(qz.scale), N.ptr(qz.azp), QUANT_MODE[quant], N.ptr(x), rows, d2 // 2, N.stream()),
+            "gelu_and_mul_quant")
+    return qz
+
+
 _gn_ws = {}
 
 

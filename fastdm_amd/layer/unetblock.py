@@ -96,8 +96,10 @@ class FeedForward_SDXL:
         self.proj2 = QLinear(out_features * 4, out_features, data_type=data_type)
 
     def forward(self, x):
-        h = gelu_and_mul(self.proj1.forward_q(_quant_in(self.proj1, x.contiguous())))
-        return self.proj2.forward_q(_quant_in(self.proj2, h))
+        h = self.proj1.forward_q(_quant_in(self.proj1, x.contiguous()))
+        if self.proj2.quant_type is None or h.shape[1] // 2 > 16384:
+            return self.proj2.forward_q(_quant_in(self.proj2, gelu_and_mul(h)))
+        return self.proj2.forward_q(fused.gelu_and_mul_quant(h, self.proj2.quant_type))
 
 
 class BasicTransformerBlock:
@@ -138,8 +140,12 @@ class BasicTransformerBlock:
             raise NotImplementedError("attn2 without encoder_hidden_states needs cross_attention_dim == hidden_size; not an SDXL case")
         o = self.attn2.attend(self._norm_in(x, 1, self.attn2.q_proj), rows, batch_size, enc)
         x = self._proj_add(self.attn2.out_proj, o, x)
-        h = gelu_and_mul(self.ff.proj1.forward_q(self._norm_in(x, 2, self.ff.proj1)))
-        return self._proj_add(self.ff.proj2, h, x)
+        h = self.ff.proj1.forward_q(self._norm_in(x, 2, self.ff.proj1))
+        lin = self.ff.proj2
+        if lin.quant_type is None or h.shape[1] // 2 > 16384:
+            return self._proj_add(lin, gelu_and_mul(h), x)
+        # GEGLU and the per-token quantisation of proj2's input in one pass (same bits as gelu_and_mul -> quantize)
+        return lin.forward_q(fused.gelu_and_mul_quant(h, lin.quant_type), N.EPI_GATE_RESIDUAL, gate=self._ones, res=x, rows_per_batch=x.shape[0])
 
 
 class Transformer2DModel:

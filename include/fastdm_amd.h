@@ -44,7 +44,7 @@ const char* fdm_last_hip_error_string(void);
 
 /* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
  * refuse to run instead of passing arguments at the wrong positions. */
-#define FDM_ABI_VERSION 16
+#define FDM_ABI_VERSION 17
 int fdm_abi_version(void);
 
 /* Provenance the binary carries itself (no stamp file beside it): the content digest (64 hex digits) of every source the
@@ -312,6 +312,13 @@ int64_t fdm_group_norm_workspace_bytes(int64_t batch, int64_t channels, int64_t 
 int fdm_group_norm(void* out, const void* x, const void* gamma, const void* beta, const void* addend,
                    int64_t batch, int64_t channels, int64_t hw, int groups, float eps, int act,
                    void* workspace, int64_t workspace_bytes, fdm_stream_t stream);
+
+/* gelu_and_mul followed by the per-token quantisation of its output (fdm_gelu_and_mul + fdm_quant_*_rowwise in one pass: the GEGLU
+ * feed-forward of the UNet, /root/reference/fastdm/layer/unetblock.py:213-224): in [rows, 2d] bf16 -> y = bf16(in[:, :d] * bf16(gelu_erf(in[:, d:])))
+ * -> q_out [rows, d] + scale_out [rows] (+ azp_out [rows] for quant_mode 2); quant_mode 1 = fp8, 2 = int8-asym.  Bit-identical to the two calls.
+ * d % 8 == 0, d <= 16384.                                                                                                              */
+int fdm_gelu_and_mul_quant(void* q_out, float* scale_out, int32_t* azp_out, int quant_mode, const void* in,
+                           int64_t rows, int d, fdm_stream_t stream);
 
 /* Element-wise GELU on bf16 (mode 1 = tanh approximation, 2 = erf), F.gelu semantics. */
 int fdm_gelu(void* out, const void* in, int64_t n, int mode, fdm_stream_t stream);

@@ -1095,6 +1095,27 @@ def test_gelu_and_mul_shapes(K, rows, d):
     ulp_close(K.gelu_and_mul(x.cuda()), O.gelu_and_mul(x), 0.01, "gelu_and_mul")
 
 
+@pytest.mark.parametrize("rows,d", [(2048, 5120), (8192, 2560), (5, 8), (3, 16384)])
+@pytest.mark.parametrize("quant", [FP8, torch.int8])
+def test_gelu_and_mul_quant_is_the_two_operators_bit_for_bit(K, rows, d, quant):
+    """fdm_gelu_and_mul_quant (GEGLU + per-token quantisation of proj2's input in one pass, unetblock.py:213-224) against gelu_and_mul followed by
+    quantize_to_fp8 / quantize_to_int8(asymmetric): codes, scales and zero points identical."""
+    from fastdm_amd.kernel import fused
+    g = gen(rows + d)
+    x = rbf(g, rows, 2 * d, scale=1.5).cuda()
+    y = K.gelu_and_mul(x)
+    got = fused.gelu_and_mul_quant(x, quant)
+    if quant == FP8:
+        q, s = K.quantize_to_fp8(y)
+        zp = None
+    else:
+        q, s, zp = K.quantize_to_int8(y, symmetric=False)
+    assert torch.equal(got.scale.reshape(-1), s.reshape(-1))
+    assert torch.equal(got.q.view(torch.uint8), q.view(torch.uint8))
+    if zp is not None:
+        assert torch.equal(got.azp.reshape(-1), zp.reshape(-1))
+
+
 @pytest.mark.parametrize("rows,hidden", [(4, 100), (33, 1), (7, 3075), (5, 129)])
 def test_rms_norm_any_width(K, rows, hidden):
     """The reference kernel takes any last dimension (csrc/elmwise_ops.cu:56-84); widths that are not a multiple of 8 (and
