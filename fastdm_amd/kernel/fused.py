@@ -113,7 +113,8 @@ def group_norm(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Te
     a multiple of 8 and FDM_GN_TORCH=1 (A/B runs) take the torch calls -- the same library ops the reference makes there."""
     B, C, H, W = x.shape
     hw = H * W
-    if x.dtype != BF16 or not x.is_contiguous() or (hw & 7) or os.environ.get("FDM_GN_TORCH", "0") == "1":
+    if (x.dtype != BF16 or not x.is_contiguous() or (hw & 7) or C % groups or B * groups > 65535 or (C // groups) * hw >= (1 << 31)
+            or os.environ.get("FDM_GN_TORCH", "0") == "1"):
         import torch.nn.functional as F
         y = F.group_norm(x if addend is None else x + addend[:, :, None, None], groups, gamma, beta, eps)
         return F.silu(y) if silu else y
