@@ -26,6 +26,7 @@ SIGNATURES = {
     "fdm_last_hip_error_string": (C.c_char_p, []),
     "fdm_rms_norm": (I32, [P, P, P, F32, I64, I32, P]),
     "fdm_rms_norm_strided": (I32, [P, P, P, F32, I64, I32, I64, I64, P]),
+    "fdm_rms_norm_rope_strided": (I32, [P, P, P, F32, I64, I32, I64, I64, P, I64, I32, P]),
     "fdm_rope_inplace": (I32, [P, P, P, I64, I64, I32, I32, I32, I32, I64, I64, I32, P]),
     "fdm_quant_fp8_rowwise": (I32, [P, P, P, I64, I32, I64, P]),
     "fdm_quant_int8_rowwise": (I32, [P, P, P, P, I64, I32, I64, P]),
@@ -65,7 +66,7 @@ SIGNATURES = {
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
 }
 
-ABI_VERSION = 17         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
+ABI_VERSION = 18         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL, EPI_GATE_RESIDUAL_F32 = 0, 1, 2, 3, 4
 
 

@@ -732,7 +732,7 @@ extern "C" int64_t fdm_attn_pvfp8_workspace_bytes(int64_t batch, int64_t sk, int
 extern "C" int64_t fdm_attn_fp8_workspace_bytes(int64_t batch, int64_t sk, int kv_heads, int head_dim) {
   if (batch <= 0 || sk <= 0 || kv_heads <= 0 || head_dim != 128) return 0;
   const int64_t ntiles = (sk + 63) / 64;
-  // the P.V part, then the e4m3 K image + per-head absmax bits + exponents (16-byte aligned)
+  // the P.V part, then the e4m3 K image + its channel statistics + per-head exponents (16-byte aligned)
   return fdm_attn_pvfp8_workspace_bytes(batch, sk, kv_heads, head_dim) + batch * kv_heads * (ntiles * 64 * 128 + (int64_t)sizeof(AttnChanStats)) +
          ((batch * kv_heads * 4 + 15) & ~(int64_t)15);
 }

@@ -67,10 +67,34 @@ __global__ void __launch_bounds__(256) rms_norm_small_kernel(bf16_t* __restrict_
   store8(out + row * hidden + sub * 8, o);
 }
 
-template <int THREADS, int NIT = 0>
+// ROPE: the GPT-J rotation of rope_kernel<false> (rot_dim == head_size) applied to the normalised row before it is written -- Wan's
+// across-head q / k norm followed by rotary_pos_embedding (layer/transformer.py:478-499) in one pass over the row.  The normalised value
+// is rounded to bf16 first, as the store of the separate norm kernel does: same bits as the two kernels.
+struct RopeArgs {
+  const bf16_t* cache;   // [seq_len rows of rot_dim]: cos | sin halves
+  int64_t seq_len;
+  int head_size;
+};
+__device__ __forceinline__ Vec8 rope_gptj8(const Vec8& x, const bf16_t* crow, int half, int c) {
+  Vec8 o;
+  const i32x2 cr = *reinterpret_cast<const i32x2*>(crow + c * 4);
+  const i32x2 sr = *reinterpret_cast<const i32x2*>(crow + half + c * 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t cw = (uint32_t)cr[j >> 1], sw = (uint32_t)sr[j >> 1];
+    const float cs = (j & 1) ? __builtin_bit_cast(float, cw & 0xffff0000u) : __builtin_bit_cast(float, cw << 16);
+    const float sn = (j & 1) ? __builtin_bit_cast(float, sw & 0xffff0000u) : __builtin_bit_cast(float, sw << 16);
+    const float a = x.v[2 * j], b = x.v[2 * j + 1];
+    o.v[2 * j] = rbf(a * cs) - rbf(b * sn);
+    o.v[2 * j + 1] = rbf(b * cs) + rbf(a * sn);
+  }
+  return o;
+}
+
+template <int THREADS, int NIT = 0, bool ROPE = false>
 __global__ void __launch_bounds__(THREADS) rms_norm_row_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ in,
                                                                const bf16_t* __restrict__ w, float eps, int hidden,
-                                                               int64_t in_stride, int64_t out_stride) {
+                                                               int64_t in_stride, int64_t out_stride, const RopeArgs ra) {
   using It = RowIt<NIT>;
   __shared__ float smem[THREADS / 64];
   const int64_t row = blockIdx.x;
@@ -111,6 +135,11 @@ __global__ void __launch_bounds__(THREADS) rms_norm_row_kernel(bf16_t* __restric
         else wv = load8(w + (size_t)v * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.v[j] = rbf(x[i].v[j] * rs) * wv.v[j];
+        if constexpr (ROPE) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o.v[j] = rbf(o.v[j]);
+          o = rope_gptj8(o, ra.cache + (row % ra.seq_len) * ra.head_size, ra.head_size >> 1, v % (ra.head_size >> 3));
+        }
         store8(dst + (size_t)v * 8, o);
       }
     }
@@ -119,16 +148,21 @@ __global__ void __launch_bounds__(THREADS) rms_norm_row_kernel(bf16_t* __restric
       Vec8 t = load8(src + (size_t)v * 8), wv = load8(w + (size_t)v * 8), o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o.v[j] = rbf(t.v[j] * rs) * wv.v[j];
+      if constexpr (ROPE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = rbf(o.v[j]);
+        o = rope_gptj8(o, ra.cache + (row % ra.seq_len) * ra.head_size, ra.head_size >> 1, v % (ra.head_size >> 3));
+      }
       store8(dst + (size_t)v * 8, o);
     }
   }
 }
 
 // host side: iteration count -> template instance (widths beyond MAXV iterations use the generic two-pass form)
-template <int THREADS>
+template <int THREADS, bool ROPE = false>
 static void launch_rms_row(bf16_t* o, const bf16_t* i, const bf16_t* w, float eps, int64_t rows, int hidden, int64_t is, int64_t os,
-                           hipStream_t s) {
-#define FDM_RMS(NITV) rms_norm_row_kernel<THREADS, NITV><<<(int)rows, THREADS, 0, s>>>(o, i, w, eps, hidden, is, os)
+                           hipStream_t s, const RopeArgs ra = RopeArgs{nullptr, 1, 8}) {
+#define FDM_RMS(NITV) rms_norm_row_kernel<THREADS, NITV, ROPE><<<(int)rows, THREADS, 0, s>>>(o, i, w, eps, hidden, is, os, ra)
   switch (((hidden >> 3) + THREADS - 1) / THREADS) {
     case 1: FDM_RMS(1); break; case 2: FDM_RMS(2); break; case 3: FDM_RMS(3); break; case 4: FDM_RMS(4); break;
     case 5: FDM_RMS(5); break; case 6: FDM_RMS(6); break; case 7: FDM_RMS(7); break; case 8: FDM_RMS(8); break;
@@ -1106,6 +1140,24 @@ int fdm_rms_norm_strided(void* out, const void* in, const void* weight, float ep
   hipStream_t s = to_stream(stream);
   if (hidden <= 4096) launch_rms_row<64>((bf16_t*)out, (const bf16_t*)in, (const bf16_t*)weight, eps, rows, hidden, in_row_stride, out_row_stride, s);
   else launch_rms_row<256>((bf16_t*)out, (const bf16_t*)in, (const bf16_t*)weight, eps, rows, hidden, in_row_stride, out_row_stride, s);
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+int fdm_rms_norm_rope_strided(void* out, const void* in, const void* weight, float eps, int64_t rows, int hidden, int64_t in_row_stride,
+                              int64_t out_row_stride, const void* cos_sin_cache, int64_t seq_len, int head_size, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (rows == 0 && hidden > 0 && !(hidden & 7)) return FDM_OK;
+  if (!out || !in || !weight || !cos_sin_cache || rows < 0 || hidden <= 0 || (hidden & 7) || !aligned16(out) || !aligned16(in) || !aligned16(weight) ||
+      in_row_stride < hidden || out_row_stride < hidden || (in_row_stride & 7) || (out_row_stride & 7) || seq_len <= 0)
+    return FDM_ERR_INVALID;
+  if (head_size <= 0 || (head_size & 7) || hidden % head_size || (reinterpret_cast<uintptr_t>(cos_sin_cache) & 7)) return FDM_ERR_UNSUPPORTED;
+  hipStream_t s = to_stream(stream);
+  const RopeArgs ra{(const bf16_t*)cos_sin_cache, seq_len, head_size};
+  if (hidden <= 4096)
+    launch_rms_row<64, true>((bf16_t*)out, (const bf16_t*)in, (const bf16_t*)weight, eps, rows, hidden, in_row_stride, out_row_stride, s, ra);
+  else
+    launch_rms_row<256, true>((bf16_t*)out, (const bf16_t*)in, (const bf16_t*)weight, eps, rows, hidden, in_row_stride, out_row_stride, s, ra);
   FDM_CHECK_LAUNCH();
   return FDM_OK;
 }

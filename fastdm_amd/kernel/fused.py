@@ -72,11 +72,19 @@ def ln_modulate_f32(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, r
     return out, qz
 
 
-def rms_norm_rows(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
-    """rms_norm over the last dim of a [rows, hidden] matrix whose rows may be column slices of a wider matrix."""
+def rms_norm_rows(x: torch.Tensor, weight: torch.Tensor, eps: float, rope: Optional[torch.Tensor] = None, seq_len: int = 0,
+                  head_dim: int = 0) -> torch.Tensor:
+    """rms_norm over the last dim of a [rows, hidden] matrix whose rows may be column slices of a wider matrix.
+    rope ([>= seq_len, head_dim] cos | sin table): the GPT-J rotary embedding of `rotary_pos_embedding(..., is_neox=False)` with
+    positions row % seq_len is applied to the normalised row in the same pass (same bits as the two operators)."""
     rows, hidden = x.shape
     assert x.stride(1) == 1 and weight.is_contiguous() and weight.numel() == hidden
     out = torch.empty((rows, hidden), device=x.device, dtype=x.dtype)
+    if rope is not None:
+        assert rope.dtype == BF16 and rope.is_contiguous() and rope.shape[1] == head_dim and rope.shape[0] >= seq_len > 0 and rows % seq_len == 0
+        N.check(N.lib().fdm_rms_norm_rope_strided(N.ptr(out), N.ptr(x), N.ptr(weight), eps, rows, hidden, x.stride(0), hidden, N.ptr(rope),
+                                                  seq_len, head_dim, N.stream()), "rms_norm_rope_strided")
+        return out
     N.check(N.lib().fdm_rms_norm_strided(N.ptr(out), N.ptr(x), N.ptr(weight), eps, rows, hidden, x.stride(0), hidden, N.stream()),
             "rms_norm_strided")
     return out

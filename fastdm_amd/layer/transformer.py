@@ -202,12 +202,10 @@ class WanAttention:
                         + fused.attention(q, k_img, v_img, batch, self.heads, self.head_dim, self.scale))
         else:
             qkv = self.qkv.forward_q(xq)
-            q = fused.rms_norm_rows(qkv[:, :D], self.norm_q_weight, self.eps)
-            k = fused.rms_norm_rows(qkv[:, D:2 * D], self.norm_k_weight, self.eps)
+            # across-head norm and (when given) the rotary embedding in one pass over each row: the bits of rms_norm -> rotary_pos_embedding
+            q = fused.rms_norm_rows(qkv[:, :D], self.norm_q_weight, self.eps, rope=rope, seq_len=seq, head_dim=self.head_dim)
+            k = fused.rms_norm_rows(qkv[:, D:2 * D], self.norm_k_weight, self.eps, rope=rope, seq_len=seq, head_dim=self.head_dim)
             v, sk = qkv[:, 2 * D:], seq
-            if rope is not None:
-                from fastdm_amd.kernel.operators_set import rotary_pos_embedding
-                rotary_pos_embedding(q.view(batch, seq, D), k.view(batch, seq, D), self.head_dim, rope, is_neox=False)
         use_sparse = False
         if sparse_attn is not None and not self.is_cross_attention:
             cb = sparse_attn.config.current_steps_callback

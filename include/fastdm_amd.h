@@ -44,7 +44,7 @@ const char* fdm_last_hip_error_string(void);
 
 /* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
  * refuse to run instead of passing arguments at the wrong positions. */
-#define FDM_ABI_VERSION 17
+#define FDM_ABI_VERSION 18
 int fdm_abi_version(void);
 
 /* Provenance the binary carries itself (no stamp file beside it): the content digest (64 hex digits) of every source the
@@ -70,6 +70,12 @@ int fdm_rms_norm(void* out, const void* in, const void* weight, float eps,
  * layer/transformer.py:478-485): row strides in elements, multiples of 8.                         */
 int fdm_rms_norm_strided(void* out, const void* in, const void* weight, float eps, int64_t rows, int hidden,
                          int64_t in_row_stride, int64_t out_row_stride, fdm_stream_t stream);
+/* The same with the GPT-J rotary embedding of fdm_rope_inplace (is_neox = 0, rot_dim == head_size, positions row % seq_len) applied to
+ * the normalised row before it is written: Wan's across-head q / k norm + rotary_emb_ (layer/transformer.py:478-499) in one pass.
+ * Bit-identical to fdm_rms_norm_strided followed by fdm_rope_inplace.  hidden % head_size == 0, head_size % 8 == 0.                  */
+int fdm_rms_norm_rope_strided(void* out, const void* in, const void* weight, float eps, int64_t rows, int hidden,
+                              int64_t in_row_stride, int64_t out_row_stride, const void* cos_sin_cache, int64_t seq_len,
+                              int head_size, fdm_stream_t stream);
 
 /* ---- replaces cuda_ops.rotary_emb_ (ops.h:22-33; elmwise_ops.cu:86-168,451-522) ---------------
  * In place on q [tokens, q_heads*head_size] and k [tokens, k_heads*head_size] (row strides in

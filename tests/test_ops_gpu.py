@@ -1042,6 +1042,27 @@ def test_sparse_attention_negative_logits_with_dropped_first_union_tile(K, mode)
     torch.testing.assert_close(got, ref, rtol=0.0, atol=SPARSE_TOL[mode][0])
 
 
+@pytest.mark.parametrize("batch,seq,heads,hd,slice_of", [(2, 300, 40, 128, 3), (1, 1000, 40, 128, 1), (2, 77, 12, 64, 3), (1, 5, 1, 8, 1), (1, 9, 80, 128, 1), (1, 4, 160, 128, 1)])
+def test_rms_norm_rope_fused_is_the_two_operators_bit_for_bit(K, batch, seq, heads, hd, slice_of):
+    """fdm_rms_norm_rope_strided (Wan: across-head q / k RMS-norm + GPT-J rotary embedding in one pass, layer/transformer.py:478-499) against
+    rms_norm on the slice followed by rotary_pos_embedding: identical bits.  Rows are column slices of a wider (fused qkv) matrix; hidden
+    5120 takes the 256-thread kernel, 768 / 8 the one-wave one, 10240 register-resident rows, 20480 the two-pass form."""
+    from fastdm_amd.kernel import fused
+    D = heads * hd
+    g = gen(batch * seq + D)
+    wide = rbf(g, batch * seq, slice_of * D, scale=1.7).cuda()
+    x = wide[:, (slice_of - 1) * D:]
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(BF16).cuda()
+    ang = torch.rand(seq + 3, hd // 2, generator=g) * 6.28
+    cache = torch.cat((ang.cos(), ang.sin()), -1).to(BF16).cuda()
+    ref_q = fused.rms_norm_rows(x, w, 1e-6)
+    ref_k = ref_q.clone()
+    K.rotary_pos_embedding(ref_q.view(batch, seq, D), ref_k.view(batch, seq, D), hd, cache, is_neox=False)
+    got = fused.rms_norm_rows(x, w, 1e-6, rope=cache, seq_len=seq, head_dim=hd)
+    assert torch.equal(got, ref_q) and torch.equal(got, ref_k)
+    assert not torch.equal(got, fused.rms_norm_rows(x, w, 1e-6))
+
+
 # every GroupNorm shape of the SDXL UNet at 1024^2 (batch 2 = CFG; incl. the up blocks' concatenated inputs) + small / odd ones:
 # a group of one vector per thread, a spatial size that is not a power of two, one slice per group
 GN_SHAPES = [(2, 320, 128, 128), (2, 960, 128, 128), (2, 640, 64, 64), (2, 1920, 64, 64), (2, 1280, 32, 32), (2, 2560, 32, 32),
