@@ -371,6 +371,55 @@ def test_radial_mask_and_sparse_attention_at_a14b_size():
 
 
 # ------------------------------------------------------------------ BASELINE.json configs[4]: ONE full forward at size and depth
+@pytest.mark.parametrize("mode", [1, 2])
+def test_quantised_sparse_attention_at_a14b_size(mode):
+    """The opt-in block-sparse quantised kernels (fdm_attn_fwd_quant_masked; mode 1: fp8 P.V, mode 2: fp8 QK^T + fp8 P.V -- the class of the
+    reference's SpargeAttn path, kernel/cuda/attention.py:77-147) on the A14B geometry with the reference's own radial mask: all 80 640 tokens,
+    40 heads x 128, against the oracle's definition (fp32 softmax over the keys of the kept blocks) on sampled query rows.  N(0, 1) q / k / v:
+    the tolerances are those of the dense quantised kernels at S = 8704 with the slack a 10 x longer key axis needs."""
+    import numpy as np
+    from fastdm_amd import _native as N
+    from fastdm_amd.kernel import fused
+    from fastdm_amd.sparse import SparseAttn
+    path = os.path.join(GOLD, "wan_radial_mask_a14b_768x1280x81f.npz")
+    if not os.path.exists(path):
+        pytest.skip("full-size radial mask fixture not generated")
+    g = np.load(path)
+    frames, tpf, bs = (int(v) for v in g["geom"])
+    S = frames * tpf
+    sa = SparseAttn.from_dict({"sparse_algorithm": "radial", "model_type": "wan", "block_size": bs, "enable_sparse": True,
+                               "decay_factor": float(g["decay"]), "dense_layers": 1, "dense_steps": 11})
+    sa.post_init(video_token_num=S, num_frame=frames)
+    km = sa.kernel_mask(S, torch.device("cuda"))
+    H, hd = 40, 128
+    D = H * hd
+    q, k, v = (fused.synth_fill(torch.empty((S, D), dtype=BF16, device="cuda"), seed, 0, 1.0 / 37837.0) for seed in (31, 32, 33))
+    mask = km[None, None].expand(1, H, -1, -1).contiguous()
+    out = torch.empty_like(q)
+    ws = N.attn_pvfp8_workspace(q.device, 1, S, H, hd, mode=mode)
+    N.check(N.lib().fdm_attn_fwd_quant_masked(N.ptr(out), N.ptr(q), N.ptr(k), N.ptr(v), 1, S, S, H, H, hd, D, D, D, D, hd ** -0.5, N.ptr(mask), 128, 64,
+                                              mode, N.ptr(ws), ws.numel(), N.stream()), "quantised radial block-sparse attention")
+    assert torch.isfinite(out[::1024].float()).all()
+    rows = torch.tensor([0, 1, 127, 128, 3839, 3840, 40320, 40321 + 128, S - 3841, S - 129, S - 1], device="cuda")
+    key_keep = km[(rows // 128)].bool().repeat_interleave(64, dim=1)
+    worst_max, worst_mean, sig_ = 0.0, 0.0, 1.0
+    for h in (0, 19, 39):
+        sl = slice(h * hd, (h + 1) * hd)
+        sc = (q[rows][:, sl].float() @ k[:, sl].float().t()) * hd ** -0.5
+        sc = sc.masked_fill(~key_keep, float("-inf"))
+        ref = torch.softmax(sc, dim=-1) @ v[:, sl].float()
+        d = (out[rows][:, sl].float() - ref).abs()
+        worst_max, worst_mean = max(worst_max, d.max().item()), max(worst_mean, d.mean().item())
+        sig_ = min(sig_, ref.abs().mean().item())
+    print(f"quantised sparse attention at A14B size, mode {mode}: max {worst_max:.2e} mean {worst_mean:.2e} on mean|ref| {sig_:.3f}")
+    assert worst_max <= QSPARSE_AT_SIZE[mode][0] and worst_mean <= QSPARSE_AT_SIZE[mode][1] and sig_ > 0.005, (worst_max, worst_mean, sig_)
+
+
+# (max, mean) |error|: measured 2.2e-3 / 4.8e-4 (mode 1) and 3.6e-3 / 6.6e-4 (mode 2) on mean|ref| 0.011 -- ~19 000 kept keys per row average
+# N(0, 1) values down to 0.007, and the e4m3 rounding of V (2^-4 relative per element) averages down with them: 4-6 % of the output, as dense
+QSPARSE_AT_SIZE = {1: (3.0e-3, 6.5e-4), 2: (5.0e-3, 9.0e-4)}
+
+
 def test_wan_a14b_full_depth_forward_sparse_dense_and_all_ones_mask():
     """Wan2.2-T2V-A14B fp8, 768 x 1280 x 81 frames (latents [1, 16, 21, 96, 160] -> 80 640 video tokens + 512 text tokens), all 40
     blocks, synthetic weights: one forward on a SPARSE step of the shipped radial config (layers >= dense_layers run the
