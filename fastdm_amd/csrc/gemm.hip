@@ -237,18 +237,33 @@ __device__ __forceinline__ void unpack4(const i32x2 v, float (&o)[4]) {
 
 // RES: the launch contains a FDM_EPI_GATE_RESIDUAL problem (a separate instantiation keeps that epilogue's
 // residual registers out of the common kernels).
-template <int DT, bool RES>
-__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup grp) {
+// NWN = 4: the 256 x 256 tile of 8 waves (2 x 4 wave tiles of 128 x 64), one block per CU.  NWN = 2 (round 5): a 256 x 128 HALF tile of 4 waves
+// (2 x 2 of the same wave tiles), 3 stages of 24 KiB so that TWO blocks share a CU -- the same 8 waves per CU, scheduled as two independent units:
+// launches whose tile count leaves most of a round empty (SD3.5's N = 2432: 350 tiles on 256 CUs; the SDXL level-2 layers: 40-120 tiles)
+// get twice the number of work items at half the size.  Same per-wave code: fragments, MFMA order, epilogue.
+template <int DT, bool RES, int NWN = 4>
+__global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp) {
   using M = Mma<DT>;
   using Acc = typename M::Acc;
   using Frag = typename M::Frag;
   constexpr int NS = BKB / M::KS;  // MFMA k-slices per step (1 for fp8, 2 for int8/bf16)
-  __shared__ __attribute__((aligned(1024))) uint8_t smem[NSTAGE * STAGE_BYTES];
+  constexpr int BNT = 64 * NWN;                    // tile width
+  constexpr int RPR = 32 * NWN;                    // rows one staging round of the block moves (threads / 4)
+  constexpr int RA = BM / RPR, RB = BNT / RPR;     // staging rounds per stage: A (2 / 4), B (2 / 2)
+  constexpr int RBYTES = RPR * BKB;                // LDS bytes of a round
+  constexpr int NSTG = NWN == 4 ? NSTAGE : 3;
+  constexpr int SBYTES = (BM + BNT) * BKB;
+  static_assert(NSTG * SBYTES >= 2 * NWN * 16384, "the epilogue's wave-private tiles live in the dead ring");
+  __shared__ __attribute__((aligned(1024))) uint8_t smem[NSTG * SBYTES];
+  auto slot_of = [](int kt) { return NSTG == 4 ? (kt & 3) : kt % 3; };
+  // s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt = bits 15:14 | 3:0, expcnt 6:4 and lgkmcnt 11:8 left at "no wait")
+  constexpr int VM1 = RA + RB, VM2 = 2 * (RA + RB);
+  constexpr int WAIT_VM1 = (VM1 & 15) | ((VM1 >> 4) << 14) | 0x0F70, WAIT_VM2 = (VM2 & 15) | ((VM2 >> 4) << 14) | 0x0F70;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / NWN, wn = wave % NWN;
 
   // ---- block -> (problem, tile): XCD-contiguous ranges of the concatenated tile list, grouped raster inside a problem
   int prob = 0, m0, n0;
@@ -291,7 +306,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
     const int gsz = min(pp.tiles_m - first_m, GROUP_M);
     const int rem = t - gid * in_group;
     m0 = (first_m + rem % gsz) * BM;
-    n0 = (rem / gsz) * BN;
+    n0 = (rem / gsz) * BNT;
   }
   const GemmProblem& p = grp.p[prob];
 #ifdef FDM_GEMM_STAMPS
@@ -312,15 +327,12 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
   // ---- staging: thread t, round i moves the 16-byte chunk that lands at (row = i*128 + t/4, slot = t%4)
   const int srow = tid >> 2;
   const int schunk = (tid & 3) ^ ((srow >> 2) & 3);  // source chunk for that slot
-  const uint8_t* ga[2];
-  const uint8_t* gb[2];
+  const uint8_t* ga[RA];
+  const uint8_t* gb[RB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ra = min(m0 + i * 128 + srow, p.M - 1);
-    const int rb = min(n0 + i * 128 + srow, p.N - 1);
-    ga[i] = p.A + (int64_t)ra * p.lda + k_off + schunk * 16;
-    gb[i] = p.B + (int64_t)rb * p.ldb + k_off + schunk * 16;
-  }
+  for (int i = 0; i < RA; ++i) ga[i] = p.A + (int64_t)min(m0 + i * RPR + srow, p.M - 1) * p.lda + k_off + schunk * 16;
+#pragma unroll
+  for (int i = 0; i < RB; ++i) gb[i] = p.B + (int64_t)min(n0 + i * RPR + srow, p.N - 1) * p.ldb + k_off + schunk * 16;
   const int nk = (int)((Kb + BKB - 1) / BKB);
 
   // Every step issues exactly 4 DMAs per wave, also past the end of K (then from a 16-byte zero page, which
@@ -328,35 +340,34 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
   // odd-step padding both multiply zeros.
   const uint8_t* zero_page = g_zero_page;
   auto stage = [&](int kt) {
-    uint8_t* sA = smem + (kt & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024;
+    uint8_t* sA = smem + slot_of(kt) * SBYTES + wave * 1024;
     uint8_t* sB = sA + BM * BKB;
     const int64_t koff = (int64_t)kt * BKB;
     const bool ok = koff + schunk * 16 < Kb;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(ok ? ga[i] + koff : zero_page, sA + i * 8192);
+    for (int i = 0; i < RA; ++i) glds16(ok ? ga[i] + koff : zero_page, sA + i * RBYTES);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(ok ? gb[i] + koff : zero_page, sB + i * 8192);
+    for (int i = 0; i < RB; ++i) glds16(ok ? gb[i] + koff : zero_page, sB + i * RBYTES);
   };
   // Steps whose whole 64-byte K slice lies inside K need no per-lane bounds select: the source is a wave-uniform base
   // (tile origin + K offset, SALU) plus a loop-invariant 32-bit lane offset, which the compiler can issue in the
   // saddr + voffset form -- no 64-bit VALU address math or v_cndmask in the steady state.
   const uint8_t* baseA = p.A + (int64_t)min(m0, p.M - 1) * p.lda + k_off;
   const uint8_t* baseB = p.B + (int64_t)min(n0, p.N - 1) * p.ldb + k_off;
-  uint32_t oa[2], ob[2];
+  uint32_t oa[RA], ob[RB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    oa[i] = (uint32_t)((min(m0 + i * 128 + srow, p.M - 1) - min(m0, p.M - 1)) * p.lda) + schunk * 16;
-    ob[i] = (uint32_t)((min(n0 + i * 128 + srow, p.N - 1) - min(n0, p.N - 1)) * p.ldb) + schunk * 16;
-  }
+  for (int i = 0; i < RA; ++i) oa[i] = (uint32_t)((min(m0 + i * RPR + srow, p.M - 1) - min(m0, p.M - 1)) * p.lda) + schunk * 16;
+#pragma unroll
+  for (int i = 0; i < RB; ++i) ob[i] = (uint32_t)((min(n0 + i * RPR + srow, p.N - 1) - min(n0, p.N - 1)) * p.ldb) + schunk * 16;
   auto stage_inner = [&](int kt) {
-    uint8_t* sA = smem + (kt & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024;
+    uint8_t* sA = smem + slot_of(kt) * SBYTES + wave * 1024;
     uint8_t* sB = sA + BM * BKB;
     const uint8_t* ka = baseA + (int64_t)kt * BKB;
     const uint8_t* kb = baseB + (int64_t)kt * BKB;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(ka + oa[i], sA + i * 8192);
+    for (int i = 0; i < RA; ++i) glds16(ka + oa[i], sA + i * RBYTES);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(kb + ob[i], sB + i * 8192);
+    for (int i = 0; i < RB; ++i) glds16(kb + ob[i], sB + i * RBYTES);
   };
 
   // ---- fragment read addresses (byte offsets inside a stage)
@@ -375,7 +386,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
     }
   };
   auto read_a = [&](int kt, int i) {
-    const uint8_t* st = smem + (kt & (NSTAGE - 1)) * STAGE_BYTES + a_row_off + i * 32 * BKB;
+    const uint8_t* st = smem + slot_of(kt) * SBYTES + a_row_off + i * 32 * BKB;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       int c0, c1;
@@ -384,7 +395,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
     }
   };
   auto read_b = [&](Frag (&fb)[NS][2], int kt) {
-    const uint8_t* st = smem + (kt & (NSTAGE - 1)) * STAGE_BYTES + b_row_off;
+    const uint8_t* st = smem + slot_of(kt) * SBYTES + b_row_off;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       int c0, c1;
@@ -404,7 +415,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
 
   // int8 split-K tail, merge launch: the accumulators are the sum of the parts' int32 partials (exact), no K loop
   bool merged = false;
-  if constexpr (DT == DT_INT8) {
+  if constexpr (DT == DT_INT8 && NWN == 4) {      // (the split-K tail's workspace layout is the 8-wave block's; half tiles are never split)
     if (grp.mode == 1) {
       // A CU pulls ~11 B/clk, so reading S x 256 KB through one CU costs as much as a good part of the K loop it replaces:
       // a tile is merged by 1, 2 or 4 blocks (as many as fit one round), each running the waves of its share of the tile
@@ -431,7 +442,8 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
     stage(0);
     stage(1);
     stage(2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(WAIT_VM2);      // stage 0 has landed (stages 1, 2 in flight)
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < 4; ++i) read_a(0, i);
@@ -443,7 +455,13 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
     // One step: wait for DMA(t+1) (leaving DMA(t+2) in flight), barrier, issue DMA(t+3), then MFMA(t) with the
     // fragments of step t+1 streaming in behind it.
     auto step = [&](auto inner_c, Frag (&bc)[NS][2], Frag (&bn)[NS][2], int t) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if constexpr (NSTG == 3) {
+        // three stages: the DMAs issued below refill the slot whose fragments were requested during the previous step -- every wave's reads
+        // must have returned before any wave passes the barrier (with four stages that slot has been idle for a whole step)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_waitcnt(WAIT_VM1);      // stage t + 1 has landed (stage t + 2 stays in flight)
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #if FDM_GEMM_SPREAD_DMA
       // (experiment) one DMA behind each of the four MFMA groups instead of a burst of four behind the barrier
@@ -493,7 +511,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // retire the padding DMAs and the dead fragment reads
   __builtin_amdgcn_s_barrier();                                  // every wave is done with the ring: reuse it below
-  if constexpr (DT == DT_INT8) {
+  if constexpr (DT == DT_INT8 && NWN == 4) {
     if (grp.mode == 1 && (wave >> (3 - grp.spread_shift)) != (int)(blockIdx.x & ((1 << grp.spread_shift) - 1))) return;   // merge launch: the other quarters belong to sibling blocks
     if (is_part) {   // int32 partial sums of this K range -> workspace; the merge launch runs the epilogue
       int32_t* dst = grp.ws + ((int64_t)part_slot) * (32 * 512 * 4) + tid * 4;
@@ -520,7 +538,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_kernel(const GemmGroup g
   // n = wn*64 + j*32 + 8*q + 4*(lane>>5) + (0..3) for register quad q = e>>2, i.e. 8-byte pieces [m][chunk j*4+q][half g].
   // Wave-private LDS tile: 128 rows x 128 B, 16-byte chunk c of row r stored at chunk c ^ (r & 7).
   uint8_t* wt = smem + wave * 16384;
-  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  const bool full = (m0 + BM <= p.M) && (n0 + BNT <= p.N);
   auto epilogue = [&](auto epi_c) {
     constexpr int EPI = decltype(epi_c)::value;
     // pass 1: scale / bias / activation, round to bf16, write 8-byte pieces to the LDS tile
@@ -1596,6 +1614,35 @@ static bool use_p4(const GemmGroup& grp, P4Args& pa) {
   return true;
 }
 
+// Do 256 x 128 half tiles (two 4-wave blocks per CU) beat 256 x 256 tiles (one 8-wave block per CU) for this launch of the 8-wave kernel?
+// Unit = the time of one full tile on a CU.  Full tiles: whole rounds + one more for any remainder.  Half tiles move 1.5 x the LDS bytes per
+// flop, so two of them side by side on a CU take h2 > 1 units and one alone h1 > 0.5 -- both grow with K as the fixed cost of a tile
+// amortises (fitted to tools/micro/gemm_bench on MI355X, profiles/r05_experiments.md: h2 = 1.02 / 1.17 / 1.32 and h1 = 0.61 / 0.65 / 0.69 at
+// K = 640 / 2432 / 9728 bytes).  They pay for sub-round launches (SDXL's 40 - 240 tile layers: -16 ... -40 %) and for a short K with a
+// nearly empty last round (SD3.5 N = K = 2432: -9 %); not for long K or many rounds.  FDM_GEMM_HALF_TILES = 0 | 1 forces the answer (A/B).
+static bool half_tiles_pay(const GemmGroup& grp) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("FDM_GEMM_HALF_TILES");
+    forced = e ? atoi(e) : -1;
+  }
+  if (grp.splits > 1 || grp.mode != 0) return false;
+  if (forced >= 0) return forced != 0;
+  const int cu = device_cu_count();
+  int half = 0;
+  int64_t kb = grp.p[0].Kb;
+  for (int i = 0; i < grp.n; ++i) {
+    half += grp.p[i].tiles_m * (int)((grp.p[i].N + BN / 2 - 1) / (BN / 2));
+    kb = kb > grp.p[i].Kb ? kb : grp.p[i].Kb;
+  }
+  const float lk = log2f((float)(kb > 512 ? kb : 512) / 512.0f);
+  const float h2 = 1.0f + 0.075f * lk, h1 = 0.6f + 0.02f * lk;
+  const float t_full = (float)((grp.total_tiles + cu - 1) / cu);
+  const int rem = half % (2 * cu);
+  const float t_half = (float)(half / (2 * cu)) * h2 + (rem == 0 ? 0.f : (rem <= cu ? h1 : h2));
+  return t_half < t_full - 0.05f;
+}
+
 constexpr int64_t SPLIT_PART_BYTES = (int64_t)BM * BN * 4;   // one K part of one tile: 256 x 256 int32
 static thread_local int g_last_gemm_kernel = -1;              // fdm_gemm_last_kernel()
 
@@ -1679,6 +1726,18 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, 
     if (res) gemm_w4_kernel<DT, true><<<grid, W4_THREADS, 0, s>>>(grp);
     else gemm_w4_kernel<DT, false><<<grid, W4_THREADS, 0, s>>>(grp);
     g_last_gemm_kernel = FDM_GEMM_KERNEL_W4;
+  } else if (half_tiles_pay(grp)) {
+    // 256 x 128 half tiles, two 4-wave blocks per CU (gemm_kernel<.., 2>): same wave code, twice the work items
+    GemmGroup g2 = grp;
+    g2.total_tiles = 0;
+    for (int i = 0; i < g2.n; ++i) {
+      g2.p[i].tiles_n = (int)((g2.p[i].N + BN / 2 - 1) / (BN / 2));
+      g2.total_tiles += g2.p[i].tiles_m * g2.p[i].tiles_n;
+    }
+    g2.n_blocks = g2.total_tiles;
+    if (res) gemm_kernel<DT, true, 2><<<g2.total_tiles, GEMM_THREADS / 2, 0, s>>>(g2);
+    else gemm_kernel<DT, false, 2><<<g2.total_tiles, GEMM_THREADS / 2, 0, s>>>(g2);
+    g_last_gemm_kernel = FDM_GEMM_KERNEL_W8;
   } else {
     if (res) gemm_kernel<DT, true><<<grid, GEMM_THREADS, 0, s>>>(grp);
     else gemm_kernel<DT, false><<<grid, GEMM_THREADS, 0, s>>>(grp);

@@ -499,6 +499,28 @@ def test_gemm_p4_persistent_assembly_is_bit_identical_to_gemm_w4():
         assert out["w4"][name][1] == out["p4"][name][1], f"{name}: gemm_p4_kernel differs from gemm_w4_kernel"
 
 
+def test_gemm_half_tiles_are_bit_identical_to_full_tiles():
+    """gemm_kernel<.., 2> (256 x 128 half tiles, two 4-wave blocks per CU: SDXL's sub-round layers, SD3.5's N = K = 2432) runs the per-wave code
+    of the 256 x 256 form -- same fragments, same MFMAs in the same K order, same epilogue -- so every output bit must agree: fp8 / int8 (+ zero
+    points) / bf16, every epilogue, ragged M / N / K, a strided output, two problems in one launch with plane outputs.  The policy is read once per
+    process: tests/gemm_half_tile_worker.py runs under FDM_GEMM_HALF_TILES = 0 and = 1 (FDM_GEMM_KERNEL=w8 keeps every case on the 8-wave kernel)."""
+    import json
+    import subprocess
+    import sys
+    from fastdm_amd import _native as N
+    N.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag in ("0", "1"):
+        env = dict(os.environ, FDM_GEMM_HALF_TILES=tag, FDM_GEMM_KERNEL="w8")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "gemm_half_tile_worker.py")], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(out["0"]) >= 11
+    for name in out["0"]:
+        assert out["0"][name] == out["1"][name], f"{name}: half tiles differ from full tiles"
+
+
 def test_bf16_gemm_and_epilogues():
     from fastdm_amd import _native as N
     g = gen(5)
