@@ -1538,6 +1538,10 @@ static bool use_w4(const GemmGroup& grp) {
   // 188.4 -> 178.6; SDXL unchanged.
   // (ragged N / K in the 4-wave kernel: SD3.5-large N = K = 2432 56.9 -> 56.6 ms per step, SDXL 45.4 -> 44.5: within noise, not taken)
   const bool many_rounds = grp.total_tiles >= device_cu_count();
+  // at most half a round of tiles: the 8-wave kernel's 256 x 128 half tiles (two blocks per CU) put twice as many CUs to work -- round 5,
+  // tools/micro/gemm_bench: SDXL level 2 M = 2048, N = 1280, K = 5120 (40 tiles) 55.3 -> 42.4 us, M = 512 52 -> 42, N = K = 2560 35 -> 27;
+  // above that (192 tiles: 44.1 vs 46-54) this kernel stays ahead
+  if (grp.total_tiles * 2 <= device_cu_count()) return false;
   for (int i = 0; i < grp.n; ++i) {
     const GemmProblem& q = grp.p[i];
     if (q.Kb < 2048) return false;
