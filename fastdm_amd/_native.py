@@ -244,9 +244,22 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def stream():
+_raw_stream = None
+
+
+def stream(device_index=None):
+    """HIP stream handle of torch's current stream (of `device_index`, default: the current device).  Every launch asks for it, so it takes the
+    two C calls behind torch.cuda.current_stream() directly: building the torch.cuda.Stream object costs 5-8 us per call (it probes the device
+    count), which was a quarter of the host time of an eager SDXL step (cProfile, round 5)."""
+    global _raw_stream
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    if _raw_stream is None:
+        raw, cur = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if raw is not None and cur is not None:
+            _raw_stream = lambda idx: raw(cur() if idx is None else idx)
+        else:
+            _raw_stream = lambda idx: torch.cuda.current_stream(idx).cuda_stream
+    return _raw_stream(device_index)
 
 
 _attn_ws = {}
@@ -272,7 +285,7 @@ def attn_pvfp8_workspace(device, batch, sk, kv_heads, head_dim, mode=1):
     every call; grows to the largest shape seen."""
     import torch
     dev = device.index if device.index is not None else torch.cuda.current_device()
-    key = (dev, int(torch.cuda.current_stream(dev).cuda_stream))
+    key = (dev, int(stream(dev)))
     fn = lib().fdm_attn_fp8_workspace_bytes if mode == 2 else lib().fdm_attn_pvfp8_workspace_bytes
     need = int(fn(batch, sk, kv_heads, head_dim))
     ws = _attn_vq_ws.get(key)
@@ -300,7 +313,7 @@ def gemm_int8_workspace(device, pin=False):
     lives, so it must never go back to the allocator."""
     import torch
     dev = device.index if device.index is not None else torch.cuda.current_device()
-    key = (dev, int(torch.cuda.current_stream(dev).cuda_stream))
+    key = (dev, int(stream(dev)))
     capturing = torch.cuda.is_current_stream_capturing()
     ws = _gemm_ws.get(key)
     if ws is None:

@@ -127,7 +127,7 @@ def group_norm(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Te
         y = F.group_norm(x if addend is None else x + addend[:, :, None, None], groups, gamma, beta, eps)
         return F.silu(y) if silu else y
     need = N.lib().fdm_group_norm_workspace_bytes(B, C, hw, groups)
-    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+    key = (x.device.index, N.stream(x.device.index))
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _gn_ws[key] = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=x.device)
