@@ -55,6 +55,7 @@ SIGNATURES = {
     "fdm_gelu_and_mul_quant": (I32, [P, P, P, I32, P, I64, I32, P]),
     "fdm_gelu": (I32, [P, P, I64, I32, P]),
     "fdm_quant_rowwise_cat2": (I32, [P, P, P, I32, P, I32, I64, P, I32, I64, I64, P]),
+    "fdm_quant_rowwise_cat2_act": (I32, [P, P, P, I32, P, I32, I64, I32, P, I32, I64, I32, I64, P]),
     "fdm_qk_norm_rope": (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, I32, I32, F32, P]),
     "fdm_qk_norm_rope_inplace": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, I32, F32, P]),
     "fdm_absdiff_sums": (I32, [P, P, P, I64, P]),
@@ -66,7 +67,7 @@ SIGNATURES = {
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
 }
 
-ABI_VERSION = 18         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
+ABI_VERSION = 19         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL, EPI_GATE_RESIDUAL_F32 = 0, 1, 2, 3, 4
 
 

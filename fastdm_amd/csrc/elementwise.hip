@@ -353,7 +353,23 @@ __device__ __forceinline__ void quant_row_cached(const Vec8 (&x)[MAXV], int nvec
 }
 
 // Virtual concatenation of two sources so proj_out's K=15360 row never exists in bf16.
-template <int THREADS, int MODE, bool SW, int NIT = 0>
+// ACT (round 6): an activation applied to a source's values on the way in -- bits 0-1 source 0, bits 2-3 source 1; 0 none, 1 tanh-GELU,
+// 2 erf-GELU: x := bf16(gelu(x)), the arithmetic of the GEMM epilogues (common.h: fast_gelu_*), so a W8A8 feed-forward can run its first
+// GEMM with the PLAIN epilogue and leave the activation to this HBM-bound pass.  Why: in the GEMMs (one wave per SIMD, MFMA-issue-bound) the
+// GELU drain of a 256 x 256 tile is 9-20 k cycles that one K step's MFMAs cannot cover (FLUX: 323 vs 265 us per launch at N = 12288); here
+// the same VALU work hides under the row's HBM / Infinity-Cache reads.  Same roundings in the same order: bit-identical to epilogue + quantiser.
+template <int ACT>
+__device__ __forceinline__ void act8(Vec8& x) {
+  if constexpr (ACT == 1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x.v[j] = rbf(fast_gelu_tanh(x.v[j]));
+  } else if constexpr (ACT == 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x.v[j] = rbf(fast_gelu_erf(x.v[j]));
+  }
+}
+
+template <int THREADS, int MODE, bool SW, int NIT = 0, int ACT = 0>
 __global__ void __launch_bounds__(THREADS) quant_rowwise_kernel(uint8_t* __restrict__ q, float* __restrict__ scale,
                                                                 int32_t* __restrict__ azp,
                                                                 const bf16_t* __restrict__ s0, int w0, int64_t st0,
@@ -371,6 +387,17 @@ __global__ void __launch_bounds__(THREADS) quant_rowwise_kernel(uint8_t* __restr
       // one address, one load: a select between two loads would issue both
       const bf16_t* src = (v < nv0) ? s0 + row * st0 + (size_t)v * 8 : s1 + row * st1 + (size_t)(v - nv0) * 8;
       x[i] = load8(src);
+    }
+  }
+  if constexpr (ACT != 0) {
+    // after ALL loads are in flight (the activation of vector 0 runs while vector NIT - 1 is still on its way)
+#pragma unroll
+    for (int i = 0; i < It::N; ++i) {
+      const int v = It::ld(i, (int)threadIdx.x + i * THREADS, nvec);
+      if (NIT || (int)threadIdx.x + i * THREADS < nvec) {
+        if (v < nv0) act8<(ACT & 3)>(x[i]);
+        else act8<((ACT >> 2) & 3)>(x[i]);
+      }
     }
   }
   quant_row_cached<THREADS, MODE, SW, NIT>(x, nvec, q + row * (int64_t)(w0 + w1), scale, azp, row, smem);
@@ -989,27 +1016,27 @@ static inline int grid_for(int64_t work, int threads, int cap = 256 * 8) {
 }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <int MODE>
+template <int MODE, int ACT = 0>
 static int launch_quant(void* q, float* scale, int32_t* azp, const bf16_t* s0, int w0, int64_t st0, const bf16_t* s1, int w1,
                         int64_t st1, int64_t rows, hipStream_t s) {
   const int hidden = w0 + w1;
   const bool sw = g_fp8_sw_cvt;   // constexpr false in the product build
   auto qq = (uint8_t*)q;
-#define FDM_QNIT(T, NITV) quant_rowwise_kernel<T, MODE, false, NITV><<<(unsigned)rows, T, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1)
+#define FDM_QNIT(T, NITV) quant_rowwise_kernel<T, MODE, false, NITV, ACT><<<(unsigned)rows, T, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1)
 #define FDM_QROW(T)                                                                                                      \
-  if (sw) quant_rowwise_kernel<T, MODE, true><<<(unsigned)rows, T, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1);     \
+  if (sw) quant_rowwise_kernel<T, MODE, true, 0, ACT><<<(unsigned)rows, T, 0, s>>>(qq, scale, azp, s0, w0, st0, s1, w1, st1);     \
   else switch (((hidden >> 3) + T - 1) / T) {                                                                             \
     case 1: FDM_QNIT(T, 1); break; case 2: FDM_QNIT(T, 2); break; case 3: FDM_QNIT(T, 3); break; case 4: FDM_QNIT(T, 4); break; \
     case 5: FDM_QNIT(T, 5); break; case 6: FDM_QNIT(T, 6); break; case 7: FDM_QNIT(T, 7); break; default: FDM_QNIT(T, 8); break; \
   }
-  if (hidden <= 4096) {
+  if (hidden <= 4096 && ACT == 0) {
     FDM_QROW(64)
   } else if (hidden <= MAXV * 256 * 8) {
     FDM_QROW(256)
 #undef FDM_QROW
 #undef FDM_QNIT
   } else {
-    if (s1 != nullptr) return FDM_ERR_UNSUPPORTED;
+    if (s1 != nullptr || ACT != 0) return FDM_ERR_UNSUPPORTED;
     if (sw) quant_rowwise_wide_kernel<MODE, true><<<(unsigned)rows, 256, 0, s>>>(qq, scale, azp, s0, hidden, st0);
     else quant_rowwise_wide_kernel<MODE, false><<<(unsigned)rows, 256, 0, s>>>(qq, scale, azp, s0, hidden, st0);
   }
@@ -1185,9 +1212,11 @@ int fdm_rope_inplace(void* q, void* k, const void* cos_sin_cache, int64_t tokens
   return FDM_OK;
 }
 
-int fdm_quant_rowwise_cat2(void* q_out, float* scale_out, int32_t* azp_out, int quant_mode, const void* src0, int w0,
-                           int64_t stride0, const void* src1, int w1, int64_t stride1, int64_t rows, fdm_stream_t stream) {
+int fdm_quant_rowwise_cat2_act(void* q_out, float* scale_out, int32_t* azp_out, int quant_mode, const void* src0, int w0,
+                               int64_t stride0, int act0, const void* src1, int w1, int64_t stride1, int act1, int64_t rows,
+                               fdm_stream_t stream) {
   (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (act0 < 0 || act0 > 2 || act1 < 0 || act1 > 2) return FDM_ERR_INVALID;
   if (rows == 0 && w0 > 0 && !(w0 & 7) && w1 >= 0 && !(w1 & 7)) return FDM_OK;
   if (!q_out || !scale_out || !src0 || w0 <= 0 || (w0 & 7) || (w1 & 7) || w1 < 0 || (stride0 & 7) || (stride1 & 7) || rows < 0)
     return FDM_ERR_INVALID;
@@ -1195,15 +1224,34 @@ int fdm_quant_rowwise_cat2(void* q_out, float* scale_out, int32_t* azp_out, int 
   if (!aligned16(src0) || !aligned16(src1) || (reinterpret_cast<uintptr_t>(q_out) & 7)) return FDM_ERR_INVALID;
   if (quant_mode == 2 && !azp_out) return FDM_ERR_INVALID;
   if (rows == 0) return FDM_OK;
+  if (w1 == 0) act1 = 0;
   hipStream_t s = to_stream(stream);
   auto a = (const bf16_t*)src0;
   auto b = (const bf16_t*)src1;
+  const int act = act0 | (act1 << 2);
+  // the activation forms are instantiated for the call sites that exist: a GELU on the only source (feed-forward) or on the second of two
+  // (FLUX single block: [attention | gelu(mlp)]); fp8 and int8-asym
+#define FDM_QACT(M)                                                                                                       \
+  switch (act) {                                                                                                          \
+    case 0: return launch_quant<M, 0>(q_out, scale_out, azp_out, a, w0, stride0, b, w1, stride1, rows, s);                \
+    case 1: return launch_quant<M, 1>(q_out, scale_out, azp_out, a, w0, stride0, b, w1, stride1, rows, s);                \
+    case 2: return launch_quant<M, 2>(q_out, scale_out, azp_out, a, w0, stride0, b, w1, stride1, rows, s);                \
+    case 4: return launch_quant<M, 4>(q_out, scale_out, azp_out, a, w0, stride0, b, w1, stride1, rows, s);                \
+    case 8: return launch_quant<M, 8>(q_out, scale_out, azp_out, a, w0, stride0, b, w1, stride1, rows, s);                \
+    default: return FDM_ERR_UNSUPPORTED;                                                                                  \
+  }
   switch (quant_mode) {
-    case 1: return launch_quant<1>(q_out, scale_out, azp_out, a, w0, stride0, b, w1, stride1, rows, s);
-    case 2: return launch_quant<2>(q_out, scale_out, azp_out, a, w0, stride0, b, w1, stride1, rows, s);
-    case 3: return launch_quant<3>(q_out, scale_out, azp_out, a, w0, stride0, b, w1, stride1, rows, s);
+    case 1: FDM_QACT(1)
+    case 2: FDM_QACT(2)
+    case 3: if (act) return FDM_ERR_UNSUPPORTED; return launch_quant<3>(q_out, scale_out, azp_out, a, w0, stride0, b, w1, stride1, rows, s);
     default: return FDM_ERR_UNSUPPORTED;
   }
+#undef FDM_QACT
+}
+
+int fdm_quant_rowwise_cat2(void* q_out, float* scale_out, int32_t* azp_out, int quant_mode, const void* src0, int w0,
+                           int64_t stride0, const void* src1, int w1, int64_t stride1, int64_t rows, fdm_stream_t stream) {
+  return fdm_quant_rowwise_cat2_act(q_out, scale_out, azp_out, quant_mode, src0, w0, stride0, 0, src1, w1, stride1, 0, rows, stream);
 }
 
 int fdm_quant_fp8_rowwise(void* q_out, float* scale_out, const void* in, int64_t rows, int hidden, int64_t in_row_stride,

@@ -161,30 +161,8 @@ __device__ __forceinline__ uint32_t lds_addr_of(const uint8_t* p) {
   return (uint32_t)reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) uint8_t*)p);
 }
 
-// cheap activations for the epilogue (libm tanhf/erff cost ~40 VALU each; x128 values per lane that is
-// longer than the K=3072 main loop).  |error| <= ~2e-7 absolute before the bf16 rounding.
-__device__ __forceinline__ float fast_gelu_tanh(float x) {
-  // 0.5 x (1 + tanh(u)) = x - x / (exp(2u) + 1), 2u log2(e) = x (c0 + c1 x^2): 4 plain VALU + exp2 + rcp.  Rounded to bf16 this
-  // equals the textbook form for every bf16 input (checked exhaustively on the host).
-  const float c0 = 0.79788456080286535588f * 2.885390081777927f, c1 = c0 * 0.044715f;
-  const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, c1, c0));
-  return __builtin_fmaf(-x, __builtin_amdgcn_rcpf(e + 1.0f), x);
-}
-__device__ __forceinline__ float fast_gelu_erf(float x) {
-  // Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): erf(z) = 1 - poly(t) exp(-z^2), t = 1/(1 + p z), z >= 0.
-  // The polynomial is evaluated with explicit FMAs (the file is built with -ffp-contract=off for the torch-faithful
-  // op chains elsewhere; here contraction only changes an approximation's last bit).
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-  float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
-  poly = __builtin_fmaf(t, poly, 1.421413741f);
-  poly = __builtin_fmaf(t, poly, -0.284496736f);
-  poly = __builtin_fmaf(t, poly, 0.254829592f);
-  poly *= t;
-  const float er = __builtin_fmaf(-poly, __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f), 1.0f);
-  const float erf_x = x < 0.f ? -er : er;
-  return 0.5f * x * (1.0f + erf_x);
-}
+// (fast_gelu_tanh / fast_gelu_erf, the cheap activations of the epilogues, live in common.h: the row-quantisation kernels of
+// elementwise.hip apply the same two functions when the activation is deferred to them -- fdm_quant_rowwise_cat2_act)
 
 // The same activations over 16 independent values, written stage by stage: hipcc packs neighbouring scalar f32 ops into
 // v_pk_* instructions, and a v_pk_* that consumes the previous instruction's result costs a wait state (s_nop); with 16

@@ -146,15 +146,19 @@ def gelu(x: torch.Tensor, approximate: str = "none") -> torch.Tensor:
     return out
 
 
-def quantize_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], quant) -> Quantized:
-    """Per-row quantisation of [x0 | x1] without materialising the concatenation (model/flux.py:69)."""
+def quantize_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], quant, act0: int = 0, act1: int = 0) -> Quantized:
+    """Per-row quantisation of [x0 | x1] without materialising the concatenation (model/flux.py:69).
+    act0 / act1 (N.EPI_GELU_TANH / N.EPI_GELU_ERF): that source holds PRE-activations -- bf16(gelu(x)) is applied on the way in, the
+    arithmetic of the GEMM's GELU epilogue followed by this quantiser (bit-identical), at the price of an HBM-bound pass's idle VALU slots
+    instead of an MFMA-bound kernel's drain (layer/activations.py:38-41 + layer/qlinear.py:62-66 of the reference)."""
     rows, w0 = x0.shape
     w1 = 0 if x1 is None else x1.shape[1]
     assert x0.stride(1) == 1 and (x1 is None or (x1.stride(1) == 1 and x1.shape[0] == rows))
+    assert act0 in (0, N.EPI_GELU_TANH, N.EPI_GELU_ERF) and act1 in (0, N.EPI_GELU_TANH, N.EPI_GELU_ERF)
     qz = _alloc_q(rows, w0 + w1, quant, x0.device)
-    N.check(N.lib().fdm_quant_rowwise_cat2(N.ptr(qz.q), N.ptr(qz.scale), N.ptr(qz.azp), QUANT_MODE[quant], N.ptr(x0), w0,
-                                           x0.stride(0), N.ptr(x1), w1, 0 if x1 is None else x1.stride(0), rows, N.stream()),
-            "quant_rowwise")
+    N.check(N.lib().fdm_quant_rowwise_cat2_act(N.ptr(qz.q), N.ptr(qz.scale), N.ptr(qz.azp), QUANT_MODE[quant], N.ptr(x0), w0,
+                                               x0.stride(0), act0, N.ptr(x1), w1, 0 if x1 is None else x1.stride(0), act1, rows,
+                                               N.stream()), "quant_rowwise")
     return qz
 
 

@@ -8,6 +8,13 @@ from collections import defaultdict
 import torch
 
 _active = None
+shape_log = None     # a list while tools/gemm_by_shape.py records one forward: every GEMM launch's [(M, N, K, epilogue), ...] in launch order
+
+
+def log_gemm(dtype: str, problems):
+    """One GEMM launch (one or two problems) for the per-dispatch table of tools/gemm_by_shape.py; a no-op unless that tool is recording."""
+    if shape_log is not None:
+        shape_log.append({"dtype": dtype, "problems": [list(map(int, p)) for p in problems if p[0] > 0]})
 GEMM_KERNEL_NAMES = {0: "fdm::gemm_kernel", 1: "fdm::gemm_w4_kernel", 2: "fdm::gemm_p4_kernel", 3: "fdm::gemv_bf16_kernel"}   # fdm_gemm_last_kernel()
 
 

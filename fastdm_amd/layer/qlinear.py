@@ -13,6 +13,7 @@ import torch
 from fastdm_amd import _native as N
 from fastdm_amd.kernel import fused
 from fastdm_amd.kernel.fused import Quantized
+from fastdm_amd.kernel import timing
 from fastdm_amd.kernel.timing import span
 
 BF16 = torch.bfloat16
@@ -98,8 +99,10 @@ class QLinear:
         self.bias = d["b"].to(dev) if "b" in d else None
 
     # ------------------------------------------------------------------ forward
-    def quantize_input(self, x2d: torch.Tensor) -> Quantized:
-        return fused.quantize_rows(x2d, None, self.quant_type)
+    def quantize_input(self, x2d: torch.Tensor, act: int = 0) -> Quantized:
+        """Per-token quantisation of this layer's input; act = N.EPI_GELU_TANH / N.EPI_GELU_ERF: x2d holds the pre-activations of the
+        GELU in front of this layer and bf16(gelu(x)) is applied in the same pass (fused.quantize_rows)."""
+        return fused.quantize_rows(x2d, None, self.quant_type, act0=act)
 
     def forward_q(self, x, epilogue: int = N.EPI_NONE, gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                   rows_per_batch: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -114,6 +117,7 @@ class QLinear:
         g_ptr, g_stride = (N.ptr(gate), gate.stride(0)) if gate is not None else (None, 0)
         lib = N.lib()
         flops = 2.0 * M * Nn * K
+        timing.log_gemm("fp8" if self.quant_type == FP8 else "int8" if self.quant_type == torch.int8 else "bf16", [(M, Nn, K, epilogue)])
         if self.quant_type == FP8:
           with span("gemm_w8a8_fp8_res" if epilogue >= N.EPI_GATE_RESIDUAL else "gemm_w8a8_fp8", flops):
             N.check(lib.fdm_gemm_w8a8_fp8(N.ptr(out), N.ptr(a), N.ptr(wt), N.ptr(x.scale), N.ptr(self.weight_quant_scale),
@@ -163,6 +167,7 @@ class QLinear:
             import ctypes
             d0, o0, f0 = lin0._desc(x0, epilogue, gate0, res0, rpb0, out0)
             d1, o1, f1 = lin1._desc(x1, epilogue, gate1, res1, rpb1, out1)
+            timing.log_gemm("fp8", [(d0.M, d0.N, d0.K, epilogue), (d1.M, d1.N, d1.K, epilogue)])
             with span("gemm_w8a8_fp8_res" if epilogue >= N.EPI_GATE_RESIDUAL else "gemm_w8a8_fp8", f0 + f1):
                 N.check(N.lib().fdm_gemm_w8a8_fp8_x2(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "fp8 linear pair")
             return o0, o1
@@ -170,6 +175,7 @@ class QLinear:
             import ctypes
             d0, o0, f0 = lin0._desc(x0, epilogue, gate0, res0, rpb0, out0)
             d1, o1, f1 = lin1._desc(x1, epilogue, gate1, res1, rpb1, out1)
+            timing.log_gemm("int8", [(d0.M, d0.N, d0.K, epilogue), (d1.M, d1.N, d1.K, epilogue)])
             with span("gemm_w8a8_int8_res" if epilogue >= N.EPI_GATE_RESIDUAL else "gemm_w8a8_int8", f0 + f1):
                 ws = N.gemm_int8_workspace(x0.q.device)
                 N.check(N.lib().fdm_gemm_w8a8_int8_x2_ws(ctypes.byref(d0), ctypes.byref(d1), N.ptr(ws), ws.numel(), N.stream()), "int8 linear pair")
@@ -193,6 +199,7 @@ class QLinear:
                 a = x
                 assert a.dtype == lin.dtype and a.stride(1) == 1
                 for pl in range(P_):
+                    timing.log_gemm("bf16", [(a.shape[0], Cc, K, N.EPI_NONE)])
                     with span("gemm_bf16", 2.0 * a.shape[0] * Cc * K):
                         N.check(N.lib().fdm_gemm_bf16(N.ptr(planes[pl, r0:]), N.ptr(a), N.ptr(wt[:, pl * Cc:]),
                                                       N.ptr(lin.bias[pl * Cc:]) if lin.bias is not None else None, a.shape[0], Cc, K,
@@ -209,6 +216,7 @@ class QLinear:
             else:
                 d1, f1 = type(d0)(), 0.0
                 d1.M, d1.N, d1.K = 0, 1, 1          # an empty problem: skipped by the library
+            timing.log_gemm("fp8" if qt == FP8 else "int8", [(d0.M, d0.N, d0.K, N.EPI_NONE), (d1.M, d1.N, d1.K, N.EPI_NONE)])
             with span("gemm_w8a8_fp8" if qt == FP8 else "gemm_w8a8_int8", f0 + f1):
                 if qt == FP8:
                     N.check(N.lib().fdm_gemm_w8a8_fp8_x2(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "plane-split linear")

@@ -30,20 +30,34 @@ class FeedForward:
         self.act_fn = _ActProj(dim, inner_dim, bias, data_type)            # keeps the reference attribute path act_fn.proj
         self.ff_out_proj = QLinear(inner_dim, dim_out or dim, bias=bias, data_type=data_type)
 
+    # The GELU between the two linears.  W8A8 (fp8 / int8): the first GEMM runs with the PLAIN epilogue and the activation rides in the
+    # per-token quantisation pass of the second linear's input (fused.quantize_rows(act0=...): same roundings in the same order, bit-identical
+    # to GELU epilogue + quantiser).  The GEMMs are MFMA-issue-bound with one wave per SIMD -- a tile's GELU drain (9-20 k cycles of VALU)
+    # cannot hide under one K step -- while the quantiser is HBM-bound with idle VALU slots (round 6: FLUX 323 -> 265 us per FF1 launch).
+    # bf16 layers (no quantiser in between) keep the GELU in the GEMM epilogue.
+    def _act_split(self):
+        """(epilogue of the first GEMM, activation of the quantiser in front of the second)"""
+        return (N.EPI_NONE, self.epilogue) if self.ff_out_proj.quant_type is not None else (self.epilogue, 0)
+
     def forward_fused(self, xq, gate: torch.Tensor, res: torch.Tensor, rows_per_batch: int, gate_epilogue: int = N.EPI_GATE_RESIDUAL) -> torch.Tensor:
         """res + gate * W2(gelu(W1 x)); xq = quantised (or bf16) [M, D] input; returns the new residual stream.
         gate_epilogue = N.EPI_GATE_RESIDUAL_F32 for Wan's fp32 gates."""
-        h = self.act_fn.proj.forward_q(xq, epilogue=self.epilogue)
-        hq = self.ff_out_proj.quantize_input(h) if self.ff_out_proj.quant_type is not None else h
+        epi, act = self._act_split()
+        h = self.act_fn.proj.forward_q(xq, epilogue=epi)
+        hq = self.ff_out_proj.quantize_input(h, act) if self.ff_out_proj.quant_type is not None else h
         return self.ff_out_proj.forward_q(hq, epilogue=gate_epilogue, gate=gate, res=res, rows_per_batch=rows_per_batch, out=res)
 
     @staticmethod
     def forward_fused_pair(ff0, xq0, gate0, res0, rpb0, ff1, xq1, gate1, res1, rpb1):
         """The image- and text-stream FFNs of a double block side by side: each GEMM pair is one launch."""
         from fastdm_amd.layer.qlinear import QLinear as QL
-        h0, h1 = QL.forward_q_pair(ff0.act_fn.proj, xq0, ff1.act_fn.proj, xq1, epilogue=ff0.epilogue)
-        q0 = ff0.ff_out_proj.quantize_input(h0) if ff0.ff_out_proj.quant_type is not None else h0
-        q1 = ff1.ff_out_proj.quantize_input(h1) if ff1.ff_out_proj.quant_type is not None else h1
+        (epi0, act0), (epi1, act1) = ff0._act_split(), ff1._act_split()
+        if epi0 != epi1:                                         # (one stream quantised, the other not: never in the shipped models)
+            epi0, act0, epi1, act1 = ff0.epilogue, 0, ff1.epilogue, 0
+            assert epi0 == epi1
+        h0, h1 = QL.forward_q_pair(ff0.act_fn.proj, xq0, ff1.act_fn.proj, xq1, epilogue=epi0)
+        q0 = ff0.ff_out_proj.quantize_input(h0, act0) if ff0.ff_out_proj.quant_type is not None else h0
+        q1 = ff1.ff_out_proj.quantize_input(h1, act1) if ff1.ff_out_proj.quant_type is not None else h1
         return QL.forward_q_pair(ff0.ff_out_proj, q0, ff1.ff_out_proj, q1, epilogue=N.EPI_GATE_RESIDUAL, gate0=gate0, res0=res0,
                                  rpb0=rpb0, out0=res0, gate1=gate1, res1=res1, rpb1=rpb1, out1=res1)
 
@@ -52,8 +66,9 @@ class FeedForward:
         x = hidden_states.reshape(-1, shp[-1])
         p = self.act_fn.proj
         xq = p.quantize_input(x) if p.quant_type is not None else x.contiguous()
-        h = p.forward_q(xq, epilogue=self.epilogue)
-        hq = self.ff_out_proj.quantize_input(h) if self.ff_out_proj.quant_type is not None else h
+        epi, act = self._act_split()
+        h = p.forward_q(xq, epilogue=epi)
+        hq = self.ff_out_proj.quantize_input(h, act) if self.ff_out_proj.quant_type is not None else h
         return self.ff_out_proj.forward_q(hq).view(*shp[:-1], -1)
 
 

@@ -49,10 +49,13 @@ class FluxSingleTransformerBlock:
         quant = self.proj_mlp.quant_type
         nh, nq, _ = fused.ln_modulate(x, scale, shift, S, quant=quant, scale_has_one=self.norm.scale_has_one)
         xin = nq if quant is not None else nh
-        mlp = self.proj_mlp.forward_q(xin, epilogue=N.EPI_GELU_ERF)
+        # act_mlp (erf-GELU, flux.py:61): W8A8 -> deferred into the [attn | mlp] quantisation pass (layer/transformer.py FeedForward note),
+        # bf16 -> the GEMM's epilogue
+        deferred = self.proj_out.quant_type is not None
+        mlp = self.proj_mlp.forward_q(xin, epilogue=N.EPI_NONE if deferred else N.EPI_GELU_ERF)
         attn = self.attn.attend(xin, B, S, image_rotary_emb)
-        if self.proj_out.quant_type is not None:
-            cat = fused.quantize_rows(attn, mlp, self.proj_out.quant_type)
+        if deferred:
+            cat = fused.quantize_rows(attn, mlp, self.proj_out.quant_type, act1=N.EPI_GELU_ERF)
         else:
             cat = torch.cat([attn, mlp], dim=1)
         out = torch.empty_like(x)

@@ -44,7 +44,7 @@ const char* fdm_last_hip_error_string(void);
 
 /* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
  * refuse to run instead of passing arguments at the wrong positions. */
-#define FDM_ABI_VERSION 18
+#define FDM_ABI_VERSION 19
 int fdm_abi_version(void);
 
 /* Provenance the binary carries itself (no stamp file beside it): the content digest (64 hex digits) of every source the
@@ -335,6 +335,18 @@ int fdm_quant_rowwise_cat2(void* q_out, float* scale_out, int32_t* azp_out, int 
                            const void* src0, int w0, int64_t stride0,
                            const void* src1, int w1, int64_t stride1,
                            int64_t rows, fdm_stream_t stream);
+
+/* The same with an activation applied to a source's values on the way in (ABI 19): act 0 = none, 1 = tanh-GELU, 2 = erf-GELU:
+ *   x := bf16(gelu(x))   -- /root/reference/fastdm/layer/activations.py:38-41 (GELU = proj, then F.gelu), fastdm/model/flux.py:61 (act_mlp)
+ * followed by the reference's per-token quantisation of the next QLinear's input (fastdm/layer/qlinear.py:62-66).  A W8A8 feed-forward
+ * runs its first GEMM with FDM_EPI_NONE and defers the activation to this pass: the rounding points are those of the GEMM's GELU epilogue
+ * followed by fdm_quant_rowwise_cat2 (bit-identical), but the activation's VALU work hides under an HBM-bound kernel instead of extending
+ * an MFMA-bound one.  Instantiated: a GELU on the only source, or on the second of two ([attention | gelu(mlp)], FLUX single block);
+ * quant_mode 1 / 2; w0 + w1 <= 16384.  Other combinations: FDM_ERR_UNSUPPORTED.                                                         */
+int fdm_quant_rowwise_cat2_act(void* q_out, float* scale_out, int32_t* azp_out, int quant_mode,
+                               const void* src0, int w0, int64_t stride0, int act0,
+                               const void* src1, int w1, int64_t stride1, int act1,
+                               int64_t rows, fdm_stream_t stream);
 
 /* q/k RMS-norm + RoPE + scatter into the joint [text ; image] q/k/v buffers
  * (layer/transformer.py:264-298).  qkv [rows, 3*heads*hd] is one stream's fused projection;
