@@ -846,6 +846,9 @@ __device__ __forceinline__ void acc_set(const i32x4& v) {
 #ifndef FDM_W4_SPREAD_READS
 #define FDM_W4_SPREAD_READS 1
 #endif
+#ifndef FDM_W4_TOUCH_AHEAD
+#define FDM_W4_TOUCH_AHEAD 3      // K steps between a B slice's cooperative touch and its LDS-DMAs (0: off; A/B switch)
+#endif
 constexpr int W4_THREADS = 256;
 constexpr int W4_STAGE = (BM + BN) * 128;   // 64 KiB
 
@@ -976,6 +979,55 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     }
   };
 
+  // ---- cooperative weight touch (round 6).  Inside the denoise step every launch streams weights nobody has read since the last step
+  // (8.6 GB per step against 256 MiB of Infinity Cache).  The LDS-DMAs of a stage are issued 0.5-1 K step ahead of their readers: enough for an
+  // L2 / Infinity-Cache hit, not for an HBM miss, so the FIRST round of tiles -- whoever asks for a B line first -- ran at up to half speed
+  // (tools/micro/gemm_lib_ab.py, same launch warm / cold: K = 12288 gate + residual 235 / 302 us, K = 3072 82 / 103; hipBLASLt 239 / 267, 75 / 84).
+  // While the first round computes, its blocks TOGETHER ask for one dword of every 128-byte line of B's K slice 3 + TOUCH_AHEAD steps ahead of
+  // the DMAs: block b the rows b * rpb ... of each problem's B, one masked load per problem and step.  Each line is asked for ONCE chip-wide and
+  // lands in the Infinity Cache, where every XCD finds it (every tile touching its own slices doubles the L1 fill traffic: 25 % slower, measured).
+  // The dwords are never read; the touch sits right behind the step's barrier and the next step's vmcnt(0) retires it (a whole step to land);
+  // the empty asm that "reads" the registers keeps them reserved until then.
+  // The activations get the same treatment when they are large (K >= 8192: the [M, K] fp8 matrix the quantiser has just written is 100-134 MB
+  // and the tail of its own traffic has pushed the head of it out of the Infinity Cache again).
+  constexpr int TOUCH_AHEAD = FDM_W4_TOUCH_AHEAD;
+  bool toucher = false, t_ok[4] = {false, false, false, false};     // B of problem 0 / 1, A of problem 0 / 1
+  uint32_t t_off[4] = {0, 0, 0, 0}, touch_v[4] = {0, 0, 0, 0};
+  if constexpr (TOUCH_AHEAD > 0) {
+    const int g0 = min((int)gridDim.x, 256);
+    toucher = (int)blockIdx.x < g0 && grp.mode == 0 && grp.splits <= 1;
+    if (toucher) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (i < grp.n) {
+          const int rpb = (grp.p[i].N + g0 - 1) / g0;
+          const int row = (int)blockIdx.x * rpb + tid;
+          t_ok[i] = tid < rpb && row < grp.p[i].N;
+          t_off[i] = (uint32_t)((int64_t)row * grp.p[i].ldb);
+          if (grp.p[i].Kb >= 8192) {
+            const int rpa = (grp.p[i].M + g0 - 1) / g0;
+            const int rowa = (int)blockIdx.x * rpa + tid;
+            t_ok[2 + i] = tid < rpa && rowa < grp.p[i].M;
+            t_off[2 + i] = (uint32_t)((int64_t)rowa * grp.p[i].lda);
+          }
+        }
+      }
+    }
+  }
+  auto touch = [&](int kt) {     // kt: the K slice asked for (wave-uniform)
+    if constexpr (TOUCH_AHEAD > 0) {
+      if (toucher) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (t_ok[i] && (int64_t)(kt + 1) * 128 <= grp.p[i & 1].Kb)
+            asm volatile("global_load_dword %0, %1, %2" : "=&v"(touch_v[i]) : "v"(t_off[i]), "s"((i < 2 ? grp.p[i & 1].B : grp.p[i & 1].A) + (int64_t)kt * 128) : "memory");
+      }
+    }
+  };
+  auto touch_retired = [&]() {   // behind a vmcnt(0): the touch registers may be reused from here
+    if constexpr (TOUCH_AHEAD > 0) asm volatile("" ::"v"(touch_v[0]), "v"(touch_v[1]), "v"(touch_v[2]), "v"(touch_v[3]));
+  };
+
   // ---- fragment reads: lane (fi = lane % 16, fq = lane / 16) of block b reads row b * 16 + fi
   const int fi = lane & 15, fq = lane >> 4;
   const int fg = ((fi >> 1) & 1) | (((fi >> 3) & 1) << 1);
@@ -1047,6 +1099,13 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     };
     const int nk = (int)((Kb + 127) / 128);
     const int nk_full = (int)(Kb / 128);
+    if constexpr (TOUCH_AHEAD > 0) {   // the slices the K loop's touches do not reach: 3 .. 2 + TOUCH_AHEAD (0-2 are DMAed right here)
+#pragma unroll
+      for (int kt = 3; kt < 3 + TOUCH_AHEAD; ++kt) {
+        touch(kt);
+        touch_retired();     // (one register pair serves them all: none of the values is ever read)
+      }
+    }
     if (nk_full >= 3) {      // stages 0..2 lie inside K: the select-free DMA form (the checked one costs ~6 VALU per DMA)
       stage_a(std::true_type{}, 0);
       stage_b(std::true_type{}, 0);
@@ -1089,7 +1148,9 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
           __builtin_amdgcn_s_barrier();
 #endif
           __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0) again, for hipcc's own bookkeeping (nothing is outstanding)
+          touch_retired();
           __builtin_amdgcn_sched_barrier(0);
+          touch(t + 3 + TOUCH_AHEAD);               // (B(t + 3)'s DMAs follow in the next step)
           read_frag(fa[0], smem + nxt * W4_STAGE + a_row, 0);
         } else {
           constexpr int cnt = (g >= 1 && g <= 4) ? 4 : 0;
@@ -1925,7 +1986,12 @@ int fdm_gemm_w8a8_fp8(void* out, const void* a, const void* b, const float* scal
 int fdm_gemm_w8a8_fp8_x2(const fdm_gemm_fp8_desc* d0, const fdm_gemm_fp8_desc* d1, fdm_stream_t stream) {
   (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!d0 || !d1) return FDM_ERR_INVALID;
-  const fdm_gemm_fp8_desc* ds[2] = {d0, d1};
+  // The smaller problem goes FIRST in the tile list (round 6).  The tile list is cut into XCD-contiguous ranges, so one problem's few tiles (a
+  // FLUX text stream: 2 of 34 M tiles) all sit on one XCD; at the END of the list they ran last there, long after the launch's cooperative weight
+  // touch had asked for their B lines and 200 MB of output had pushed those out of the Infinity Cache again (in-step: 280 us for the image +
+  // text FF1 pair against 207 + 6 % for the image problem alone).  At the front they run while the touch streams their weights in.
+  const bool swap = d1->M > 0 && d0->M > d1->M;
+  const fdm_gemm_fp8_desc* ds[2] = {swap ? d1 : d0, swap ? d0 : d1};
   GemmGroup g;
   int n = 0;
   for (int i = 0; i < 2; ++i) {
@@ -1978,7 +2044,8 @@ int fdm_gemm_w8a8_int8_x2_ws(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_d
   (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!d0) return FDM_ERR_INVALID;
   if (workspace != nullptr && ((reinterpret_cast<uintptr_t>(workspace) & 15) || workspace_bytes < 0)) return FDM_ERR_INVALID;
-  const fdm_gemm_int8_desc* ds[2] = {d0, d1};
+  const bool swap = d1 != nullptr && d1->M > 0 && d0->M > d1->M;       // the smaller problem first: see fdm_gemm_w8a8_fp8_x2
+  const fdm_gemm_int8_desc* ds[2] = {swap ? d1 : d0, swap ? d0 : d1};
   GemmGroup g;
   int n = 0;
   for (int i = 0; i < 2; ++i) {

@@ -44,6 +44,8 @@ class Gen:
         self.sreg = {}
         self.label_n = 0
         self.packed_bias = epi != EPI_NONE        # GELU variants keep the bias packed (2 bf16 per register): their temporaries need the room
+        # weight touch: the plain body (every launch of the models since the GELUs moved into the row quantiser); P4_TOUCH=0 builds it without (A/B)
+        self.touch = epi == EPI_NONE and not (os.environ.get("P4_OUT") and (os.environ.get("P4_SCALED") or os.environ.get("P4_TOUCH") == "0"))
 
     # ---- text
     def e(self, line):
@@ -84,6 +86,10 @@ V_ALO = [10, 12]                       # A fragment read bases, stage 0 / 1 (lo 
 V_BLO = [14, 16]
 V_STRIPW, V_STRIPR, V_STOREOFF = 18, 19, 20
 V_SAOFF, V_SBOFF, V_BIASOFF = 21, 22, 23
+# cooperative weight touch (plain body only, round 6 -- see touch_loads): v7 is V_ONE's slot (the non-scaled MFMA encoding does not read it);
+# v23 is V_BIASOFF's (= V_SBOFF >> 1, recomputed into a temporary where the plain body needs it).  The loaded dwords go to v0 / v1, never read.
+V_TOUCHOFF, V_TOUCHOK = 7, 23
+TOUCH_AHEAD = 3
 V_SAM = 24                             # 8: sa of this lane's row in each of the 8 row blocks
 V_TRAIL = 32                           # 16: a row block read back from the strip as row-contiguous pieces
 V_FA = [48, 56]                        # A fragments (2 x 8)
@@ -213,7 +219,31 @@ def build(epi):
     e(f"v_lshl_add_u32 v{V_STOREOFF}, v{fi}, 4, v{V_STOREOFF}")
     e(f"v_lshlrev_b32 v{V_SAOFF}, 2, v{fi}")
     e(f"v_lshlrev_b32 v{V_SBOFF}, 4, v{fq}")
-    e(f"v_lshlrev_b32 v{V_BIASOFF}, 3, v{fq}")
+    if g.touch:
+        c("weight touch: this block asks for rows bid * rpb + tid (tid < rpb, row < N) of every B slice; rpb = ceil(N / grid) <= 256")
+        # grid = 8 * STRIDE; N = TN * 256; rpb = (N + grid - 1) / grid by repeated subtraction (SALU has no divide; <= a few hundred rounds, once)
+        e(f"s_lshl_b32 {X0}, {TN}, 8")                      # N
+        e(f"s_lshl_b32 {X1}, {STRIDE}, 3")                  # grid
+        e(f"s_add_u32 {X2}, {X0}, {X1}")
+        e(f"s_sub_u32 {X2}, {X2}, 1")                       # N + grid - 1
+        e(f"s_mov_b32 {X3}, 0")
+        lp, dn = g.label("rl"), g.label("rd")
+        e(f"{lp}:")
+        e(f"s_cmp_lt_u32 {X2}, {X1}")
+        e(f"s_cbranch_scc1 {dn}")
+        e(f"s_sub_u32 {X2}, {X2}, {X1}")
+        e(f"s_add_u32 {X3}, {X3}, 1")
+        e(f"s_branch {lp}")
+        e(f"{dn}:")                                          # X3 = rpb
+        e(f"s_mul_i32 {X2}, {BID}, {X3}")                    # first row of this block
+        e(f"v_add_u32 v{T[4]}, {X2}, v{T[0]}")               # row = bid * rpb + tid   (T[0] still holds tid)
+        e(f"v_cmp_gt_u32 vcc, {X3}, v{T[0]}")                # tid < rpb
+        e(f"v_cndmask_b32 v{V_TOUCHOK}, 0, 1, vcc")
+        e(f"v_cmp_gt_u32 vcc, {X0}, v{T[4]}")                # row < N
+        e(f"v_cndmask_b32 v{V_TOUCHOK}, 0, v{V_TOUCHOK}, vcc")
+        e(f"v_mul_lo_u32 v{V_TOUCHOFF}, v{T[4]}, {LDB}")
+    else:
+        e(f"v_lshlrev_b32 v{V_BIASOFF}, 3, v{fq}")
     if os.environ.get("P4_OUT") and os.environ.get("P4_SCALED"):      # unit E8M0 scales: only the scaled MFMA encoding (bring-up builds) reads them
         e(f"v_mov_b32 v{ONE}, 0x7f7f7f7f")
 
@@ -297,6 +327,26 @@ def build(epi):
     PTRA, PTRB, NEXTA, NEXTB, STA, STB = s("ptra", 2), s("ptrb", 2), s("nexta", 2), s("nextb", 2), s("sta", 2), s("stb", 2)
     POSA, POSB, LOOP = s("posa"), s("posb"), s("loop")
     SAP, SBP, BIASP, CRUN, CWAVE = s("sap", 2), s("sbp", 2), s("biasp", 2), s("crun", 2), s("cwave", 2)
+    if g.touch:
+        # the kernel-argument pointer, block id, wave id and LDS base are read for the last time in the setup above: their registers carry
+        # the two touch pointers (aligned pairs) and their K position from here on
+        assert g.sreg["karg"][0] % 2 == 0 and g.sreg["bid"][0] % 2 == 0 and g.sreg["wave"][0] == g.sreg["bid"][0] + 1
+        g.sreg["tp0"] = (g.sreg["karg"][0], 2)
+        g.sreg["tp1"] = (g.sreg["bid"][0], 2)
+        TP0, TP1, TPOS = g.s2("tp0"), g.s2("tp1"), LDS0
+        c(f"touch pointers: K slice {3 + TOUCH_AHEAD} of each problem's B (slices 0-2 are DMAed by the prologue; 3 .. {2 + TOUCH_AHEAD} are asked for right here)")
+        e(f"s_mov_b64 {TP0}, {g.s2('p0', 2)}")
+        e(f"s_mov_b64 {TP1}, {g.s2('p1', 2)}")
+        e(f"v_cmp_ne_u32 vcc, 0, v{V_TOUCHOK}")
+        e("s_mov_b64 exec, vcc")
+        for k in range(3, 3 + TOUCH_AHEAD):
+            e(f"global_load_dword v{T[0]}, v{V_TOUCHOFF}, {TP0} offset:{k * 128}")
+            e(f"global_load_dword v{T[1]}, v{V_TOUCHOFF}, {TP1} offset:{k * 128}")
+        e("s_mov_b64 exec, -1")
+        for nm in ("tp0", "tp1"):
+            e(f"s_add_u32 {g.s1(nm, 0)}, {g.s1(nm, 0)}, {(3 + TOUCH_AHEAD) * 128}")
+            e(f"s_addc_u32 {g.s1(nm, 1)}, {g.s1(nm, 1)}, 0")
+        e(f"s_mov_b32 {TPOS}, {3 + TOUCH_AHEAD}")
 
     def epi_ptrs(prob, mt, nt):
         """per-tile epilogue pointers of the CURRENT tile: sa rows, sb / bias columns of this wave, and the wave's first output row"""
@@ -408,6 +458,24 @@ def build(epi):
                     f"s_cmp_eq_u32 {pos}, {NK}", f"s_cselect_b64 {ptr}, {nxt}, {ptr}", f"s_cselect_b32 {pos}, 0, {pos}"]
         return out
 
+    def touch_loads():
+        """Cooperative weight touch, a block's FIRST tile only.  Inside the denoise step every launch streams weights that nobody has read
+        since the last step (8.6 GB per step against 256 MiB of Infinity Cache), and the LDS-DMAs of a stage are issued 0.5-1 K step ahead
+        of their readers: enough for an L2 / Infinity-Cache hit, not for an HBM miss -- the first tile of every CU ran at half speed
+        (tools/micro/gemm_lib_ab.py, same launch warm / cold: 168 / 202 us at K = 3072 N = 9216; hipBLASLt 194 / 200).  So while the first
+        tile computes, the grid's blocks TOGETHER ask for one dword of every 128-byte line of B's K slice 3 + TOUCH_AHEAD steps ahead of
+        the DMAs: block b the rows b * rpb ... of both problems' B, one masked load per problem and step (a line is asked for ONCE chip-wide:
+        it lands in the Infinity Cache, where every XCD finds it; per-tile touches of the tile's own slices double the L1 fill traffic and
+        were 25 % SLOWER).  The dwords go to v0 / v1 and are never read; the next step's vmcnt wait retires the loads (a whole step to land)."""
+        skip = g.label("ts")
+        return [f"s_cmp_ge_u32 {TPOS}, {NK}", f"s_cbranch_scc1 {skip}",
+                f"v_cmp_ne_u32 vcc, 0, v{V_TOUCHOK}", "s_mov_b64 exec, vcc",
+                f"global_load_dword v{T[0]}, v{V_TOUCHOFF}, {TP0}", f"global_load_dword v{T[1]}, v{V_TOUCHOFF}, {TP1}",
+                "s_mov_b64 exec, -1",
+                f"s_add_u32 {g.s1('tp0', 0)}, {g.s1('tp0', 0)}, 128", f"s_addc_u32 {g.s1('tp0', 1)}, {g.s1('tp0', 1)}, 0",
+                f"s_add_u32 {g.s1('tp1', 0)}, {g.s1('tp1', 0)}, 128", f"s_addc_u32 {g.s1('tp1', 1)}, {g.s1('tp1', 1)}, 0",
+                f"s_add_u32 {TPOS}, {TPOS}, 1", f"{skip}:"]
+
     # ---- epilogue pieces ------------------------------------------------------------------------------------------------------
     def bias_regs(nb):
         return [V_BIAS + nb * 4 + k for k in range(4)] if not g.packed_bias else None
@@ -507,9 +575,13 @@ def build(epi):
             o += [f"global_load_dword v{SAM[mb]}, v{V_SAOFF}, {SAP} offset:{mb * 64}"]
         for nb in range(8):
             o += [f"global_load_dwordx4 {vr(V_SB + nb * 4, 4)}, v{V_SBOFF}, {SBP} offset:{nb * 64}"]
+        boff = V_BIASOFF
+        if g.touch:      # V_BIASOFF's register holds the touch flag: fq * 8 = V_SBOFF >> 1 into a temporary (nothing else uses v6 in this group)
+            boff = T[6]
+            o += [f"v_lshrrev_b32 v{boff}, 1, v{V_SBOFF}"]
         for nb in range(8):
             dst = V_BIAS + (nb * 2 if g.packed_bias else nb * 4)
-            o += [f"global_load_dwordx2 {vr(dst, 2)}, v{V_BIASOFF}, {BIASP} offset:{nb * 32}"]
+            o += [f"global_load_dwordx2 {vr(dst, 2)}, v{boff}, {BIASP} offset:{nb * 32}"]
         return o
 
     def bias_unpack():
@@ -582,6 +654,8 @@ def build(epi):
                     e(ln)
                 for slot in range(4):
                     after[2 * slot + 1] = dma("a", par, slot)                      # A(s + 2) rounds 0..3 -> stage (s + 2) & 1 = par
+                if g.touch and kind == "reg":
+                    after[0] = touch_loads()     # not in a tile's first / last step: v0 / v1 are the drain's temporaries there
             elif grp < 4:
                 for slot in range(3):
                     j = 4 + 3 * grp + slot

@@ -13,10 +13,12 @@ TFLOP per launch, PFLOP/s, fraction of the dense MFMA peak (5.0 PF fp8 / int8, 2
 """
 import csv
 import json
+import os
 import statistics
 import sys
 from collections import OrderedDict, defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PEAK = {"fp8": 5000.0, "int8": 5000.0, "bf16": 2500.0}
 EPI = {0: "plain", 1: "gelu_tanh", 2: "gelu_erf", 3: "gate+res", 4: "gate_f32+res"}
 TILE_KERNELS = ("gemm_p4_kernel", "gemm_w4_kernel", "gemm_kernel<")
