@@ -209,10 +209,51 @@ class DeviceState:
         except Exception as e:  # noqa: BLE001
             self.probe = {"error": str(e)}
 
+    def sample_in_step(self, one_step, seconds: float = 3.0):
+        """package power / DPM clock WHILE the step runs -- an extra, UNTIMED repetition of the steps (about `seconds`
+        of them, after the clock has stopped) with rocm-smi polled back to back from a thread.  Reported as `in_step`: what the package
+        draws under exactly this kernel sequence, which the MFMA + LDS probe behind the steps does not show."""
+        import subprocess
+        import threading
+        if not self.smi_usable():
+            return
+        samples, stop = [], threading.Event()
+
+        def poll():
+            while not stop.is_set():
+                try:
+                    out = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+                    smp = self.parse(out)
+                    if smp:
+                        samples.append(smp)
+                except Exception:  # noqa: BLE001
+                    return
+
+        torch.cuda.synchronize()
+        th = threading.Thread(target=poll, daemon=True)
+        t0 = time.perf_counter()
+        th.start()
+        n = 0
+        while time.perf_counter() - t0 < seconds:
+            one_step()
+            torch.cuda.synchronize()
+            n += 1
+        dt = time.perf_counter() - t0
+        stop.set()
+        th.join(timeout=15)
+        samples = samples[1:] if len(samples) > 2 else samples      # the first poll may have started before the GPU was busy
+        if samples:
+            pw = sorted(p for _, p in samples if p is not None)
+            ck = sorted(c for c, _ in samples)
+            self.smi["in_step"] = {"samples": len(samples), "steps": n, "ms_per_step_untimed": round(dt / max(n, 1) * 1e3, 2),
+                                   "package_power_w": {"median": pw[len(pw) // 2], "min": pw[0], "max": pw[-1]} if pw else None,
+                                   "sclk_dpm_mhz": {"median": ck[len(ck) // 2], "min": ck[0], "max": ck[-1]}}
+
     def summary(self):
         return {"mfma_clock_mhz": self.probe, "rocm_smi": self.smi or None,
                 "source": "fdm_clock_probe (s_memtime / s_memrealtime stamps of an fp8 MFMA + LDS loop) right AFTER the timed steps; rocm-smi "
-                          "once before the warm-up and once after the probe; nothing is sampled inside the timed window"}
+                          "once before the warm-up and once after the probe; `in_step`: rocm-smi polled during an extra UNTIMED repetition of the "
+                          "steps (a synchronize per step, so its ms_per_step is not the benchmark's); nothing is sampled inside the timed window"}
 
 
 def spawn_ranks(n: int) -> int:
@@ -324,7 +365,9 @@ def main():
                          "trained model: the shipped 0.2 never skips on them; reported in the workload string)")
     ap.add_argument("--cache-negative", action="store_true", help="set the cache config's negtive_cache flag: separate cache entries for the "
                     "conditional / unconditional forward of a true-CFG step (the shipped teacache_qwenimage.json has it off)")
-    ap.add_argument("--batch-cfg", action="store_true", help="qwen: conditional + unconditional prompt as one batch-2 forward per step")
+    ap.add_argument("--batch-cfg", action="store_true", help="qwen: conditional + unconditional prompt as one batch-2 forward per step (the default since round 6 "
+                    "whenever it applies: no --cfg-pair, no step cache; bit-identical to two forwards)")
+    ap.add_argument("--no-batch-cfg", action="store_true", help="qwen: two batch-1 forwards per step")
     ap.add_argument("--graph", action="store_true", help="sdxl: replay the UNet forward from a HIP graph (the step is launch-bound: ~2000 small kernels)")
     ap.add_argument("--nhwc", action="store_true", help="sdxl: keep convolution activations channels-last instead of NCHW")
     ap.add_argument("--cfg-pair", action="store_true", help="qwen / wan / sd35 / sdxl with --gpus 2k: ranks (2i, 2i+1) share image i -- one runs the "
@@ -348,6 +391,8 @@ def main():
     dflt = {"flux": (1024, 2048, 512, "fp8"), "qwen": (1328, 1328, 128, "int8"), "wan": (768, 1280, 512, "fp8"), "sd35": (1024, 1024, 333, "fp8"), "sdxl": (1024, 1024, 77, "fp8")}[args.model]
     args.height, args.width = args.height or dflt[0], args.width or dflt[1]
     args.max_seq_len, args.quant = args.max_seq_len or dflt[2], args.quant or dflt[3]
+    if args.model == "qwen":
+        args.batch_cfg = (args.batch_cfg or not args.no_batch_cfg) and not args.cfg_pair and not args.cache_config
     if args.graph:
         args.no_kernel_timing = True       # HIP-event spans cannot be recorded inside a graph replay
     args.steps = args.steps if args.steps is not None else (3 if args.model == "wan" else 25)
@@ -575,6 +620,7 @@ def main():
         if smi:                                     # the clock has stopped: probe the loaded chip, then read rocm-smi once more
             smi.run_probe()
             smi.sample_smi("after")
+            smi.sample_in_step(one_step)
     elapsed = D.max_over_ranks(elapsed, dev)
     per_rank = D.gather_floats([t_steps / args.steps * 1e3, t_gather * 1e3], dev)     # [world][2]
     assert torch.isfinite(final.float()).all(), "non-finite latents"

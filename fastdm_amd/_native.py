@@ -37,6 +37,7 @@ SIGNATURES = {
     "fdm_gemm_w8a8_int8_x2_ws": (I32, [P, P, P, I64, P]),
     "fdm_gemm_int8_workspace_bytes": (I64, []),
     "fdm_gemm_last_kernel": (I32, []),
+    "fdm_set_gemm_dispatch": (I32, [I32, I32, I32]),
     "fdm_gemm_w8a8_int8": (I32, [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_gemm_bf16": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_linear_skinny_bf16": (I32, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, P]),
@@ -222,8 +223,30 @@ def _load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError -> missing export: let it propagate loudly
             fn.restype, fn.argtypes = res, args
+        _apply_env_dispatch(handle)
         _lib = handle
     return _lib
+
+
+def gemm_dispatch_from_env(env=None):
+    """(kernel, p4, half_tiles) for fdm_set_gemm_dispatch from FDM_GEMM_KERNEL = auto|p4|w4|w8, FDM_GEMM_P4 = 0|1|2 and
+    FDM_GEMM_HALF_TILES = 0|1 (A/B runs and the parity tests' worker processes).  The LIBRARY reads no environment variable: the host
+    side translates these once, when it loads the library."""
+    env = os.environ if env is None else env
+    k = {"": -1, "auto": -1, "w8": 0, "w4": 1, "p4": 2}.get(env.get("FDM_GEMM_KERNEL", ""), None)
+    if k is None:
+        raise ValueError("FDM_GEMM_KERNEL: auto | p4 | w4 | w8")
+    p4 = int(env["FDM_GEMM_P4"]) if env.get("FDM_GEMM_P4", "") != "" else -1
+    half = int(env["FDM_GEMM_HALF_TILES"]) if env.get("FDM_GEMM_HALF_TILES", "") != "" else -1
+    return k, p4, half
+
+
+def _apply_env_dispatch(handle):
+    k, p4, half = gemm_dispatch_from_env()
+    if (k, p4, half) != (-1, -1, -1):
+        rc = handle.fdm_set_gemm_dispatch(k, p4, half)
+        if rc != 0:
+            raise ValueError(f"FDM_GEMM_KERNEL / FDM_GEMM_P4 / FDM_GEMM_HALF_TILES = {k}, {p4}, {half}: rejected by fdm_set_gemm_dispatch ({rc})")
 
 
 def provenance() -> dict:
@@ -278,24 +301,43 @@ def attn_workspace(device, head_dim):
     return ws
 
 
-_attn_vq_ws = {}
+class StreamScratch:
+    """A growing scratch buffer per (device, stream), rewritten by every call that uses it.  The rule of `gemm_int8_workspace`:
+    a buffer handed out while its stream is CAPTURING has its address baked into a HIP graph, so the key is pinned from then on -- when a
+    later, larger request on a stream with the same handle (torch reuses its 32 pooled handles) replaces a pinned buffer, the old one is
+    RETIRED, not freed: a replay of the old graph keeps writing into memory this cache still owns.  Growth during a capture raises (the
+    allocation would land in the graph's private pool): warm the stream up with the largest shape first."""
+
+    def __init__(self, what, min_bytes=0):
+        self.what, self.min_bytes = what, min_bytes
+        self.buf, self.pinned, self.retired = {}, set(), []
+
+    def get(self, device, need):
+        import torch
+        dev = device.index if device.index is not None else torch.cuda.current_device()
+        key = (dev, int(stream(dev)))
+        capturing = torch.cuda.is_current_stream_capturing()
+        ws = self.buf.get(key)
+        if ws is None or ws.numel() < need:
+            if capturing:
+                raise RuntimeError(f"fastdm_amd: the {self.what} of this stream must be allocated (at its largest size) before graph capture")
+            if ws is not None and key in self.pinned:
+                self.retired.append(ws)
+            ws = torch.empty(max(int(need), self.min_bytes), dtype=torch.uint8, device=device)
+            self.buf[key] = ws
+        if capturing:
+            self.pinned.add(key)
+        return ws
+
+
+_attn_vq_ws = StreamScratch("fp8 attention image workspace")
 
 
 def attn_pvfp8_workspace(device, batch, sk, kv_heads, head_dim, mode=1):
     """Per-(device, stream) buffer for the e4m3 images of fdm_attn_fwd_pvfp8 (mode 1: V) / fdm_attn_fwd_fp8 (mode 2: V and K); rewritten by
-    every call; grows to the largest shape seen."""
-    import torch
-    dev = device.index if device.index is not None else torch.cuda.current_device()
-    key = (dev, int(stream(dev)))
+    every call; grows to the largest shape seen (StreamScratch: pinned once a capture has seen it)."""
     fn = lib().fdm_attn_fp8_workspace_bytes if mode == 2 else lib().fdm_attn_pvfp8_workspace_bytes
-    need = int(fn(batch, sk, kv_heads, head_dim))
-    ws = _attn_vq_ws.get(key)
-    if ws is None or ws.numel() < need:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("fastdm_amd: the fp8 P.V attention workspace of this stream must be allocated before graph capture")
-        ws = torch.empty(need, dtype=torch.uint8, device=device)
-        _attn_vq_ws[key] = ws
-    return ws
+    return _attn_vq_ws.get(device, int(fn(batch, sk, kv_heads, head_dim)))
 
 
 import collections

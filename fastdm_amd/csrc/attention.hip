@@ -778,8 +778,12 @@ static int attn_fwd_impl(void* o, const void* q, const void* k, const void* v, i
   p.mask_bq = p.mask_bk = 1;
   p.mask_nq = p.mask_nk = 0;
   {
+#ifdef FDM_ATT_ENV_KNOBS      // A/B builds only: the product library reads no environment variable
     static const int stretch = [] { const char* e = getenv("FDM_ATT_STRETCH"); return (e != nullptr && e[0] == '0') ? 0 : 1; }();
     p.mask_stretch = stretch;
+#else
+    p.mask_stretch = 1;
+#endif
   }
   if (block_mask != nullptr) {
     if (block_q <= 0 || block_k <= 0 || block_q % 128 || block_k % 64) return FDM_ERR_UNSUPPORTED;

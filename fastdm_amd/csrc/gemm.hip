@@ -33,6 +33,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <atomic>
+
 #include "common.h"
 
 namespace fdm {
@@ -443,6 +445,7 @@ __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp)
       __builtin_amdgcn_s_barrier();
 #if FDM_GEMM_SPREAD_DMA
       // (experiment) one DMA behind each of the four MFMA groups instead of a burst of four behind the barrier
+      static_assert(NWN == 4, "FDM_GEMM_SPREAD_DMA hard-codes the 8-wave geometry (4 stages, 2 A + 2 B rounds): not for the half tiles");
       if constexpr (decltype(inner_c)::value) {
         uint8_t* sA = smem + ((t + 3) & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024;
         uint8_t* sB = sA + BM * BKB;
@@ -1554,14 +1557,11 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_p4_kernel(const P4Args arg
 #ifdef FDM_GEMM_AB
 int g_gemm_use_w4 = 1;   // micro-benchmark builds only: both kernels in one process
 #endif
-static int gemm_kernel_mode() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("FDM_GEMM_KERNEL");
-    mode = (e && !strcmp(e, "w4")) ? 1 : (e && !strcmp(e, "w8")) ? 0 : 2;
-  }
-  return mode;
-}
+// Dispatch policy knobs (A/B runs, parity tests): process-wide atomics set through fdm_set_gemm_dispatch() -- the library reads NO environment
+// variable; fastdm_amd/_native.py translates FDM_GEMM_KERNEL / FDM_GEMM_P4 / FDM_GEMM_HALF_TILES on the host side when it loads
+// the library.  kernel: 2 auto (default) | 1 the 4-wave kernel everywhere it runs | 0 the 8-wave kernel everywhere.
+static std::atomic<int> g_dispatch_kernel{2}, g_dispatch_p4{1}, g_dispatch_half{-1};
+static int gemm_kernel_mode() { return g_dispatch_kernel.load(std::memory_order_relaxed); }
 template <int DT>
 static bool use_w4(const GemmGroup& grp) {
 #ifdef FDM_GEMM_AB
@@ -1605,16 +1605,8 @@ static bool use_p4(const GemmGroup& grp, P4Args& pa) {
 #ifdef FDM_GEMM_AB
   if (!g_gemm_use_p4) return false;
 #else
-  // FDM_GEMM_P4 = 0: never; 1 (default): the epilogues it measured faster with (plain, tanh-GELU); 2: every epilogue it implements.
-  // FDM_GEMM_KERNEL = w4 | w8 also switches it off (those select a kernel for every launch), = p4 means 2.
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("FDM_GEMM_P4");
-    const char* k = getenv("FDM_GEMM_KERNEL");
-    on = e ? atoi(e) : 1;
-    if (k && (!strcmp(k, "w4") || !strcmp(k, "w8"))) on = 0;
-    if (k && !strcmp(k, "p4")) on = 2;
-  }
+  // p4: 0 never; 1 (default) the epilogues it measured faster with (plain, tanh-GELU); 2 every epilogue it implements
+  const int on = g_dispatch_p4.load(std::memory_order_relaxed);
   if (!on) return false;
   if (on == 1 && grp.p[0].epi == FDM_EPI_GELU_ERF) return false;   // erf-GELU drain is VALU-bound either way: 373-378 vs 366-372 us (profiles/r04_experiments.md)
 #endif
@@ -1664,11 +1656,7 @@ static bool use_p4(const GemmGroup& grp, P4Args& pa) {
 // K = 640 / 2432 / 9728 bytes).  They pay for sub-round launches (SDXL's 40 - 240 tile layers: -16 ... -40 %) and for a short K with a
 // nearly empty last round (SD3.5 N = K = 2432: -9 %); not for long K or many rounds.  FDM_GEMM_HALF_TILES = 0 | 1 forces the answer (A/B).
 static bool half_tiles_pay(const GemmGroup& grp) {
-  static int forced = -2;
-  if (forced == -2) {
-    const char* e = getenv("FDM_GEMM_HALF_TILES");
-    forced = e ? atoi(e) : -1;
-  }
+  const int forced = g_dispatch_half.load(std::memory_order_relaxed);     // -1 the cost model below (default), 0 / 1 forced
   if (grp.splits > 1 || grp.mode != 0) return false;
   if (forced >= 0) return forced != 0;
   const int cu = device_cu_count();
@@ -1780,7 +1768,7 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, 
     g2.n_blocks = g2.total_tiles;
     if (res) gemm_kernel<DT, true, 2><<<g2.total_tiles, GEMM_THREADS / 2, 0, s>>>(g2);
     else gemm_kernel<DT, false, 2><<<g2.total_tiles, GEMM_THREADS / 2, 0, s>>>(g2);
-    g_last_gemm_kernel = FDM_GEMM_KERNEL_W8;
+    g_last_gemm_kernel = FDM_GEMM_KERNEL_W8_HALF;
   } else {
     if (res) gemm_kernel<DT, true><<<grid, GEMM_THREADS, 0, s>>>(grp);
     else gemm_kernel<DT, false><<<grid, GEMM_THREADS, 0, s>>>(grp);
@@ -1965,6 +1953,22 @@ static int launch_gemv(void* out, const void* a, const void* b, const void* bias
 extern "C" {
 
 int fdm_gemm_last_kernel(void) { return g_last_gemm_kernel; }
+
+int fdm_set_gemm_dispatch(int kernel, int p4, int half_tiles) {
+  if (kernel < -1 || kernel > 2 || p4 < -1 || p4 > 2 || half_tiles < -1 || half_tiles > 1) return FDM_ERR_INVALID;
+  // kernel: -1 auto | 0 w8 | 1 w4 | 2 p4 (= auto with every epilogue the persistent kernel implements); w8 / w4 switch the persistent kernel off
+  int km = 2, pm = p4 < 0 ? 1 : p4;
+  if (kernel == 0 || kernel == 1) {
+    km = kernel;
+    pm = 0;
+  } else if (kernel == 2) {
+    pm = 2;
+  }
+  fdm::g_dispatch_kernel.store(km, std::memory_order_relaxed);
+  fdm::g_dispatch_p4.store(pm, std::memory_order_relaxed);
+  fdm::g_dispatch_half.store(half_tiles, std::memory_order_relaxed);
+  return FDM_OK;
+}
 
 int fdm_gemm_w8a8_fp8(void* out, const void* a, const void* b, const float* scale_a, const float* scale_b, const void* bias,
                       int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int epilogue,

@@ -22,7 +22,7 @@ Structure of one block (256 threads = 4 waves, ONE per SIMD, wave tile 128 x 128
   * per-tile epilogue operands (sa rows, sb / bias columns) are requested in the tile's last K step and sit in 72 dedicated VGPRs.
 
 The emitted text is the body of ONE `asm volatile` statement of gemm.hip (operands: %0 kernel-argument pointer, %1 blockIdx.x,
-%2 threadIdx.x, %3 LDS base of the block's 160 KiB, %4 address of a zero bias vector); it clobbers v8-v255, a0-a255, s8-s101, vcc.
+%2 threadIdx.x, %3 LDS base of the block's 160 KiB, %4 address of a zero bias vector); it clobbers v8-v255, a0-a255, s8-s99 without s32, vcc.
 """
 import os
 import sys
@@ -41,6 +41,7 @@ class Gen:
         self.epi = epi
         self.out = []
         self.s_next = 8
+        self.s_used = set()
         self.sreg = {}
         self.label_n = 0
         self.packed_bias = epi != EPI_NONE        # GELU variants keep the bias packed (2 bf16 per register): their temporaries need the room
@@ -58,14 +59,21 @@ class Gen:
         self.label_n += 1
         return f".Lp4_{stem}_{self.label_n}_%="
 
-    # ---- SGPR allocation
+    # ---- SGPR allocation: first fit in s8 .. s99 without s32.  hipcc holds s32 (the stack pointer of its calling convention) and
+    # s100 / s101 (the kernel uses VCC, which the hardware places behind the last allocated SGPR: 102 - 2) as RESERVED and warns that an asm
+    # statement clobbering them "may lead to undefined behaviour" -- the body names none of them, so the clobber list does not either.
+    S_FIRST, S_END, S_AVOID = 8, 100, (32,)
+
     def s(self, name, n=1, align=None):
         if name not in self.sreg:
             al = align or (4 if n >= 4 else n)
-            self.s_next = (self.s_next + al - 1) // al * al
-            self.sreg[name] = (self.s_next, n)
-            self.s_next += n
-            assert self.s_next <= 102, f"out of SGPRs at {name}"
+            b = (self.S_FIRST + al - 1) // al * al
+            while any((r in self.s_used or r in self.S_AVOID) for r in range(b, b + n)):
+                b += al
+            assert b + n <= self.S_END, f"out of SGPRs at {name}"
+            self.sreg[name] = (b, n)
+            self.s_used.update(range(b, b + n))
+            self.s_next = max(self.s_next, b + n)
         b, n_ = self.sreg[name]
         return f"s{b}" if n_ == 1 else f"s[{b}:{b + n_ - 1}]"
 
@@ -400,7 +408,7 @@ def build(epi):
     def next_tile():
         """(NPROB, NMT, NNT, HASNEXT, NEXTA, NEXTB) for tile TCUR + 32; no such tile: the current tile again (its DMAs land in stages
         nobody reads) and HASNEXT = 0"""
-        TN_ = s("tnext")
+        TN_ = LOOP        # (the K loop's counter is dead between a tile's last step and the next tile's first: one register for both)
         no, done = g.label("nn"), g.label("nd")
         e(f"s_add_u32 {TN_}, {TCUR}, {STRIDE}")
         e(f"s_cmp_lt_u32 {TN_}, {TEND}")
@@ -860,7 +868,8 @@ def outputs():
         n_ins = sum(1 for l in g.out if not l.startswith(";") and not l.rstrip().endswith(":"))
         print(f"gemm_p4_body_{name}.inc: {n_ins} instructions, {g.s_next} SGPRs", file=sys.stderr if "--check" in sys.argv else sys.stdout)
     # the statement's clobber list: everything the body names (inputs are therefore allocated in v0-v7 / s0-s7)
-    regs = [f"v{i}" for i in range(8, 256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(8, 102)] + ["vcc", "memory"]
+    regs = ([f"v{i}" for i in range(8, 256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(Gen.S_FIRST, Gen.S_END) if i not in Gen.S_AVOID]
+            + ["vcc", "memory"])
     files["gemm_p4_clobbers.inc"] = ("// generated by gen_gemm_p4.py -- do not edit\n"
                                      + ",\n".join(", ".join(f'"{r}"' for r in regs[i:i + 16]) for i in range(0, len(regs), 16)) + "\n")
     return files

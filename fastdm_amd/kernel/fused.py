@@ -110,7 +110,7 @@ def gelu_and_mul_quant(x: torch.Tensor, quant) -> Quantized:
     return qz
 
 
-_gn_ws = {}
+_gn_ws = N.StreamScratch("GroupNorm statistics workspace", min_bytes=1 << 16)
 
 
 def group_norm(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float, addend: Optional[torch.Tensor] = None,
@@ -121,19 +121,16 @@ def group_norm(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Te
     a multiple of 8 and FDM_GN_TORCH=1 (A/B runs) take the torch calls -- the same library ops the reference makes there."""
     B, C, H, W = x.shape
     hw = H * W
+    affine_ok = all(t.dtype == BF16 and t.is_contiguous() and t.numel() == C and t.device == x.device for t in (gamma, beta))   # read as raw bf16[C]
     if (x.dtype != BF16 or not x.is_contiguous() or (hw & 7) or C % groups or B * groups > 65535 or (C // groups) * hw >= (1 << 31)
-            or os.environ.get("FDM_GN_TORCH", "0") == "1"):
+            or not affine_ok or os.environ.get("FDM_GN_TORCH", "0") == "1"):
         import torch.nn.functional as F
         y = F.group_norm(x if addend is None else x + addend[:, :, None, None], groups, gamma, beta, eps)
         return F.silu(y) if silu else y
-    need = N.lib().fdm_group_norm_workspace_bytes(B, C, hw, groups)
-    key = (x.device.index, N.stream(x.device.index))
-    ws = _gn_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _gn_ws[key] = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=x.device)
-    out = torch.empty_like(x)
     if addend is not None:
         assert addend.shape == (B, C) and addend.dtype == BF16 and addend.is_contiguous()
+    ws = _gn_ws.get(x.device, N.lib().fdm_group_norm_workspace_bytes(B, C, hw, groups))
+    out = torch.empty_like(x)
     N.check(N.lib().fdm_group_norm(N.ptr(out), N.ptr(x), N.ptr(gamma), N.ptr(beta), N.ptr(addend), B, C, hw, groups, eps, 1 if silu else 0,
                                    N.ptr(ws), ws.numel(), N.stream()), "group_norm")
     return out

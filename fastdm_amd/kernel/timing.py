@@ -15,7 +15,8 @@ def log_gemm(dtype: str, problems):
     """One GEMM launch (one or two problems) for the per-dispatch table of tools/gemm_by_shape.py; a no-op unless that tool is recording."""
     if shape_log is not None:
         shape_log.append({"dtype": dtype, "problems": [list(map(int, p)) for p in problems if p[0] > 0]})
-GEMM_KERNEL_NAMES = {0: "fdm::gemm_kernel", 1: "fdm::gemm_w4_kernel", 2: "fdm::gemm_p4_kernel", 3: "fdm::gemv_bf16_kernel"}   # fdm_gemm_last_kernel()
+GEMM_KERNEL_NAMES = {0: "fdm::gemm_kernel", 1: "fdm::gemm_w4_kernel", 2: "fdm::gemm_p4_kernel", 3: "fdm::gemv_bf16_kernel",
+                     4: "fdm::gemm_kernel<.., 2> (half tiles)"}   # fdm_gemm_last_kernel()
 
 
 class Recorder:

@@ -304,7 +304,8 @@ class FastDMEngine:
         elif architecture == "qwen":
             from fastdm_amd.pipeline import SyntheticQwenPipeline
             from fastdm_amd.synthetic import SyntheticQwenStateDict
-            batch_cfg = bool(model_kwargs.pop("batch_cfg", False))      # cond + uncond as one batch-2 forward (pipeline.py)
+            batch_cfg = model_kwargs.pop("batch_cfg", None)      # cond + uncond as one batch-2 forward (pipeline.py); None: whenever no step cache is set
+            batch_cfg = (self.cache is None) if batch_cfg is None else bool(batch_cfg)
             if batch_cfg and self.cache is not None:
                 raise ValueError("batch_cfg runs both prompts in one forward; the step caches key on the cond / uncond alternation")
             keys = ("patch_size", "num_layers", "attention_head_dim", "num_attention_heads", "joint_attention_dim", "in_channels", "out_channels")

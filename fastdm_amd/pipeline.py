@@ -11,6 +11,8 @@ encoder_hidden_states=..., txt_ids=..., img_ids=..., return_dict=False)[0]` call
 import math
 
 import numpy as np
+from typing import Optional
+
 import torch
 
 from fastdm_amd import synthetic
@@ -79,14 +81,17 @@ class SyntheticQwenPipeline:
     to the conditional prediction's per-token norm, then the flow-match Euler update.  Latents are packed
     [B, (H/16)*(W/16), 64]; `timestep = sigma`; prompt / negative-prompt embeddings are synthetic."""
 
-    def __init__(self, transformer, seed: int = 0, batch_cfg: bool = False, cfg_pair=None):
+    def __init__(self, transformer, seed: int = 0, batch_cfg: Optional[bool] = None, cfg_pair=None):
         """cfg_pair: a `distributed.CFGPair` -- this rank runs only its branch of the CFG forward pair and the two noise
         predictions meet in one all-gather per step (the combine + Euler update then run identically on both ranks).
         batch_cfg: run the conditional and the unconditional prompt as ONE batch-2 forward (same bits as two forwards: all
         quantisation is per token) when both prompts have the same length and no step cache keys on the cond / uncond
-        alternation; the N = 3072 GEMMs then fill 2.6 instead of 1.3 rounds of the chip."""
+        alternation; the N = 3072 GEMMs then fill 2.6 instead of 1.3 rounds of the chip.  None (default, round 6): on whenever it applies --
+        no CFG pair, no step cache on the transformer (198 -> 179 ms per 1328 x 1328 step for the same bits)."""
         self.transformer = transformer
         self.seed = seed
+        if batch_cfg is None:
+            batch_cfg = cfg_pair is None and not getattr(getattr(transformer, "core_model", None), "enable_caching", False)
         self.batch_cfg = batch_cfg
         self.cfg_pair = cfg_pair
         if cfg_pair is not None and batch_cfg:

@@ -184,13 +184,22 @@ int fdm_gemm_w8a8_int8_x2_ws(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_d
 
 /* Diagnostic: which kernel the LAST GEMM entry point called on this host thread launched (the dispatch policy of gemm.hip picks
  * per launch): 0 fdm::gemm_kernel (8 waves), 1 fdm::gemm_w4_kernel (4 waves), 2 fdm::gemm_p4_kernel (persistent, hand-written
- * assembly), 3 fdm::gemv_bf16_kernel, -1 nothing launched yet.  bench.py names the kernel of a timing span with it; the parity
+ * assembly), 3 fdm::gemv_bf16_kernel, 4 fdm::gemm_kernel<.., 2> (half tiles), -1 nothing launched yet.  bench.py names the kernel of a timing span with it; the parity
  * tests use it to prove which kernel they compared.  No reference counterpart.                                                  */
 #define FDM_GEMM_KERNEL_W8 0
 #define FDM_GEMM_KERNEL_W4 1
 #define FDM_GEMM_KERNEL_P4 2
 #define FDM_GEMM_KERNEL_GEMV 3
+#define FDM_GEMM_KERNEL_W8_HALF 4    /* fdm::gemm_kernel<.., 2>: the 8-wave kernel's wave code on 256 x 128 half tiles (ABI 19) */
 int fdm_gemm_last_kernel(void);
+
+/* A/B and parity-test control of the GEMM dispatch policy (process-wide, atomic; default = auto everywhere).  The library reads no environment
+ * variable: fastdm_amd/_native.py translates FDM_GEMM_KERNEL / FDM_GEMM_P4 / FDM_GEMM_HALF_TILES into one call of this when it loads the
+ * library; a host that binds the C ABI directly never needs it.  No reference counterpart.
+ *   kernel     -1 auto | 0 the 8-wave kernel for every launch | 1 the 4-wave kernel wherever it runs | 2 auto + every epilogue on the persistent kernel
+ *   p4         -1 default (plain / tanh-GELU launches) | 0 never | 1 default | 2 every epilogue it implements      (ignored when kernel is 0 / 1)
+ *   half_tiles -1 the cost model | 0 never | 1 always (8-wave kernel only)                                                               */
+int fdm_set_gemm_dispatch(int kernel, int p4, int half_tiles);
 
 /* ---- bf16 GEMM (QLinear's un-quantised branch: torch.addmm, layer/qlinear.py:76) --------------
  * out[M,N] = bf16(acc_f32(A[M,K] bf16 row-major x B[K,N] bf16 column-major) + bias[N])          */

@@ -234,3 +234,52 @@ def test_bench_line_carries_the_library_identity():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'if prov["lib_flags"] and not args.allow_build_flags' in src and '"experimental": True' in src
     assert "**prov" in src            # lib_digest / lib_flags / lib_path on the JSON line
+
+
+def test_stream_scratch_never_frees_a_buffer_a_capture_has_seen(monkeypatch):
+    """the per-(device, stream) scratch caches (GroupNorm statistics, fp8 attention images) follow the int8 split-K
+    workspace's rule -- a buffer handed out during a capture is pinned; when a later, larger request on the same stream handle replaces
+    it the old tensor is retired (kept), and growth during a capture raises."""
+    import torch
+    state = {"capturing": False}
+    monkeypatch.setattr(N, "stream", lambda idx=None: 1234)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: state["capturing"])
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    sc = N.StreamScratch("test scratch", min_bytes=64)
+    dev = torch.device("cpu")
+    a = sc.get(dev, 100)
+    assert a.numel() == 100 and sc.get(dev, 50) is a and not sc.retired            # eager: reuse, grow freely
+    b = sc.get(dev, 200)
+    assert b.numel() == 200 and not sc.retired                                      # the unpinned predecessor simply goes
+    state["capturing"] = True
+    assert sc.get(dev, 200) is b and (0, 1234) in sc.pinned                          # handed out during a capture: pinned
+    with pytest.raises(RuntimeError):
+        sc.get(dev, 300)                                                             # growth inside a capture
+    state["capturing"] = False
+    c = sc.get(dev, 300)
+    assert c.numel() == 300 and sc.retired == [b] and sc.get(dev, 10) is c           # the captured address stays owned by the cache
+
+
+def test_gemm_dispatch_env_is_translated_on_the_host_side():
+    """The library reads no environment variable: FDM_GEMM_KERNEL / FDM_GEMM_P4 / FDM_GEMM_HALF_TILES become one
+    fdm_set_gemm_dispatch call when _native loads the library; csrc has no getenv outside FDM_DEBUG_BUILD / A/B blocks."""
+    assert N.gemm_dispatch_from_env({}) == (-1, -1, -1)
+    assert N.gemm_dispatch_from_env({"FDM_GEMM_KERNEL": "w8", "FDM_GEMM_HALF_TILES": "1"}) == (0, -1, 1)
+    assert N.gemm_dispatch_from_env({"FDM_GEMM_KERNEL": "w4", "FDM_GEMM_P4": "0"}) == (1, 0, -1)
+    assert N.gemm_dispatch_from_env({"FDM_GEMM_P4": "2"}) == (-1, 2, -1)
+    with pytest.raises(ValueError):
+        N.gemm_dispatch_from_env({"FDM_GEMM_KERNEL": "fast"})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in ("gemm.hip", "attention.hip", "elementwise.hip", "capi.hip"):
+        src = open(os.path.join(root, "fastdm_amd", "csrc", f)).read()
+        depth_ok = True
+        lines = src.split("\n")
+        guard = []          # stack of preprocessor conditions
+        for ln in lines:
+            t = ln.strip()
+            if t.startswith(("#ifdef", "#ifndef", "#if ")):
+                guard.append(t)
+            elif t.startswith("#endif") and guard:
+                guard.pop()
+            if "getenv(" in t and not t.startswith("//"):
+                assert any(("FDM_DEBUG_BUILD" in g or "ENV_KNOBS" in g or "FDM_GEMM_AB" in g) for g in guard), f"{f}: getenv outside a debug / A-B block: {t}"
