@@ -20,6 +20,9 @@ def sha(t):
     return hashlib.sha256(t.cpu().view(torch.int16).numpy().tobytes()).hexdigest()
 
 
+W8 = 4 if os.environ.get("FDM_GEMM_HALF_TILES") == "1" else 0      # FDM_GEMM_KERNEL_W8_HALF / FDM_GEMM_KERNEL_W8: the kernel id proves which form ran
+
+
 def main():
     g = torch.Generator().manual_seed(4321)
     res = {}
@@ -39,7 +42,7 @@ def main():
         rpb = (m + 1) // 2
         rc = L.fdm_gemm_w8a8_fp8(N.ptr(out), N.ptr(a), N.ptr(b), N.ptr(sa), N.ptr(sb), N.ptr(bias), m, n, k, k, k, n + 8, epi,
                                  N.ptr(gate) if epi == N.EPI_GATE_RESIDUAL else None, n, N.ptr(r) if epi == N.EPI_GATE_RESIDUAL else None, rpb, s)
-        assert rc == 0 and L.fdm_gemm_last_kernel() == 0, (name, rc, L.fdm_gemm_last_kernel())
+        assert rc == 0 and L.fdm_gemm_last_kernel() == W8, (name, rc, L.fdm_gemm_last_kernel())
         assert (out[:, n:] == 3.0).all(), name
         res[name] = sha(out)
     # int8 with asymmetric zero points
@@ -54,7 +57,7 @@ def main():
         out = torch.empty((m, n), dtype=BF16, device="cuda")
         rc = L.fdm_gemm_w8a8_int8(N.ptr(out), N.ptr(a), N.ptr(b), N.ptr(sa), N.ptr(sb), N.ptr(adj), N.ptr(azp), N.ptr(bias), m, n, k, k, k, n, epi,
                                   N.ptr(gate) if epi == N.EPI_GATE_RESIDUAL else None, n, N.ptr(r) if epi == N.EPI_GATE_RESIDUAL else None, m, s)
-        assert rc == 0 and L.fdm_gemm_last_kernel() == 0, (name, rc)
+        assert rc == 0 and L.fdm_gemm_last_kernel() == W8, (name, rc)
         res[name] = sha(out)
     # bf16
     for name, (m, k, n, epi) in {"bf16_small": (300, 72, 528, N.EPI_GELU_TANH), "bf16_sdxl": (2048, 640, 1280, N.EPI_NONE)}.items():
@@ -62,7 +65,7 @@ def main():
         bias = (torch.randn(n, generator=g) * 0.1).to(BF16).cuda()
         out = torch.empty((m, n), dtype=BF16, device="cuda")
         rc = L.fdm_gemm_bf16(N.ptr(out), N.ptr(a), N.ptr(w), N.ptr(bias), m, n, k, k, k, n, epi, None, 0, None, 0, s)
-        assert rc == 0 and L.fdm_gemm_last_kernel() == 0, (name, rc)
+        assert rc == 0 and L.fdm_gemm_last_kernel() == W8, (name, rc)
         res[name] = sha(out)
     # two problems in one launch, outputs as three planes whose width (152) straddles the half tiles
     C, kk, m_img, m_txt = 152, 192, 300, 37
@@ -83,7 +86,7 @@ def main():
         d.out_plane_cols, d.out_plane_stride = C, (m_img + m_txt) * C
         ds.append(d)
     rc = L.fdm_gemm_w8a8_fp8_x2(ctypes.byref(ds[0]), ctypes.byref(ds[1]), s)
-    assert rc == 0 and L.fdm_gemm_last_kernel() == 0, rc
+    assert rc == 0 and L.fdm_gemm_last_kernel() == W8, rc
     res["pair_planes"] = sha(planes)
     print(json.dumps(res))
 
