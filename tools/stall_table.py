@@ -3,7 +3,7 @@
    parked %   = SQ_WAIT_ANY / SQ_WAVE_CYCLES        (s_waitcnt, s_barrier)
    stalled %  = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES   (an instruction is ready but cannot issue: MFMA dependency, busy pipe)   [LDS part separately]
    issuing %  = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES, split by unit (VALU incl. MFMA issue, LDS, VMEM, scalar, misc)
-   MFMA busy  = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CYCLES)   (the matrix pipe of a SIMD), coexec = cycles with VALU and MFMA both executing
+   MFMA busy  = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)   (the matrix pipe of a SIMD), coexec = cycles with VALU and MFMA both executing
 and instructions per wave.  usage: stall_table.py <pmc dir> ..."""
 import collections
 import csv
@@ -51,8 +51,9 @@ for _, name, us, wc in rows[:14]:
     waves = g("SQ_WAVES")
     busy = g("SQ_BUSY_CYCLES")
     pct = lambda c: 100.0 * g(c) / wc
-    mf = 100.0 * g("SQ_VALU_MFMA_BUSY_CYCLES") / (4.0 * busy) if busy == busy and busy > 0 else float("nan")
-    co = 100.0 * g("SQ_VALU_MFMA_COEXEC_CYCLES") / (4.0 * busy) if busy == busy and busy > 0 else float("nan")
+    simd = g("GRBM_GUI_ACTIVE") / 8.0 * 1024.0         # SIMD-cycles of the dispatch (GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs): the MfmaUtil expression of `rocprofv3 -L`
+    mf = 100.0 * g("SQ_VALU_MFMA_BUSY_CYCLES") / simd if simd == simd and simd > 0 else float("nan")
+    co = 100.0 * g("SQ_VALU_MFMA_COEXEC_CYCLES") / simd if simd == simd and simd > 0 else float("nan")
     ghz = g("GRBM_GUI_ACTIVE") / 8.0 / (us * 1e3) if us > 0 else float("nan")
     pw = lambda c: g(c) / waves if waves == waves and waves > 0 else float("nan")
     print(f"{name:58s} {us:7.1f} {pct('SQ_WAIT_ANY'):8.1f} {pct('SQ_WAIT_INST_ANY'):7.1f} {pct('SQ_WAIT_INST_LDS'):7.1f} {pct('SQ_ACTIVE_INST_ANY'):7.1f} | "
