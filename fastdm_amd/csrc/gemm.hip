@@ -1030,22 +1030,6 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
   auto touch_retired = [&]() {   // behind a vmcnt(0): the touch registers may be reused from here
     if constexpr (TOUCH_AHEAD > 0) asm volatile("" ::"v"(touch_v[0]), "v"(touch_v[1]), "v"(touch_v[2]), "v"(touch_v[3]));
   };
-  // gate + residual: the tile's 256 x 256 residual (the residual stream, last written a whole block ago: HBM-cold by now) is asked for a few
-  // K steps before the epilogue reads it -- every tile its OWN 1024 lines, thread tid the four 128-byte lines of row m0 + tid.  The epilogue of
-  // this kernel has no MFMA work to hide a miss under (one tile per block).
-  auto touch_res = [&]() {
-    if constexpr (TOUCH_AHEAD > 0 && RES) {
-      if (p.epi == FDM_EPI_GATE_RESIDUAL && p.res != nullptr) {
-        const uint32_t roff = (uint32_t)(min(m0 + tid, p.M - 1) - m0) * (uint32_t)(p.ldc * 2);
-        const uint8_t* rbase = reinterpret_cast<const uint8_t*>(p.res + (int64_t)m0 * p.ldc + n0);
-        asm volatile("global_load_dword %0, %4, %5\n\tglobal_load_dword %1, %4, %5 offset:128\n\t"
-                     "global_load_dword %2, %4, %5 offset:256\n\tglobal_load_dword %3, %4, %5 offset:384"
-                     : "=&v"(touch_v[0]), "=&v"(touch_v[1]), "=&v"(touch_v[2]), "=&v"(touch_v[3])
-                     : "v"(roff), "s"(rbase)
-                     : "memory");
-      }
-    }
-  };
 
   // ---- fragment reads: lane (fi = lane % 16, fq = lane / 16) of block b reads row b * 16 + fi
   const int fi = lane & 15, fq = lane >> 4;
@@ -1170,7 +1154,6 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
           touch_retired();
           __builtin_amdgcn_sched_barrier(0);
           touch(t + 3 + TOUCH_AHEAD);               // (B(t + 3)'s DMAs follow in the next step)
-          if (t == nk - 5) touch_res();             // lands during the last four steps (the touch registers are free: no slice touch past the end of K)
           read_frag(fa[0], smem + nxt * W4_STAGE + a_row, 0);
         } else {
           constexpr int cnt = (g >= 1 && g <= 4) ? 4 : 0;

@@ -3,7 +3,7 @@
 tag=${1:-r01}
 out=$PWD/gpurun_out
 mkdir -p "$out"
-python3 bench.py --model qwen --no-batch-cfg > "$out/${tag}_qwen_bench.json" 2> "$out/${tag}_qwen.err"      # two forwards per step (the default is the batch-2 CFG forward since round 6)
+python3 bench.py --model qwen > "$out/${tag}_qwen_bench.json" 2> "$out/${tag}_qwen.err"
 python3 bench.py --model qwen --batch-cfg > "$out/${tag}_qwen_batchcfg_bench.json" 2> "$out/${tag}_qwen_batchcfg.err"
 python3 bench.py --quant bf16 --height 1024 --width 1024 > "$out/${tag}_flux_bf16_1024_bench.json" 2> "$out/${tag}_flux_bf16_1024.err"
 python3 bench.py --quant int8 > "$out/${tag}_flux_int8_bench.json" 2> "$out/${tag}_flux_int8.err"
