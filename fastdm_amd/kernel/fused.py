@@ -143,7 +143,7 @@ def gelu(x: torch.Tensor, approximate: str = "none") -> torch.Tensor:
     return out
 
 
-def quantize_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], quant, act0: int = 0, act1: int = 0) -> Quantized:
+def quantize_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], quant, act0: int = 0, act1: int = 0, out: Optional[Quantized] = None) -> Quantized:
     """Per-row quantisation of [x0 | x1] without materialising the concatenation (model/flux.py:69).
     act0 / act1 (N.EPI_GELU_TANH / N.EPI_GELU_ERF): that source holds PRE-activations -- bf16(gelu(x)) is applied on the way in, the
     arithmetic of the GEMM's GELU epilogue followed by this quantiser (bit-identical), at the price of an HBM-bound pass's idle VALU slots
@@ -152,7 +152,9 @@ def quantize_rows(x0: torch.Tensor, x1: Optional[torch.Tensor], quant, act0: int
     w1 = 0 if x1 is None else x1.shape[1]
     assert x0.stride(1) == 1 and (x1 is None or (x1.stride(1) == 1 and x1.shape[0] == rows))
     assert act0 in (0, N.EPI_GELU_TANH, N.EPI_GELU_ERF) and act1 in (0, N.EPI_GELU_TANH, N.EPI_GELU_ERF)
-    qz = _alloc_q(rows, w0 + w1, quant, x0.device)
+    # out: rows of a larger Quantized (the batch elements of a CFG batch quantised one by one into ONE GEMM operand)
+    qz = _alloc_q(rows, w0 + w1, quant, x0.device) if out is None else out
+    assert qz.q.shape == (rows, w0 + w1) and qz.q.is_contiguous() and qz.scale.is_contiguous()
     N.check(N.lib().fdm_quant_rowwise_cat2_act(N.ptr(qz.q), N.ptr(qz.scale), N.ptr(qz.azp), QUANT_MODE[quant], N.ptr(x0), w0,
                                                x0.stride(0), act0, N.ptr(x1), w1, 0 if x1 is None else x1.stride(0), act1, rows,
                                                N.stream()), "quant_rowwise")

@@ -99,10 +99,10 @@ class QLinear:
         self.bias = d["b"].to(dev) if "b" in d else None
 
     # ------------------------------------------------------------------ forward
-    def quantize_input(self, x2d: torch.Tensor, act: int = 0) -> Quantized:
+    def quantize_input(self, x2d: torch.Tensor, act: int = 0, out: Optional[Quantized] = None) -> Quantized:
         """Per-token quantisation of this layer's input; act = N.EPI_GELU_TANH / N.EPI_GELU_ERF: x2d holds the pre-activations of the
         GELU in front of this layer and bf16(gelu(x)) is applied in the same pass (fused.quantize_rows)."""
-        return fused.quantize_rows(x2d, None, self.quant_type, act0=act)
+        return fused.quantize_rows(x2d, None, self.quant_type, act0=act, out=out)
 
     def forward_q(self, x, epilogue: int = N.EPI_NONE, gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                   rows_per_batch: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:

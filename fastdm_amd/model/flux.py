@@ -25,7 +25,7 @@ from fastdm_amd.layer.embeddings import (CombinedTimestepGuidanceTextProjEmbeddi
                                          FluxPosEmbed)
 from fastdm_amd.layer.normalization import (AdaLayerNormContinuous, AdaLayerNormZero, AdaLayerNormZeroSingle, ModulationTable)
 from fastdm_amd.layer.qlinear import QLinear
-from fastdm_amd.layer.transformer import Attention, FeedForward
+from fastdm_amd.layer.transformer import _rows, Attention, FeedForward
 from fastdm_amd.model.basemodel import BaseModelCore
 
 BF16 = torch.bfloat16
@@ -110,24 +110,38 @@ def fused_double_stream(attn, ff_img, ff_txt, mod_img, mod_txt, hidden_states, e
     ein = pick(fused.ln_modulate(e, c_scale_msa, c_shift_msa, s_txt, quant=quant, scale_has_one=one_txt))
     o = attn.attend(xin, B, s_img, image_rotary_emb, ein, s_txt).view(B, s_txt + s_img, D)
 
-    # attention rows of a stream are a strided slice of the joint output: quantise / project per batch element;
-    # the image and text projections of one batch element share a launch
+    # attention rows of a stream are a strided slice of the joint output [B, s_txt + s_img, D].  W8A8: every batch element's rows are quantised
+    # into its slice of ONE compact operand per stream, then ONE launch projects image and text rows of the whole batch (round 6: a CFG batch of
+    # two -- Qwen-Image, SD3.5 -- ran two launches of 1.3 rounds of tiles each: Qwen-Image to_out 2 x 98 us at 0.27 of peak).  bf16: per batch element.
     x_new = torch.empty_like(x)
     e_new = None if context_pre_only else torch.empty_like(e)
     to_o = attn.to_out
-    for b in range(B):
-        ai = o[b, s_txt:]
-        aqi = to_o.quantize_input(ai) if to_o.quant_type is not None else ai
-        if context_pre_only:
-            to_o.forward_q(aqi, epilogue=N.EPI_GATE_RESIDUAL, gate=gate_msa[b:b + 1], res=x[b * s_img:(b + 1) * s_img], rows_per_batch=s_img,
-                           out=x_new[b * s_img:(b + 1) * s_img])
-            continue
-        to_ao = attn.to_add_out
-        at = o[b, :s_txt]
-        aqt = to_ao.quantize_input(at) if to_ao.quant_type is not None else at
-        QLinear.forward_q_pair(to_o, aqi, to_ao, aqt, epilogue=N.EPI_GATE_RESIDUAL,
-                               gate0=gate_msa[b:b + 1], res0=x[b * s_img:(b + 1) * s_img], rpb0=s_img, out0=x_new[b * s_img:(b + 1) * s_img],
-                               gate1=c_gate_msa[b:b + 1], res1=e[b * s_txt:(b + 1) * s_txt], rpb1=s_txt, out1=e_new[b * s_txt:(b + 1) * s_txt])
+    to_ao = None if context_pre_only else attn.to_add_out
+    if to_o.quant_type is not None and (to_ao is None or to_ao.quant_type == to_o.quant_type):
+        aq_img = fused._alloc_q(B * s_img, D, to_o.quant_type, x.device)
+        aq_txt = None if to_ao is None else fused._alloc_q(B * s_txt, D, to_ao.quant_type, x.device)
+        for b in range(B):
+            to_o.quantize_input(o[b, s_txt:], out=_rows(aq_img, b, s_img, B))
+            if to_ao is not None:
+                to_ao.quantize_input(o[b, :s_txt], out=_rows(aq_txt, b, s_txt, B))
+        if to_ao is None:
+            to_o.forward_q(aq_img, epilogue=N.EPI_GATE_RESIDUAL, gate=gate_msa, res=x, rows_per_batch=s_img, out=x_new)
+        else:
+            QLinear.forward_q_pair(to_o, aq_img, to_ao, aq_txt, epilogue=N.EPI_GATE_RESIDUAL, gate0=gate_msa, res0=x, rpb0=s_img, out0=x_new,
+                                   gate1=c_gate_msa, res1=e, rpb1=s_txt, out1=e_new)
+    else:
+        for b in range(B):
+            ai = o[b, s_txt:]
+            aqi = to_o.quantize_input(ai) if to_o.quant_type is not None else ai
+            if context_pre_only:
+                to_o.forward_q(aqi, epilogue=N.EPI_GATE_RESIDUAL, gate=gate_msa[b:b + 1], res=x[b * s_img:(b + 1) * s_img], rows_per_batch=s_img,
+                               out=x_new[b * s_img:(b + 1) * s_img])
+                continue
+            at = o[b, :s_txt]
+            aqt = to_ao.quantize_input(at) if to_ao.quant_type is not None else at
+            QLinear.forward_q_pair(to_o, aqi, to_ao, aqt, epilogue=N.EPI_GATE_RESIDUAL,
+                                   gate0=gate_msa[b:b + 1], res0=x[b * s_img:(b + 1) * s_img], rpb0=s_img, out0=x_new[b * s_img:(b + 1) * s_img],
+                                   gate1=c_gate_msa[b:b + 1], res1=e[b * s_txt:(b + 1) * s_txt], rpb1=s_txt, out1=e_new[b * s_txt:(b + 1) * s_txt])
     if attn2 is not None:
         # second, image-only attention on the same LayerNorm output with its own modulation (sd35.py:166-169)
         shift_msa2, scale_msa2, gate_msa2 = im[6:]
