@@ -40,6 +40,7 @@ SIGNATURES = {
     "fdm_set_gemm_dispatch": (I32, [I32, I32, I32]),
     "fdm_gemm_w8a8_int8": (I32, [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_gemm_bf16": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
+    "fdm_conv2d_3x3_nhwc_bf16": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, I32, P]),
     "fdm_linear_skinny_bf16": (I32, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, P]),
     "fdm_attn_fwd": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I32, I32, P, I64, P]),
     "fdm_attn_fwd_workspace_bytes": (I64, [I32]),
@@ -53,6 +54,8 @@ SIGNATURES = {
     "fdm_gate_residual": (I32, [P, P, P, P, I64, I64, I32, I64, P]),
     "fdm_group_norm_workspace_bytes": (I64, [I64, I64, I64, I32]),
     "fdm_group_norm": (I32, [P, P, P, P, P, I64, I64, I64, I32, F32, I32, P, I64, P]),
+    "fdm_group_norm_nhwc_workspace_bytes": (I64, [I64, I64, I64, I32]),
+    "fdm_group_norm_nhwc": (I32, [P, P, P, P, P, I64, I64, I64, I32, F32, I32, P, I64, P]),
     "fdm_gelu_and_mul_quant": (I32, [P, P, P, I32, P, I64, I32, P]),
     "fdm_gelu": (I32, [P, P, I64, I32, P]),
     "fdm_quant_rowwise_cat2": (I32, [P, P, P, I32, P, I32, I64, P, I32, I64, I64, P]),

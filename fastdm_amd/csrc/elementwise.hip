@@ -1004,6 +1004,115 @@ __global__ void __launch_bounds__(GN_THREADS) group_norm_apply_kernel(bf16_t* __
   }
 }
 
+// ---- the same GroupNorm (+ addend, + SiLU) on an NHWC tensor [batch, hw, C] (round 6: the layout of fdm_conv2d_3x3_nhwc_bf16).  A group's
+// channels are cpg = C / groups neighbours in EVERY pixel, so a thread owns one 8-channel vector position and walks down the pixels of its
+// slice: its affine coefficients are loop constants.  Statistics: per-thread fp32 (sum, sum of squares) over <= 64 pixels, reduced over the
+// block's pixel lanes and the group's channels in a fixed order, merged over the slices in double by the apply kernel (deterministic; the
+// partial sums are short enough that E[x^2] - mean^2 is formed in double from exact-to-fp32 parts).  cpg is even (a vector never splits a
+// channel pair) but not a multiple of 8 (C = 320: 10), so a vector may straddle two groups: per-channel bookkeeping, not per-vector.
+constexpr int GNH_MAXT = 512;
+__global__ void __launch_bounds__(GNH_MAXT) group_norm_nhwc_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ addend, float* __restrict__ part,
+                                                                        int hw, int channels, int groups, int P, int rpi) {
+  extern __shared__ float gsm[];      // [rpi][channels] sums, then [rpi][channels] sums of squares
+  const int nv = channels >> 3, cpg = channels / groups;
+  const int slice = blockIdx.x, b = blockIdx.y;
+  const int r0 = (int)((int64_t)hw * slice / P), r1 = (int)((int64_t)hw * (slice + 1) / P);
+  const int rsub = (int)threadIdx.x / nv, vec = (int)threadIdx.x - rsub * nv;
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+  Vec8 ad;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ad.v[j] = 0.f;
+  if (addend != nullptr) ad = load8(addend + (int64_t)b * channels + vec * 8);
+  const bf16_t* src = x + ((int64_t)b * hw) * channels + vec * 8;
+  for (int r = r0 + rsub; r < r1; r += rpi) {
+    Vec8 xv = load8(src + (int64_t)r * channels);
+    if (addend != nullptr) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xv.v[j] = rbf(xv.v[j] + ad.v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s[j] += xv.v[j];
+      q[j] = __builtin_fmaf(xv.v[j], xv.v[j], q[j]);
+    }
+  }
+  float* ssum = gsm;
+  float* ssq = gsm + rpi * channels;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ssum[rsub * channels + vec * 8 + j] = s[j];
+    ssq[rsub * channels + vec * 8 + j] = q[j];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < groups) {      // group g: its channels in order, each channel's pixel lanes in order
+    const int g = threadIdx.x;
+    double ts = 0.0, tq = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c)
+      for (int rr = 0; rr < rpi; ++rr) {
+        ts += (double)ssum[rr * channels + c];
+        tq += (double)ssq[rr * channels + c];
+      }
+    float* o = part + (((int64_t)b * P + slice) * groups + g) * 2;
+    o[0] = (float)ts;
+    o[1] = (float)tq;
+  }
+}
+
+template <bool SILU>
+__global__ void __launch_bounds__(GNH_MAXT) group_norm_nhwc_apply_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ x, const bf16_t* __restrict__ addend,
+                                                                        const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                                                        const float* __restrict__ part, int hw, int channels, int groups, int P, int rpi, float eps) {
+  __shared__ float smean[64], srstd[64];
+  const int nv = channels >> 3, cpg = channels / groups;
+  const int slice = blockIdx.x, b = blockIdx.y;
+  const int r0 = (int)((int64_t)hw * slice / P), r1 = (int)((int64_t)hw * (slice + 1) / P);
+  const int rsub = (int)threadIdx.x / nv, vec = (int)threadIdx.x - rsub * nv;
+  if ((int)threadIdx.x < groups) {
+    const int g = threadIdx.x;
+    double ts = 0.0, tq = 0.0;
+    for (int i = 0; i < P; ++i) {      // fixed order over the slices
+      const float* pp = part + (((int64_t)b * P + i) * groups + g) * 2;
+      ts += (double)pp[0];
+      tq += (double)pp[1];
+    }
+    const double n = (double)hw * cpg, mean = ts / n;
+    double var = tq / n - mean * mean;      // biased, as F.group_norm
+    if (var < 0.0) var = 0.0;
+    smean[g] = (float)mean;
+    srstd[g] = 1.0f / sqrtf((float)var + eps);
+  }
+  __syncthreads();
+  float a[8], bb[8];
+  Vec8 ad;
+  {
+    const Vec8 gm = load8(gamma + vec * 8), bt = load8(beta + vec * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (vec * 8 + j) / cpg;
+      a[j] = srstd[g] * gm.v[j];
+      bb[j] = bt.v[j] - a[j] * smean[g];
+      ad.v[j] = 0.f;
+    }
+    if (addend != nullptr) ad = load8(addend + (int64_t)b * channels + vec * 8);
+  }
+  const bf16_t* src = x + ((int64_t)b * hw) * channels + vec * 8;
+  bf16_t* dst = out + ((int64_t)b * hw) * channels + vec * 8;
+  for (int r = r0 + rsub; r < r1; r += rpi) {
+    Vec8 xv = load8(src + (int64_t)r * channels);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = xv.v[j];
+      if (addend != nullptr) v = rbf(v + ad.v[j]);
+      float y = rbf(__builtin_fmaf(a[j], v, bb[j]));
+      if constexpr (SILU) y = y / (1.0f + expf(-y));
+      xv.v[j] = y;
+    }
+    store8(dst + (int64_t)r * channels, xv);
+  }
+}
+
 }  // namespace fdm
 
 using namespace fdm;
@@ -1341,6 +1450,52 @@ int fdm_group_norm(void* out, const void* x, const void* gamma, const void* beta
   if (per_thread <= 4) FDM_GN_LAUNCH(4);
   else FDM_GN_LAUNCH(8);
 #undef FDM_GN_LAUNCH
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
+}
+
+// slices of the pixel axis for the NHWC form: enough blocks for ~4 per CU, at least 64 pixels per pixel lane of a block
+static int gnh_slices(int64_t batch, int64_t hw, int rpi) {
+  int64_t P = (1024 + batch - 1) / batch;
+  const int64_t cap = hw / ((int64_t)rpi * 8) > 0 ? hw / ((int64_t)rpi * 8) : 1;
+  if (P > cap) P = cap;
+  if (P < 1) P = 1;
+  return (int)P;
+}
+static int gnh_rpi(int64_t channels) {
+  const int nv = (int)(channels >> 3);
+  int rpi = 256 / nv;
+  return rpi < 1 ? 1 : rpi;
+}
+
+int64_t fdm_group_norm_nhwc_workspace_bytes(int64_t batch, int64_t channels, int64_t hw, int groups) {
+  if (batch <= 0 || channels <= 0 || hw <= 0 || groups <= 0 || channels % groups) return 0;
+  return batch * (int64_t)gnh_slices(batch, hw, gnh_rpi(channels)) * groups * 8;
+}
+
+int fdm_group_norm_nhwc(void* out, const void* x, const void* gamma, const void* beta, const void* addend, int64_t batch, int64_t channels, int64_t hw,
+                        int groups, float eps, int act, void* workspace, int64_t workspace_bytes, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (!out || !x || !gamma || !beta || batch < 0 || channels <= 0 || hw <= 0 || groups <= 0 || channels % groups) return FDM_ERR_INVALID;
+  if (!aligned16(out) || !aligned16(x) || !aligned16(gamma) || !aligned16(beta) || !aligned16(addend)) return FDM_ERR_INVALID;
+  if (act != 0 && act != 1) return FDM_ERR_UNSUPPORTED;
+  const int cpg = (int)(channels / groups);
+  if ((channels & 7) || (cpg & 1) || groups > 64 || channels > 8 * GNH_MAXT || batch > 65535 || hw >= ((int64_t)1 << 31)) return FDM_ERR_UNSUPPORTED;
+  if (batch == 0) return FDM_OK;
+  const int nv = (int)(channels >> 3), rpi = gnh_rpi(channels), threads = nv * rpi;
+  const int P = gnh_slices(batch, hw, rpi);
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15) || workspace_bytes < batch * (int64_t)P * groups * 8) return FDM_ERR_INVALID;
+  if (threads < groups) return FDM_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)P, (unsigned)batch);
+  hipStream_t s = to_stream(stream);
+  float* part = reinterpret_cast<float*>(workspace);
+  const size_t shm = (size_t)2 * rpi * channels * sizeof(float);
+  group_norm_nhwc_stats_kernel<<<grid, threads, shm, s>>>((const bf16_t*)x, (const bf16_t*)addend, part, (int)hw, (int)channels, groups, P, rpi);
+  FDM_CHECK_LAUNCH();
+  if (act) group_norm_nhwc_apply_kernel<true><<<grid, threads, 0, s>>>((bf16_t*)out, (const bf16_t*)x, (const bf16_t*)addend, (const bf16_t*)gamma,
+                                                                       (const bf16_t*)beta, part, (int)hw, (int)channels, groups, P, rpi, eps);
+  else group_norm_nhwc_apply_kernel<false><<<grid, threads, 0, s>>>((bf16_t*)out, (const bf16_t*)x, (const bf16_t*)addend, (const bf16_t*)gamma,
+                                                                    (const bf16_t*)beta, part, (int)hw, (int)channels, groups, P, rpi, eps);
   FDM_CHECK_LAUNCH();
   return FDM_OK;
 }

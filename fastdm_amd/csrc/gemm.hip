@@ -77,6 +77,10 @@ struct GemmProblem {
   int gate_f32;      // the gate vector is fp32 and the epilogue rounds once
   int plane_cols;    // > 0: output column n lands in plane n / plane_cols at column n % plane_cols (fused-qkv -> q|k|v planes)
   int64_t plane_stride;  // elements between planes
+  // 3 x 3 convolution as an implicit GEMM (gemm_kernel<DT_BF16, RES, NWN, true>, fdm_conv2d_3x3_nhwc_bf16): A is an NHWC image
+  // [batch, cv_hin, cv_win, cv_cin] and row m = (b, y, x) of the virtual A matrix is the 3 x 3 x cv_cin patch around input pixel
+  // (y * stride + dy - 1, x * stride + dx - 1), K ordered (tap, channel); cv_up: the input is read through a nearest-neighbour 2x upsampling
+  int cv_hin, cv_win, cv_hout, cv_wout, cv_cin, cv_stride, cv_up;
 };
 
 struct GemmGroup {
@@ -221,8 +225,13 @@ __device__ __forceinline__ void unpack4(const i32x2 v, float (&o)[4]) {
 // (2 x 2 of the same wave tiles), 3 stages of 24 KiB so that TWO blocks share a CU -- the same 8 waves per CU, scheduled as two independent units:
 // launches whose tile count leaves most of a round empty (SD3.5's N = 2432: 350 tiles on 256 CUs; the SDXL level-2 layers: 40-120 tiles)
 // get twice the number of work items at half the size.  Same per-wave code: fragments, MFMA order, epilogue.
-template <int DT, bool RES, int NWN = 4>
+// CONV (round 6, bf16 only): the A operand is gathered from an NHWC image, 3 x 3 taps, zero padding 1 (GemmProblem::cv_*): a K step of 64 bytes
+// is 32 channels of ONE tap (cv_cin % 32 == 0), so a staging round's source row is the patch pixel of that tap or the zero page.  The SDXL
+// UNet's convolutions: fp32 accumulation over all 9 C_in products (MIOpen's bf16 kernels were the whole distance of BASELINE configs[0] from
+// the two-implementation envelope, profiles/r06g_sdxl_isolate.txt) on the 8-wave kernel's checked staging; same fragments, MFMAs and epilogue.
+template <int DT, bool RES, int NWN = 4, bool CONV = false>
 __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp) {
+  static_assert(!CONV || DT == DT_BF16, "implicit-GEMM convolution: bf16");
   using M = Mma<DT>;
   using Acc = typename M::Acc;
   using Frag = typename M::Frag;
@@ -319,13 +328,49 @@ __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp)
   // zero-fills the stage): the loop body is branch-free, s_waitcnt counts are constants, the K tail and the
   // odd-step padding both multiply zeros.
   const uint8_t* zero_page = g_zero_page;
+  // CONV: this lane's output pixel of staging round i -- (y * stride - 1, x * stride - 1) of the patch origin in (upsampled) input
+  // coordinates and the image's first pixel; rows past M have an origin no tap can bring inside the image
+  int cy[RA], cx[RA], cb[RA];
+  int c_tap = 0, c_cs = 0;       // tap and 32-channel slice of the NEXT stage() call (stage() is called with kt = 0, 1, 2, ... in order)
+  if constexpr (CONV) {
+    const int hw = p.cv_hout * p.cv_wout;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int m = m0 + i * RPR + srow;
+      const int b = m / hw, rem = m - b * hw, y = rem / p.cv_wout, x = rem - y * p.cv_wout;
+      cy[i] = m < p.M ? y * p.cv_stride - 1 : -(1 << 20);
+      cx[i] = x * p.cv_stride - 1;
+      cb[i] = b * p.cv_hin * p.cv_win;
+    }
+  }
   auto stage = [&](int kt) {
     uint8_t* sA = smem + slot_of(kt) * SBYTES + wave * 1024;
     uint8_t* sB = sA + BM * BKB;
     const int64_t koff = (int64_t)kt * BKB;
     const bool ok = koff + schunk * 16 < Kb;
+    if constexpr (CONV) {
+      const int dy = c_tap / 3, dx = c_tap - 3 * dy;       // (wave-uniform; taps >= 9 only past the end of K: ok is false there)
+      const int hlim = p.cv_up ? 2 * p.cv_hin : p.cv_hin, wlim = p.cv_up ? 2 * p.cv_win : p.cv_win;
+      const int64_t coff = (int64_t)c_cs * BKB + schunk * 16;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) glds16(ok ? ga[i] + koff : zero_page, sA + i * RBYTES);
+      for (int i = 0; i < RA; ++i) {
+        int iy = cy[i] + dy, ix = cx[i] + dx;
+        const bool in = ok && (unsigned)iy < (unsigned)hlim && (unsigned)ix < (unsigned)wlim;
+        if (p.cv_up) {
+          iy >>= 1;
+          ix >>= 1;
+        }
+        const int64_t pix = (int64_t)cb[i] + (int64_t)iy * p.cv_win + ix;
+        glds16(in ? p.A + pix * ((int64_t)p.cv_cin * 2) + coff : zero_page, sA + i * RBYTES);
+      }
+      if (++c_cs == p.cv_cin / 32) {
+        c_cs = 0;
+        ++c_tap;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < RA; ++i) glds16(ok ? ga[i] + koff : zero_page, sA + i * RBYTES);
+    }
 #pragma unroll
     for (int i = 0; i < RB; ++i) glds16(ok ? gb[i] + koff : zero_page, sB + i * RBYTES);
   };
@@ -479,7 +524,7 @@ __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp)
       }
     };
     const int nk2 = (nk + 1) & ~1;
-    const int nk_full = (int)(Kb / BKB);          // slices that lie completely inside K
+    const int nk_full = CONV ? 0 : (int)(Kb / BKB);          // slices that lie completely inside K (CONV: every A slice is gathered: the checked form)
     int t = 0;
     for (; t + 4 < nk_full; t += 2) {              // issues slices t+3 and t+4: both complete
       step(std::true_type{}, fb0, fb1, t);
@@ -2096,6 +2141,49 @@ int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias, int
   g.p[0].bias = (const bf16_t*)bias;
   finish_group(g, 1);
   return launch_gemm<DT_BF16>(g, to_stream(stream));
+}
+
+int fdm_conv2d_3x3_nhwc_bf16(void* out, const void* x, const void* w, const void* bias, const void* res, const void* res_gate,
+                             int64_t batch, int64_t h_in, int64_t w_in, int64_t c_in, int64_t c_out, int stride, int upsample2x,
+                             fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (!out || !x || !w || batch < 0 || h_in <= 0 || w_in <= 0 || c_in <= 0 || c_out <= 0) return FDM_ERR_INVALID;
+  if ((stride != 1 && stride != 2) || (upsample2x != 0 && upsample2x != 1) || (upsample2x && stride != 1)) return FDM_ERR_UNSUPPORTED;
+  if ((c_in % 32) || (c_out % 8)) return FDM_ERR_UNSUPPORTED;      // a 64-byte K step is 32 channels of one tap; 16-byte output pieces
+  if (batch == 0) return FDM_OK;
+  const int64_t h_out = upsample2x ? 2 * h_in : (h_in - 1) / stride + 1, w_out = upsample2x ? 2 * w_in : (w_in - 1) / stride + 1;
+  const int64_t M = batch * h_out * w_out, K = 9 * c_in;
+  if (M > 0x7fffffff || batch * h_in * w_in > 0x7fffffff) return FDM_ERR_UNSUPPORTED;
+  if ((res != nullptr) != (res_gate != nullptr)) return FDM_ERR_INVALID;
+  GemmGroup g;
+  // (lda is not used by the gathered A operand; K = ldb = 9 * c_in: the weights are [c_out][3][3][c_in])
+  int rc = fill_problem(g.p[0], out, x, w, M, c_out, K, K, K, c_out, 2, res ? FDM_EPI_GATE_RESIDUAL : FDM_EPI_NONE, res_gate, 0, res, M);
+  if (rc != FDM_OK) return rc;
+  GemmProblem& p = g.p[0];
+  p.bias = (const bf16_t*)bias;
+  p.cv_hin = (int)h_in;
+  p.cv_win = (int)w_in;
+  p.cv_hout = (int)h_out;
+  p.cv_wout = (int)w_out;
+  p.cv_cin = (int)c_in;
+  p.cv_stride = stride;
+  p.cv_up = upsample2x;
+  finish_group(g, 1);
+  hipStream_t s = to_stream(stream);
+  if (half_tiles_pay(g)) {      // the 8-wave kernel's 256 x 128 half tiles where its cost model prefers them (C_out = 320, 640: 128-wide tiles waste less of N)
+    GemmGroup g2 = g;
+    g2.p[0].tiles_n = (int)((c_out + BN / 2 - 1) / (BN / 2));
+    g2.total_tiles = g2.n_blocks = g2.p[0].tiles_m * g2.p[0].tiles_n;
+    if (res) gemm_kernel<DT_BF16, true, 2, true><<<g2.total_tiles, GEMM_THREADS / 2, 0, s>>>(g2);
+    else gemm_kernel<DT_BF16, false, 2, true><<<g2.total_tiles, GEMM_THREADS / 2, 0, s>>>(g2);
+    g_last_gemm_kernel = FDM_GEMM_KERNEL_W8_HALF;
+  } else {
+    if (res) gemm_kernel<DT_BF16, true, 4, true><<<g.total_tiles, GEMM_THREADS, 0, s>>>(g);
+    else gemm_kernel<DT_BF16, false, 4, true><<<g.total_tiles, GEMM_THREADS, 0, s>>>(g);
+    g_last_gemm_kernel = FDM_GEMM_KERNEL_W8;
+  }
+  FDM_CHECK_LAUNCH();
+  return FDM_OK;
 }
 
 }  // extern "C"

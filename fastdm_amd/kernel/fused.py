@@ -121,6 +121,17 @@ def group_norm(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Te
     a multiple of 8 and FDM_GN_TORCH=1 (A/B runs) take the torch calls -- the same library ops the reference makes there."""
     B, C, H, W = x.shape
     hw = H * W
+    if (x.dtype == BF16 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last) and C % groups == 0 and C % 8 == 0
+            and (C // groups) % 2 == 0 and groups <= 64 and C <= 4096 and B <= 65535 and os.environ.get("FDM_GN_TORCH", "0") != "1"
+            and all(t.dtype == BF16 and t.is_contiguous() and t.numel() == C and t.device == x.device for t in (gamma, beta))):
+        # channels-last activations (the layout of the HIP convolution): the NHWC form of the same two kernels
+        if addend is not None:
+            assert addend.shape == (B, C) and addend.dtype == BF16 and addend.is_contiguous()
+        ws = _gn_ws.get(x.device, N.lib().fdm_group_norm_nhwc_workspace_bytes(B, C, hw, groups))
+        out = torch.empty_like(x)          # preserves the channels_last strides
+        N.check(N.lib().fdm_group_norm_nhwc(N.ptr(out), N.ptr(x), N.ptr(gamma), N.ptr(beta), N.ptr(addend), B, C, hw, groups, eps, 1 if silu else 0,
+                                            N.ptr(ws), ws.numel(), N.stream()), "group_norm_nhwc")
+        return out
     affine_ok = all(t.dtype == BF16 and t.is_contiguous() and t.numel() == C and t.device == x.device for t in (gamma, beta))   # read as raw bf16[C]
     if (x.dtype != BF16 or not x.is_contiguous() or (hw & 7) or C % groups or B * groups > 65535 or (C // groups) * hw >= (1 << 31)
             or not affine_ok or os.environ.get("FDM_GN_TORCH", "0") == "1"):
@@ -134,6 +145,44 @@ def group_norm(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Te
     N.check(N.lib().fdm_group_norm(N.ptr(out), N.ptr(x), N.ptr(gamma), N.ptr(beta), N.ptr(addend), B, C, hw, groups, eps, 1 if silu else 0,
                                    N.ptr(ws), ws.numel(), N.stream()), "group_norm")
     return out
+
+
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, padding: int = 0, upsample: bool = False,
+           res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.conv2d of the UNet's call sites (reference layer/resnetblock.py:29-47, layer/unetblock.py:203-240, cuDNN there) [+ the nearest 2x
+    upsampling in front of it] [+ the residual add behind it].  3 x 3 / padding 1 convolutions of channels-last bf16 tensors with
+    C_in % 32 == 0 and C_out % 8 == 0 run as an implicit GEMM on the HIP tile kernel (fdm_conv2d_3x3_nhwc_bf16: fp32 accumulation over all
+    9 C_in products, one rounding); everything else -- NCHW activations, conv_in's 4 input and conv_out's 4 output channels, 1 x 1 shortcuts,
+    FDM_CONV_TORCH=1 (A/B) -- takes the library call the reference makes.  `weight` is the [O, I, 3, 3] tensor in channels_last memory
+    format: its bytes ARE the [O, 3, 3, I] layout the kernel reads."""
+    import torch.nn.functional as F
+    B, C, H, W = x.shape
+    O = weight.shape[0]
+    hip = (x.dtype == BF16 and weight.dtype == BF16 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and padding == 1 and stride in (1, 2)
+           and not (upsample and stride != 1) and C % 32 == 0 and O % 8 == 0 and weight.shape[1] == C
+           and x.is_contiguous(memory_format=torch.channels_last) and weight.is_contiguous(memory_format=torch.channels_last)
+           and (bias is None or (bias.dtype == BF16 and bias.is_contiguous()))
+           and (res is None or (res.dtype == BF16 and res.is_contiguous(memory_format=torch.channels_last)))
+           and os.environ.get("FDM_CONV_TORCH", "0") != "1")
+    if not hip:
+        if upsample:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        y = F.conv2d(x, weight, bias, stride, padding)
+        return y if res is None else res + y
+    Ho, Wo = (2 * H, 2 * W) if upsample else ((H - 1) // stride + 1, (W - 1) // stride + 1)
+    out = torch.empty((B, O, Ho, Wo), device=x.device, dtype=BF16, memory_format=torch.channels_last)
+    ones = None
+    if res is not None:
+        assert res.shape == out.shape
+        ones = _conv_ones.get((x.device, O))
+        if ones is None:
+            ones = _conv_ones[(x.device, O)] = torch.ones(O, device=x.device, dtype=BF16)
+    N.check(N.lib().fdm_conv2d_3x3_nhwc_bf16(N.ptr(out), N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(res), N.ptr(ones), B, H, W, C, O, stride,
+                                             1 if upsample else 0, N.stream()), "conv2d_3x3_nhwc")
+    return out
+
+
+_conv_ones = {}
 
 
 def gelu(x: torch.Tensor, approximate: str = "none") -> torch.Tensor:

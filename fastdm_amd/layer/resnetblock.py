@@ -25,14 +25,15 @@ class ResnetBlock2D:
         self.convshortcut_weight = self.convshortcut_bias = None
 
     @staticmethod
-    def _gn_silu_conv3(x, gamma, beta, weight, bias, addend=None):
+    def _gn_silu_conv3(x, gamma, beta, weight, bias, addend=None, res=None):
         """[x + addend[:, :, None, None] ->] GroupNorm(32, eps 1e-5) -> SiLU -> 3x3 convolution (stride 1, padding 1).  The element-wise
-        part is one fused HIP op (kernel/fused.py:group_norm, NCHW); the convolution is MIOpen."""
-        return F.conv2d(fused.group_norm(x, 32, gamma, beta, 1e-05, addend=addend, silu=True), weight, bias, 1, 1)
+        part is one fused HIP op (kernel/fused.py:group_norm, NCHW or NHWC); the convolution is the HIP implicit GEMM for channels-last
+        activations (kernel/fused.py:conv2d), MIOpen otherwise.  res: added behind the convolution (the block's skip connection)."""
+        return fused.conv2d(fused.group_norm(x, 32, gamma, beta, 1e-05, addend=addend, silu=True), weight, bias, 1, 1, res=res)
 
     def forward(self, input_tensor, temb):
         h = self._gn_silu_conv3(input_tensor, self.norm1_gamma, self.norm1_beta, self.conv1_weight, self.conv1_bias)
         shift = self.time_emb_proj.forward(F.silu(temb))                   # [B, C_out]: per-channel offset from the time embedding
-        h = self._gn_silu_conv3(h, self.norm2_gamma, self.norm2_beta, self.conv2_weight, self.conv2_bias, addend=shift.contiguous())
         skip = input_tensor if not self.conv_shortcut else F.conv2d(input_tensor, self.convshortcut_weight, self.convshortcut_bias, 1)
-        return skip + h
+        # skip + h: the add rides in the convolution's epilogue (channels-last + HIP convolution), same roundings as the separate add
+        return self._gn_silu_conv3(h, self.norm2_gamma, self.norm2_beta, self.conv2_weight, self.conv2_bias, addend=shift.contiguous(), res=skip)

@@ -188,7 +188,7 @@ class DownBlock2D:
         for module in self.resnets:
             hidden_states = module.forward(hidden_states, temb)
             output_states.append(hidden_states)
-        hidden_states = F.conv2d(hidden_states, self.downsample_conv_weight, self.downsample_conv_bias, 2, 1)
+        hidden_states = fused.conv2d(hidden_states, self.downsample_conv_weight, self.downsample_conv_bias, 2, 1)
         output_states.append(hidden_states)
         return hidden_states, output_states
 
@@ -212,7 +212,7 @@ class CrossAttnDownBlock2D:
             hidden_states = attn.forward(hidden_states, encoder_hidden_states=encoder_hidden_states, transformer_options=transformer_options)
             output_states.append(hidden_states)
         if self.has_downsamplers:
-            hidden_states = F.conv2d(hidden_states, self.downsample_conv_weight, self.downsample_conv_bias, 2, 1)
+            hidden_states = fused.conv2d(hidden_states, self.downsample_conv_weight, self.downsample_conv_bias, 2, 1)
             output_states.append(hidden_states)
         return hidden_states, output_states
 
@@ -236,8 +236,8 @@ class CrossAttnUpBlock2D:
             hidden_states = torch.cat([hidden_states, res_hidden_states], dim=1)
             hidden_states = resnet.forward(hidden_states, temb)
             hidden_states = attn.forward(hidden_states, encoder_hidden_states=encoder_hidden_states, transformer_options=transformer_options)
-        hidden_states = F.interpolate(hidden_states, scale_factor=2.0, mode="nearest")
-        return F.conv2d(hidden_states, self.upsample_conv_weight, self.upsample_conv_bias, 1, 1)
+        # nearest 2x upsampling + 3 x 3 convolution: one HIP launch that reads the low-resolution tensor through the upsampling (channels-last)
+        return fused.conv2d(hidden_states, self.upsample_conv_weight, self.upsample_conv_bias, 1, 1, upsample=True)
 
 
 class UpBlock2D:

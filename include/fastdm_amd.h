@@ -201,6 +201,21 @@ int fdm_gemm_last_kernel(void);
  *   half_tiles -1 the cost model | 0 never | 1 always (8-wave kernel only)                                                               */
 int fdm_set_gemm_dispatch(int kernel, int p4, int half_tiles);
 
+/* ---- 3 x 3 convolution, NHWC bf16, as an implicit GEMM on the 8-wave tile kernel (ABI 19) ----------------------------------------
+ * The UNet's convolutions (/root/reference/fastdm/layer/resnetblock.py:29-47 conv1 / conv2, fastdm/layer/unetblock.py:203-218 downsample
+ * (stride 2), :232-240 upsample (nearest 2x, then the convolution), F.conv2d there = cuDNN) with fp32 accumulation over all 9 * c_in products
+ * and ONE rounding: out[b, y, x, :] = bf16(sum_{dy, dx, c} x[b, y * stride + dy - 1, x * stride + dx - 1, c] * w[:, dy, dx, c] + bias)
+ * with zero padding 1; upsample2x: x is read through a nearest-neighbour 2x upsampling (stride 1 only), so the upsampled tensor never exists.
+ *   x    [batch, h_in, w_in, c_in]   NHWC bf16 (a channels_last torch tensor's memory), c_in % 32 == 0
+ *   w    [c_out, 3, 3, c_in]         bf16 (the checkpoint's OIHW weight permuted once at load), c_out % 8 == 0
+ *   out  [batch, h_out, w_out, c_out], h_out = (h_in - 1) / stride + 1 (2 * h_in with upsample2x)
+ *   res / res_gate (both or neither): out = bf16(res + bf16(res_gate[c] * y)), res like out, res_gate bf16 [c_out] -- a ResNet block's skip
+ *   connection with a vector of ones (x + h, resnetblock.py:47), rounded like the two torch ops.
+ * FDM_ERR_UNSUPPORTED for other strides / channel counts (the caller keeps F.conv2d for conv_in's 4 channels).                          */
+int fdm_conv2d_3x3_nhwc_bf16(void* out, const void* x, const void* w, const void* bias, const void* res, const void* res_gate,
+                             int64_t batch, int64_t h_in, int64_t w_in, int64_t c_in, int64_t c_out, int stride, int upsample2x,
+                             fdm_stream_t stream);
+
 /* ---- bf16 GEMM (QLinear's un-quantised branch: torch.addmm, layer/qlinear.py:76) --------------
  * out[M,N] = bf16(acc_f32(A[M,K] bf16 row-major x B[K,N] bf16 column-major) + bias[N])          */
 int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias,
@@ -327,6 +342,14 @@ int64_t fdm_group_norm_workspace_bytes(int64_t batch, int64_t channels, int64_t 
 int fdm_group_norm(void* out, const void* x, const void* gamma, const void* beta, const void* addend,
                    int64_t batch, int64_t channels, int64_t hw, int groups, float eps, int act,
                    void* workspace, int64_t workspace_bytes, fdm_stream_t stream);
+
+/* The same GroupNorm on an NHWC tensor [batch, hw, channels] (ABI 19; the layout of fdm_conv2d_3x3_nhwc_bf16): same rounding order, same
+ * arguments.  channels % 8 == 0, an even number of channels per group, groups <= 64, channels <= 4096 (FDM_ERR_UNSUPPORTED otherwise); gamma /
+ * beta / addend 16-byte aligned.  Statistics: fp32 partial sums of <= 64 pixels per channel, merged in double in a fixed order (deterministic). */
+int64_t fdm_group_norm_nhwc_workspace_bytes(int64_t batch, int64_t channels, int64_t hw, int groups);
+int fdm_group_norm_nhwc(void* out, const void* x, const void* gamma, const void* beta, const void* addend,
+                        int64_t batch, int64_t channels, int64_t hw, int groups, float eps, int act,
+                        void* workspace, int64_t workspace_bytes, fdm_stream_t stream);
 
 /* gelu_and_mul followed by the per-token quantisation of its output (fdm_gelu_and_mul + fdm_quant_*_rowwise in one pass: the GEGLU
  * feed-forward of the UNet, /root/reference/fastdm/layer/unetblock.py:213-224): in [rows, 2d] bf16 -> y = bf16(in[:, :d] * bf16(gelu_erf(in[:, d:])))

@@ -1309,3 +1309,57 @@ def test_deferred_gelu_quantiser_on_every_bf16_input(K, quant, epi):
     gq, rq = got.q.cpu().view(torch.uint8)[ok_rows], q.view(torch.uint8)[ok_rows]
     same = (gq == rq) | ((((gq & 0x7f) == 0) & ((rq & 0x7f) == 0)) if quant == FP8 else torch.zeros_like(gq, dtype=torch.bool))
     assert same.all(), f"{int((~same).sum())} codes differ from the oracle"
+
+
+# ------------------------------------------------------------------ round 6: the UNet's 3 x 3 convolution and GroupNorm on NHWC tensors
+@pytest.mark.parametrize("B,C,H,W,O,stride,up,res", [
+    (2, 320, 64, 64, 320, 1, False, True),       # SDXL level-0 ResNet conv2 (+ skip) at 512 x 512
+    (2, 320, 64, 64, 320, 2, False, False),      # downsample
+    (2, 640, 32, 32, 640, 1, False, True),
+    (2, 960, 32, 32, 640, 1, False, False),      # up block: concatenated skip channels
+    (2, 1280, 16, 16, 1280, 1, True, False),     # nearest 2x upsampling + convolution
+    (1, 32, 33, 31, 328, 1, False, True),        # ragged everything: odd image, C_out not a multiple of the tile
+    (3, 64, 17, 9, 40, 2, False, False),         # stride 2 on odd sizes, three images
+    (1, 32, 5, 7, 8, 1, True, True),
+])
+def test_conv2d_3x3_nhwc_against_fp32_convolution(K, B, C, H, W, O, stride, up, res):
+    """fdm_conv2d_3x3_nhwc_bf16 (implicit GEMM on the 8-wave tile kernel, fp32 accumulation over all 9 * C_in products, one rounding) against
+    F.conv2d in fp32 on the same bf16 operands (reference call sites: layer/resnetblock.py:29-47, layer/unetblock.py:203-240): <= 1 bf16 ulp
+    (fp32 summation order), zero padding, stride 2, the folded nearest-neighbour upsampling and the residual epilogue included."""
+    import torch.nn.functional as F
+    from fastdm_amd.kernel import fused
+    g = gen(B * 1000 + C + H * 7 + O)
+    x = rbf(g, B, C, H, W).contiguous(memory_format=torch.channels_last)
+    w = rbf(g, O, C, 3, 3, scale=(9 * C) ** -0.5).contiguous(memory_format=torch.channels_last)
+    bias = rbf(g, O, scale=0.2)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    y = F.conv2d(xin, w.float(), bias.float(), stride, 1).to(BF16)
+    r = rbf(g, *y.shape).contiguous(memory_format=torch.channels_last) if res else None
+    want = y if r is None else (r.float() + y.float()).to(BF16)
+    got = fused.conv2d(x.cuda(), w.cuda(), bias.cuda(), stride, 1, upsample=up, res=None if r is None else r.cuda())
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    ulp_close(got, want, 0.03, f"conv {B}x{C}x{H}x{W} -> {O} stride {stride} up {up} res {res}")
+
+
+@pytest.mark.parametrize("B,C,H,W,silu,add", [(2, 320, 64, 64, True, False), (2, 640, 32, 32, True, True), (2, 1280, 16, 16, False, False),
+                                              (2, 2560, 16, 16, True, True), (1, 960, 9, 5, True, True), (3, 64, 7, 3, False, True)])
+def test_group_norm_nhwc_matches_the_nchw_kernel_and_torch(K, B, C, H, W, silu, add):
+    """fdm_group_norm_nhwc (channels-last form of the fused [x + temb] -> GroupNorm(32) -> [SiLU] chain) against the torch chain of the
+    reference's call sites with fp32 statistics (resnetblock.py:29-47): <= 1 bf16 ulp; and against the NCHW kernel on the same values."""
+    import torch.nn.functional as F
+    from fastdm_amd.kernel import fused
+    g = gen(C + H * 13 + W)
+    x = rbf(g, B, C, H, W, scale=1.3) + 0.25
+    x = x.to(BF16)
+    gamma, beta = (1.0 + 0.1 * torch.randn(C, generator=g)).to(BF16), (0.1 * torch.randn(C, generator=g)).to(BF16)
+    addend = rbf(g, B, C, scale=0.5) if add else None
+    v = x if addend is None else (x.float() + addend.float()[:, :, None, None]).to(BF16)
+    y = F.group_norm(v.float(), 32, gamma.float(), beta.float(), 1e-5).to(BF16)
+    want = F.silu(y.float()).to(BF16) if silu else y
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    got = fused.group_norm(xd, 32, gamma.cuda(), beta.cuda(), 1e-5, addend=None if addend is None else addend.cuda(), silu=silu)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    ulp_close(got, want, 0.03, f"group_norm nhwc {B}x{C}x{H}x{W}")
+    if (H * W) % 8 == 0:
+        nchw = fused.group_norm(x.cuda(), 32, gamma.cuda(), beta.cuda(), 1e-5, addend=None if addend is None else addend.cuda(), silu=silu)
+        ulp_close(got, nchw, 0.01, f"group_norm nhwc vs nchw {B}x{C}x{H}x{W}")
