@@ -1368,7 +1368,7 @@ def test_group_norm_nhwc_matches_the_nchw_kernel_and_torch(K, B, C, H, W, silu, 
     xd = x.cuda().contiguous(memory_format=torch.channels_last)
     got = fused.group_norm(xd, 32, gamma.cuda(), beta.cuda(), 1e-5, addend=None if addend is None else addend.cuda(), silu=silu)
     assert got.is_contiguous(memory_format=torch.channels_last)
-    ulp_close(got, want, 0.03, f"group_norm nhwc {B}x{C}x{H}x{W}")
+    ulp_close(got, want, 0.03, f"group_norm nhwc {B}x{C}x{H}x{W}", ulps=2 if silu else 1)      # (SiLU of a y one ulp apart can land two apart: the NCHW test's rule)
     if (H * W) % 8 == 0:
         nchw = fused.group_norm(x.cuda(), 32, gamma.cuda(), beta.cuda(), 1e-5, addend=None if addend is None else addend.cuda(), silu=silu)
-        ulp_close(got, nchw, 0.01, f"group_norm nhwc vs nchw {B}x{C}x{H}x{W}")
+        ulp_close(got, nchw, 0.01, f"group_norm nhwc vs nchw {B}x{C}x{H}x{W}", ulps=2 if silu else 1)
