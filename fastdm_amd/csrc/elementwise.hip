@@ -1011,6 +1011,7 @@ __global__ void __launch_bounds__(GN_THREADS) group_norm_apply_kernel(bf16_t* __
 // partial sums are short enough that E[x^2] - mean^2 is formed in double from exact-to-fp32 parts).  cpg is even (a vector never splits a
 // channel pair) but not a multiple of 8 (C = 320: 10), so a vector may straddle two groups: per-channel bookkeeping, not per-vector.
 constexpr int GNH_MAXT = 512;
+constexpr int GNH_ROWS = 8;      // pixels a thread holds in registers: a slice is at most GNH_ROWS * rpi pixels
 __global__ void __launch_bounds__(GNH_MAXT) group_norm_nhwc_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ addend, float* __restrict__ part,
                                                                         int hw, int channels, int groups, int P, int rpi) {
   extern __shared__ float gsm[];      // [rpi][channels] sums, then [rpi][channels] sums of squares
@@ -1026,16 +1027,27 @@ __global__ void __launch_bounds__(GNH_MAXT) group_norm_nhwc_stats_kernel(const b
   for (int j = 0; j < 8; ++j) ad.v[j] = 0.f;
   if (addend != nullptr) ad = load8(addend + (int64_t)b * channels + vec * 8);
   const bf16_t* src = x + ((int64_t)b * hw) * channels + vec * 8;
-  for (int r = r0 + rsub; r < r1; r += rpi) {
-    Vec8 xv = load8(src + (int64_t)r * channels);
-    if (addend != nullptr) {
+  // a thread's <= GNH_ROWS pixels are requested back to back (one load in flight per thread left the kernel latency-bound: 74 us per launch)
+  i32x4 raw[GNH_ROWS];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xv.v[j] = rbf(xv.v[j] + ad.v[j]);
-    }
+  for (int k = 0; k < GNH_ROWS; ++k) {
+    const int r = r0 + rsub + k * rpi;
+    if (r < r1) raw[k] = *reinterpret_cast<const i32x4*>(src + (int64_t)r * channels);
+  }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      s[j] += xv.v[j];
-      q[j] = __builtin_fmaf(xv.v[j], xv.v[j], q[j]);
+  for (int k = 0; k < GNH_ROWS; ++k) {
+    const int r = r0 + rsub + k * rpi;
+    if (r < r1) {
+      Vec8 xv = unpack8(raw[k]);
+      if (addend != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv.v[j] = rbf(xv.v[j] + ad.v[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s[j] += xv.v[j];
+        q[j] = __builtin_fmaf(xv.v[j], xv.v[j], q[j]);
+      }
     }
   }
   float* ssum = gsm;
@@ -1069,6 +1081,15 @@ __global__ void __launch_bounds__(GNH_MAXT) group_norm_nhwc_apply_kernel(bf16_t*
   const int slice = blockIdx.x, b = blockIdx.y;
   const int r0 = (int)((int64_t)hw * slice / P), r1 = (int)((int64_t)hw * (slice + 1) / P);
   const int rsub = (int)threadIdx.x / nv, vec = (int)threadIdx.x - rsub * nv;
+  i32x4 raw[GNH_ROWS];      // the slice is requested before the partials are merged
+  {
+    const bf16_t* src0 = x + ((int64_t)b * hw) * channels + vec * 8;
+#pragma unroll
+    for (int k = 0; k < GNH_ROWS; ++k) {
+      const int r = r0 + rsub + k * rpi;
+      if (r < r1) raw[k] = *reinterpret_cast<const i32x4*>(src0 + (int64_t)r * channels);
+    }
+  }
   if ((int)threadIdx.x < groups) {
     const int g = threadIdx.x;
     double ts = 0.0, tq = 0.0;
@@ -1099,17 +1120,21 @@ __global__ void __launch_bounds__(GNH_MAXT) group_norm_nhwc_apply_kernel(bf16_t*
   }
   const bf16_t* src = x + ((int64_t)b * hw) * channels + vec * 8;
   bf16_t* dst = out + ((int64_t)b * hw) * channels + vec * 8;
-  for (int r = r0 + rsub; r < r1; r += rpi) {
-    Vec8 xv = load8(src + (int64_t)r * channels);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v = xv.v[j];
-      if (addend != nullptr) v = rbf(v + ad.v[j]);
-      float y = rbf(__builtin_fmaf(a[j], v, bb[j]));
-      if constexpr (SILU) y = y / (1.0f + expf(-y));
-      xv.v[j] = y;
+  for (int k = 0; k < GNH_ROWS; ++k) {
+    const int r = r0 + rsub + k * rpi;
+    if (r < r1) {
+      Vec8 xv = unpack8(raw[k]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = xv.v[j];
+        if (addend != nullptr) v = rbf(v + ad.v[j]);
+        float y = rbf(__builtin_fmaf(a[j], v, bb[j]));
+        if constexpr (SILU) y = y / (1.0f + expf(-y));
+        xv.v[j] = y;
+      }
+      store8(dst + (int64_t)r * channels, xv);
     }
-    store8(dst + (int64_t)r * channels, xv);
   }
 }
 
@@ -1456,11 +1481,9 @@ int fdm_group_norm(void* out, const void* x, const void* gamma, const void* beta
 
 // slices of the pixel axis for the NHWC form: enough blocks for ~4 per CU, at least 64 pixels per pixel lane of a block
 static int gnh_slices(int64_t batch, int64_t hw, int rpi) {
-  int64_t P = (1024 + batch - 1) / batch;
-  const int64_t cap = hw / ((int64_t)rpi * 8) > 0 ? hw / ((int64_t)rpi * 8) : 1;
-  if (P > cap) P = cap;
-  if (P < 1) P = 1;
-  return (int)P;
+  (void)batch;
+  const int64_t per = (int64_t)rpi * GNH_ROWS;      // pixels a block holds in registers
+  return (int)((hw + per - 1) / per);
 }
 static int gnh_rpi(int64_t channels) {
   const int nv = (int)(channels >> 3);

@@ -232,6 +232,10 @@ __device__ __forceinline__ void unpack4(const i32x2 v, float (&o)[4]) {
 template <int DT, bool RES, int NWN = 4, bool CONV = false>
 __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp) {
   static_assert(!CONV || DT == DT_BF16, "implicit-GEMM convolution: bf16");
+  // K ranges of a tile on several blocks, partial accumulators through a workspace, merged by a second launch (mode 1): the int8 GEMMs' exact
+  // split-K tail, and -- round 6 -- the convolutions whose M is too small to fill the chip (SDXL level 2: 2 x 32 x 32 pixels = 8 M tiles;
+  // fp32 partials summed in a fixed order: deterministic)
+  constexpr bool SPLITK = (DT == DT_INT8 || CONV) && NWN == 4;
   using M = Mma<DT>;
   using Acc = typename M::Acc;
   using Frag = typename M::Frag;
@@ -263,7 +267,7 @@ __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp)
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    if constexpr (DT == DT_INT8) {
+    if constexpr (SPLITK) {
       if (grp.mode == 1) {
         t = grp.total_tiles - grp.split_tiles + (bid >> grp.spread_shift);   // merge launch: 1 << spread_shift blocks per tail tile
       } else if (grp.splits > 1) {
@@ -304,12 +308,14 @@ __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp)
 #endif
 
   int64_t Kb = p.Kb, k_off = 0;
-  if constexpr (DT == DT_INT8) {
+  int kt_first = 0;      // CONV: the K step this block starts at (its tap / channel-slice counters start there)
+  if constexpr (SPLITK) {
     if (is_part) {   // K range of this part, in whole 64-byte steps; the last part takes the K tail
       const int nk_all = (int)((p.Kb + BKB - 1) / BKB);
       const int kt0 = (int)((int64_t)part * nk_all / grp.splits), kt1 = (int)((int64_t)(part + 1) * nk_all / grp.splits);
       k_off = (int64_t)kt0 * BKB;
       Kb = min(p.Kb - k_off, (int64_t)(kt1 - kt0) * BKB);
+      kt_first = kt0;
     }
   }
 
@@ -333,6 +339,8 @@ __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp)
   int cy[RA], cx[RA], cb[RA];
   int c_tap = 0, c_cs = 0;       // tap and 32-channel slice of the NEXT stage() call (stage() is called with kt = 0, 1, 2, ... in order)
   if constexpr (CONV) {
+    c_tap = kt_first / (p.cv_cin / 32);
+    c_cs = kt_first - c_tap * (p.cv_cin / 32);
     const int hw = p.cv_hout * p.cv_wout;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -440,7 +448,7 @@ __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp)
 
   // int8 split-K tail, merge launch: the accumulators are the sum of the parts' int32 partials (exact), no K loop
   bool merged = false;
-  if constexpr (DT == DT_INT8 && NWN == 4) {      // (the split-K tail's workspace layout is the 8-wave block's; half tiles are never split)
+  if constexpr (SPLITK) {      // (the split-K tail's workspace layout is the 8-wave block's; half tiles are never split)
     if (grp.mode == 1) {
       // A CU pulls ~11 B/clk, so reading S x 256 KB through one CU costs as much as a good part of the K loop it replaces:
       // a tile is merged by 1, 2 or 4 blocks (as many as fit one round), each running the waves of its share of the tile
@@ -457,7 +465,10 @@ __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp)
             for (int q = 0; q < 4; ++q) {
               const i32x4 v = *reinterpret_cast<const i32x4*>(src + ((i * 2 + j) * 4 + q) * (512 * 4));
 #pragma unroll
-              for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] += v[c];
+              for (int c = 0; c < 4; ++c) {
+                if constexpr (DT == DT_INT8) acc[i][j][4 * q + c] += v[c];
+                else acc[i][j][4 * q + c] += __builtin_bit_cast(float, v[c]);      // fp32 partials, parts in order: deterministic
+              }
             }
       }
     }
@@ -537,9 +548,9 @@ __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp)
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // retire the padding DMAs and the dead fragment reads
   __builtin_amdgcn_s_barrier();                                  // every wave is done with the ring: reuse it below
-  if constexpr (DT == DT_INT8 && NWN == 4) {
+  if constexpr (SPLITK) {
     if (grp.mode == 1 && (wave >> (3 - grp.spread_shift)) != (int)(blockIdx.x & ((1 << grp.spread_shift) - 1))) return;   // merge launch: the other quarters belong to sibling blocks
-    if (is_part) {   // int32 partial sums of this K range -> workspace; the merge launch runs the epilogue
+    if (is_part) {   // partial sums of this K range (int32, or fp32 bits) -> workspace; the merge launch runs the epilogue
       int32_t* dst = grp.ws + ((int64_t)part_slot) * (32 * 512 * 4) + tid * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -549,7 +560,10 @@ __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp)
           for (int q = 0; q < 4; ++q) {
             i32x4 v;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = acc[i][j][4 * q + c];
+            for (int c = 0; c < 4; ++c) {
+              if constexpr (DT == DT_INT8) v[c] = acc[i][j][4 * q + c];
+              else v[c] = __builtin_bit_cast(int, acc[i][j][4 * q + c]);
+            }
             *reinterpret_cast<i32x4*>(dst + ((i * 2 + j) * 4 + q) * (512 * 4)) = v;
           }
       return;
@@ -2145,7 +2159,7 @@ int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias, int
 
 int fdm_conv2d_3x3_nhwc_bf16(void* out, const void* x, const void* w, const void* bias, const void* res, const void* res_gate,
                              int64_t batch, int64_t h_in, int64_t w_in, int64_t c_in, int64_t c_out, int stride, int upsample2x,
-                             fdm_stream_t stream) {
+                             void* workspace, int64_t workspace_bytes, fdm_stream_t stream) {
   (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!out || !x || !w || batch < 0 || h_in <= 0 || w_in <= 0 || c_in <= 0 || c_out <= 0) return FDM_ERR_INVALID;
   if ((stride != 1 && stride != 2) || (upsample2x != 0 && upsample2x != 1) || (upsample2x && stride != 1)) return FDM_ERR_UNSUPPORTED;
@@ -2170,6 +2184,38 @@ int fdm_conv2d_3x3_nhwc_bf16(void* out, const void* x, const void* w, const void
   p.cv_up = upsample2x;
   finish_group(g, 1);
   hipStream_t s = to_stream(stream);
+  if (workspace != nullptr && ((reinterpret_cast<uintptr_t>(workspace) & 15) || workspace_bytes < 0)) return FDM_ERR_INVALID;
+  {
+    // Few pixels, long K (SDXL level 2: 2 x 32 x 32 pixels x 1280 channels = 40 tiles of 180-360 K steps on 256 CUs): every tile's K range is cut
+    // into S parts on S blocks, fp32 partial accumulators go through the workspace and a merge launch sums them in order and runs the epilogue
+    // (the int8 GEMMs' split-K machinery; 239 -> ~100 us where MIOpen takes 154)
+    const int cu = device_cu_count(), tiles = g.total_tiles;
+    const int64_t nk = (K * 2 + BKB - 1) / BKB;
+    int S = 1;
+    if (workspace != nullptr && tiles * 2 <= cu) {
+      S = cu / tiles;
+      if (S > 8) S = 8;
+      if (S > nk / 16) S = (int)(nk / 16);
+      while (S > 1 && (int64_t)tiles * S * SPLIT_PART_BYTES > workspace_bytes) --S;
+    }
+    if (S > 1) {
+      GemmGroup g2 = g;
+      g2.split_tiles = tiles;
+      g2.splits = S;
+      g2.n_blocks = tiles * S;
+      g2.ws = reinterpret_cast<int32_t*>(workspace);
+      if (res) gemm_kernel<DT_BF16, true, 4, true><<<g2.n_blocks, GEMM_THREADS, 0, s>>>(g2);
+      else gemm_kernel<DT_BF16, false, 4, true><<<g2.n_blocks, GEMM_THREADS, 0, s>>>(g2);
+      FDM_CHECK_LAUNCH();
+      g2.mode = 1;
+      g2.spread_shift = tiles * 4 <= cu ? 2 : (tiles * 2 <= cu ? 1 : 0);
+      if (res) gemm_kernel<DT_BF16, true, 4, true><<<tiles << g2.spread_shift, GEMM_THREADS, 0, s>>>(g2);
+      else gemm_kernel<DT_BF16, false, 4, true><<<tiles << g2.spread_shift, GEMM_THREADS, 0, s>>>(g2);
+      FDM_CHECK_LAUNCH();
+      g_last_gemm_kernel = FDM_GEMM_KERNEL_W8;
+      return FDM_OK;
+    }
+  }
   if (half_tiles_pay(g)) {      // the 8-wave kernel's 256 x 128 half tiles where its cost model prefers them (C_out = 320, 640: 128-wide tiles waste less of N)
     GemmGroup g2 = g;
     g2.p[0].tiles_n = (int)((c_out + BN / 2 - 1) / (BN / 2));

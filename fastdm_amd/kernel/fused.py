@@ -177,8 +177,9 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
         ones = _conv_ones.get((x.device, O))
         if ones is None:
             ones = _conv_ones[(x.device, O)] = torch.ones(O, device=x.device, dtype=BF16)
+    ws = N.gemm_int8_workspace(x.device)      # the per-(device, stream) split-K scratch of the tile GEMMs (pinned once a capture has seen it)
     N.check(N.lib().fdm_conv2d_3x3_nhwc_bf16(N.ptr(out), N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(res), N.ptr(ones), B, H, W, C, O, stride,
-                                             1 if upsample else 0, N.stream()), "conv2d_3x3_nhwc")
+                                             1 if upsample else 0, N.ptr(ws), ws.numel(), N.stream()), "conv2d_3x3_nhwc")
     return out
 
 

@@ -211,10 +211,13 @@ int fdm_set_gemm_dispatch(int kernel, int p4, int half_tiles);
  *   out  [batch, h_out, w_out, c_out], h_out = (h_in - 1) / stride + 1 (2 * h_in with upsample2x)
  *   res / res_gate (both or neither): out = bf16(res + bf16(res_gate[c] * y)), res like out, res_gate bf16 [c_out] -- a ResNet block's skip
  *   connection with a vector of ones (x + h, resnetblock.py:47), rounded like the two torch ops.
+ *   workspace (may be NULL: never split): 16-byte aligned scratch, fdm_gemm_int8_workspace_bytes() suffices; a convolution of few pixels and a
+ *   long K (at most half a round of 256 x 256 tiles) is cut into K ranges whose fp32 partial sums go through it and are merged, in a fixed
+ *   order, by a second launch.  Owned by the caller, reusable by consecutive calls on ONE stream.
  * FDM_ERR_UNSUPPORTED for other strides / channel counts (the caller keeps F.conv2d for conv_in's 4 channels).                          */
 int fdm_conv2d_3x3_nhwc_bf16(void* out, const void* x, const void* w, const void* bias, const void* res, const void* res_gate,
                              int64_t batch, int64_t h_in, int64_t w_in, int64_t c_in, int64_t c_out, int stride, int upsample2x,
-                             fdm_stream_t stream);
+                             void* workspace, int64_t workspace_bytes, fdm_stream_t stream);
 
 /* ---- bf16 GEMM (QLinear's un-quantised branch: torch.addmm, layer/qlinear.py:76) --------------
  * out[M,N] = bf16(acc_f32(A[M,K] bf16 row-major x B[K,N] bf16 column-major) + bias[N])          */

@@ -1317,7 +1317,9 @@ def test_deferred_gelu_quantiser_on_every_bf16_input(K, quant, epi):
     (2, 320, 64, 64, 320, 2, False, False),      # downsample
     (2, 640, 32, 32, 640, 1, False, True),
     (2, 960, 32, 32, 640, 1, False, False),      # up block: concatenated skip channels
-    (2, 1280, 16, 16, 1280, 1, True, False),     # nearest 2x upsampling + convolution
+    (2, 1280, 16, 16, 1280, 1, True, False),     # nearest 2x upsampling + convolution (40 tiles: split-K, 6 parts)
+    (2, 1280, 32, 32, 1280, 1, False, True),     # SDXL level 2 at 1024 x 1024: 40 tiles of 360 K steps -> split-K with the residual epilogue in the merge
+    (2, 640, 8, 8, 256, 1, False, True),         # one tile, 5 parts
     (1, 32, 33, 31, 328, 1, False, True),        # ragged everything: odd image, C_out not a multiple of the tile
     (3, 64, 17, 9, 40, 2, False, False),         # stride 2 on odd sizes, three images
     (1, 32, 5, 7, 8, 1, True, True),
