@@ -466,8 +466,12 @@ __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp)
               const i32x4 v = *reinterpret_cast<const i32x4*>(src + ((i * 2 + j) * 4 + q) * (512 * 4));
 #pragma unroll
               for (int c = 0; c < 4; ++c) {
-                if constexpr (DT == DT_INT8) acc[i][j][4 * q + c] += v[c];
-                else acc[i][j][4 * q + c] += __builtin_bit_cast(float, v[c]);      // fp32 partials, parts in order: deterministic
+                if constexpr (DT == DT_INT8) {
+                  acc[i][j][4 * q + c] += v[c];
+                } else {      // fp32 partials, parts in order: deterministic
+                  const f32x4 vf = __builtin_bit_cast(f32x4, v);
+                  acc[i][j][4 * q + c] += vf[c];
+                }
               }
             }
       }
@@ -558,12 +562,10 @@ __global__ void __launch_bounds__(128 * NWN, 2) gemm_kernel(const GemmGroup grp)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
+            const i32x16 ai = __builtin_bit_cast(i32x16, acc[i][j]);      // (the whole register block at once: int32 sums, or the bits of fp32 sums)
             i32x4 v;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              if constexpr (DT == DT_INT8) v[c] = acc[i][j][4 * q + c];
-              else v[c] = __builtin_bit_cast(int, acc[i][j][4 * q + c]);
-            }
+            for (int c = 0; c < 4; ++c) v[c] = ai[4 * q + c];
             *reinterpret_cast<i32x4*>(dst + ((i * 2 + j) * 4 + q) * (512 * 4)) = v;
           }
       return;

@@ -6,6 +6,7 @@ stages swapped, one at a time, for arithmetic that is the CPU reference's:
     gn_torch     torch's GroupNorm / SiLU instead of fdm_group_norm (FDM_GN_TORCH=1)
     conv_fp32    every convolution as fp32 F.conv2d on the bf16 operands, rounded to bf16 once (what a CPU bf16 convolution computes)
     both         gn_torch + conv_fp32
+    hip_nhwc     (round 6) the channels-last model: fdm_conv2d_3x3_nhwc_bf16 (fp32 accumulation) + fdm_group_norm_nhwc
 and prints mean|HIP - ref| / mean|control - ref| per step and per variant (and the step-0 stage taps of the variant that moves it).
     python3 tools/diag_sdxl_isolate.py > gpurun_out/<tag>_sdxl_isolate.txt
 """
@@ -43,7 +44,10 @@ def main():
         inp = sdxl_step_inputs(2, hw, hw, int(g["n_txt"]), seed=seed)
         sub = tuple(int(x) for x in c["tap_sub"])
         print(f"==== {tag}: mean|HIP - ref| / mean|control - ref| per step (limits of the test: measured default + 10 %)")
-        for variant in ("default", "gn_torch", "conv_fp32", "both"):
+        model_cl = create_model("sdxl", ckpt_path=SyntheticSDXLStateDict(seed=seed), dtype=BF16, quant_type=qt, kernel_backend="hip", channels_last=True).eval()
+        model_nchw = model
+        for variant in ("default", "gn_torch", "conv_fp32", "both", "hip_nhwc"):
+            model = model_cl if variant == "hip_nhwc" else model_nchw
             os.environ["FDM_GN_TORCH"] = "1" if variant in ("gn_torch", "both") else "0"
             F.conv2d = conv_fp32 if variant in ("conv_fp32", "both") else real_conv
             ratios, taps_line = [], []
@@ -68,7 +72,7 @@ def main():
             F.conv2d = real_conv
             print(f"  {variant:10s} " + "  ".join(f"{r:.3f}" for r in ratios) + "    step-0 stage taps |HIP - ref| / |control - ref|: " + ", ".join(taps_line))
         os.environ["FDM_GN_TORCH"] = "0"
-        del model, pipe
+        del model, model_cl, model_nchw, pipe
         torch.cuda.empty_cache()
 
 
