@@ -46,10 +46,11 @@ def main():
         print(f"==== {tag}: mean|HIP - ref| / mean|control - ref| per step (limits of the test: measured default + 10 %)")
         model_cl = create_model("sdxl", ckpt_path=SyntheticSDXLStateDict(seed=seed), dtype=BF16, quant_type=qt, kernel_backend="hip", channels_last=True).eval()
         model_nchw = model
-        for variant in ("default", "gn_torch", "conv_fp32", "both", "hip_nhwc"):
-            model = model_cl if variant == "hip_nhwc" else model_nchw
-            os.environ["FDM_GN_TORCH"] = "1" if variant in ("gn_torch", "both") else "0"
-            F.conv2d = conv_fp32 if variant in ("conv_fp32", "both") else real_conv
+        for variant in ("default", "gn_torch", "conv_fp32", "both", "hip_nhwc", "nhwc_gn_torch", "nhwc_conv_torch", "nhwc_conv_fp32"):
+            model = model_cl if "nhwc" in variant else model_nchw
+            os.environ["FDM_GN_TORCH"] = "1" if variant in ("gn_torch", "both", "nhwc_gn_torch") else "0"
+            os.environ["FDM_CONV_TORCH"] = "1" if variant in ("nhwc_conv_torch", "nhwc_conv_fp32") else "0"
+            F.conv2d = conv_fp32 if variant in ("conv_fp32", "both", "nhwc_conv_fp32") else real_conv
             ratios, taps_line = [], []
             with torch.no_grad():
                 for i in range(steps):
@@ -72,6 +73,7 @@ def main():
             F.conv2d = real_conv
             print(f"  {variant:10s} " + "  ".join(f"{r:.3f}" for r in ratios) + "    step-0 stage taps |HIP - ref| / |control - ref|: " + ", ".join(taps_line))
         os.environ["FDM_GN_TORCH"] = "0"
+        os.environ["FDM_CONV_TORCH"] = "0"
         del model, model_cl, model_nchw, pipe
         torch.cuda.empty_cache()
 
