@@ -34,7 +34,8 @@ IMAGE_STEPS = 25
 HIP_KERNEL = {"attn_fwd_bf16": "fdm::attn_fwd64_kernel<128, false>", "attn_sparse_bf16": "fdm::attn_fwd64_kernel<128, true>",
               "attn_fwd_bf16_hd64": "fdm::attn_fwd_kernel<64, 512, 64>",
               "attn_fwd_pvfp8": "fdm::attn_fwd64_pv8_kernel<128, false>", "attn_fwd_fp8": "fdm::attn_fwd64_qk8_kernel<128, false>",
-              "attn_sparse_pvfp8": "fdm::attn_fwd64_pv8_kernel<128, true>", "attn_sparse_fp8": "fdm::attn_fwd64_qk8_kernel<128, true>"}
+              "attn_sparse_pvfp8": "fdm::attn_fwd64_pv8_kernel<128, true>", "attn_sparse_fp8": "fdm::attn_fwd64_qk8_kernel<128, true>",
+              "conv3x3_bf16": "fdm::gemm_kernel<2, *, *, true> (3 x 3 convolution as an implicit GEMM)"}
 
 
 def span_kernel(span: str, by_kernel=None) -> str:

@@ -1072,10 +1072,52 @@ __global__ void __launch_bounds__(GNH_MAXT) group_norm_nhwc_stats_kernel(const b
   }
 }
 
+// (mean, rstd) per (image, group) from the slices' partial sums: 8 threads per group take every 8th slice with loads issued in batches (a
+// serial walk over the ~340 slices of a 128 x 128 image inside EVERY apply block was 70 of that kernel's 97 us), then the 8 sub-sums are added in
+// a fixed order -- deterministic, in double.
+__global__ void __launch_bounds__(512) group_norm_nhwc_finalize_kernel(float* __restrict__ stat, const float* __restrict__ part, int hw, int cpg, int groups, int P,
+                                                                      float eps) {
+  __shared__ double sh[2][64][8];
+  const int b = blockIdx.x, g = (int)threadIdx.x >> 3, k = (int)threadIdx.x & 7;
+  double ts = 0.0, tq = 0.0;
+  if (g < groups) {
+    for (int i0 = k; i0 < P; i0 += 64) {      // 8 slices per batch of loads
+      float a[8], c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 8 * u;
+        const float* pp = part + (((int64_t)b * P + (i < P ? i : 0)) * groups + g) * 2;
+        a[u] = i < P ? pp[0] : 0.f;
+        c[u] = i < P ? pp[1] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        ts += (double)a[u];
+        tq += (double)c[u];
+      }
+    }
+    sh[0][g][k] = ts;
+    sh[1][g][k] = tq;
+  }
+  __syncthreads();
+  if (g < groups && k == 0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int u = 0; u < 8; ++u) {
+      s0 += sh[0][g][u];
+      s1 += sh[1][g][u];
+    }
+    const double n = (double)hw * cpg, mean = s0 / n;
+    double var = s1 / n - mean * mean;      // biased, as F.group_norm
+    if (var < 0.0) var = 0.0;
+    stat[((int64_t)b * groups + g) * 2] = (float)mean;
+    stat[((int64_t)b * groups + g) * 2 + 1] = 1.0f / sqrtf((float)var + eps);
+  }
+}
+
 template <bool SILU>
 __global__ void __launch_bounds__(GNH_MAXT) group_norm_nhwc_apply_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ x, const bf16_t* __restrict__ addend,
                                                                         const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
-                                                                        const float* __restrict__ part, int hw, int channels, int groups, int P, int rpi, float eps) {
+                                                                        const float* __restrict__ stat, int hw, int channels, int groups, int P, int rpi) {
   __shared__ float smean[64], srstd[64];
   const int nv = channels >> 3, cpg = channels / groups;
   const int slice = blockIdx.x, b = blockIdx.y;
@@ -1090,19 +1132,9 @@ __global__ void __launch_bounds__(GNH_MAXT) group_norm_nhwc_apply_kernel(bf16_t*
       if (r < r1) raw[k] = *reinterpret_cast<const i32x4*>(src0 + (int64_t)r * channels);
     }
   }
-  if ((int)threadIdx.x < groups) {
-    const int g = threadIdx.x;
-    double ts = 0.0, tq = 0.0;
-    for (int i = 0; i < P; ++i) {      // fixed order over the slices
-      const float* pp = part + (((int64_t)b * P + i) * groups + g) * 2;
-      ts += (double)pp[0];
-      tq += (double)pp[1];
-    }
-    const double n = (double)hw * cpg, mean = ts / n;
-    double var = tq / n - mean * mean;      // biased, as F.group_norm
-    if (var < 0.0) var = 0.0;
-    smean[g] = (float)mean;
-    srstd[g] = 1.0f / sqrtf((float)var + eps);
+  if ((int)threadIdx.x < groups) {      // (mean, rstd) of this image's groups: group_norm_nhwc_finalize_kernel
+    smean[threadIdx.x] = stat[((int64_t)b * groups + threadIdx.x) * 2];
+    srstd[threadIdx.x] = stat[((int64_t)b * groups + threadIdx.x) * 2 + 1];
   }
   __syncthreads();
   float a[8], bb[8];
@@ -1493,7 +1525,7 @@ static int gnh_rpi(int64_t channels) {
 
 int64_t fdm_group_norm_nhwc_workspace_bytes(int64_t batch, int64_t channels, int64_t hw, int groups) {
   if (batch <= 0 || channels <= 0 || hw <= 0 || groups <= 0 || channels % groups) return 0;
-  return batch * (int64_t)gnh_slices(batch, hw, gnh_rpi(channels)) * groups * 8;
+  return batch * (int64_t)gnh_slices(batch, hw, gnh_rpi(channels)) * groups * 8 + batch * (int64_t)groups * 8;      // slice partials + (mean, rstd)
 }
 
 int fdm_group_norm_nhwc(void* out, const void* x, const void* gamma, const void* beta, const void* addend, int64_t batch, int64_t channels, int64_t hw,
@@ -1507,7 +1539,8 @@ int fdm_group_norm_nhwc(void* out, const void* x, const void* gamma, const void*
   if (batch == 0) return FDM_OK;
   const int nv = (int)(channels >> 3), rpi = gnh_rpi(channels), threads = nv * rpi;
   const int P = gnh_slices(batch, hw, rpi);
-  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15) || workspace_bytes < batch * (int64_t)P * groups * 8) return FDM_ERR_INVALID;
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15) || workspace_bytes < batch * (int64_t)P * groups * 8 + batch * (int64_t)groups * 8)
+    return FDM_ERR_INVALID;
   if (threads < groups) return FDM_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)P, (unsigned)batch);
   hipStream_t s = to_stream(stream);
@@ -1515,10 +1548,13 @@ int fdm_group_norm_nhwc(void* out, const void* x, const void* gamma, const void*
   const size_t shm = (size_t)2 * rpi * channels * sizeof(float);
   group_norm_nhwc_stats_kernel<<<grid, threads, shm, s>>>((const bf16_t*)x, (const bf16_t*)addend, part, (int)hw, (int)channels, groups, P, rpi);
   FDM_CHECK_LAUNCH();
+  float* stat = part + batch * (int64_t)P * groups * 2;
+  group_norm_nhwc_finalize_kernel<<<(unsigned)batch, 512, 0, s>>>(stat, part, (int)hw, cpg, groups, P, eps);
+  FDM_CHECK_LAUNCH();
   if (act) group_norm_nhwc_apply_kernel<true><<<grid, threads, 0, s>>>((bf16_t*)out, (const bf16_t*)x, (const bf16_t*)addend, (const bf16_t*)gamma,
-                                                                       (const bf16_t*)beta, part, (int)hw, (int)channels, groups, P, rpi, eps);
+                                                                       (const bf16_t*)beta, stat, (int)hw, (int)channels, groups, P, rpi);
   else group_norm_nhwc_apply_kernel<false><<<grid, threads, 0, s>>>((bf16_t*)out, (const bf16_t*)x, (const bf16_t*)addend, (const bf16_t*)gamma,
-                                                                    (const bf16_t*)beta, part, (int)hw, (int)channels, groups, P, rpi, eps);
+                                                                    (const bf16_t*)beta, stat, (int)hw, (int)channels, groups, P, rpi);
   FDM_CHECK_LAUNCH();
   return FDM_OK;
 }

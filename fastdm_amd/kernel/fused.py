@@ -149,40 +149,68 @@ def group_norm(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Te
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, padding: int = 0, upsample: bool = False,
            res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """F.conv2d of the UNet's call sites (reference layer/resnetblock.py:29-47, layer/unetblock.py:203-240, cuDNN there) [+ the nearest 2x
-    upsampling in front of it] [+ the residual add behind it].  3 x 3 / padding 1 convolutions of channels-last bf16 tensors with
-    C_in % 32 == 0 and C_out % 8 == 0 run as an implicit GEMM on the HIP tile kernel (fdm_conv2d_3x3_nhwc_bf16: fp32 accumulation over all
-    9 C_in products, one rounding); everything else -- NCHW activations, conv_in's 4 input and conv_out's 4 output channels, 1 x 1 shortcuts,
-    FDM_CONV_TORCH=1 (A/B) -- takes the library call the reference makes.  `weight` is the [O, I, 3, 3] tensor in channels_last memory
-    format: its bytes ARE the [O, 3, 3, I] layout the kernel reads."""
+    """F.conv2d of the UNet's call sites (reference layer/resnetblock.py:29-47, layer/unetblock.py:203-240, model/sdxl.py:417,470; cuDNN there)
+    [+ the nearest 2x upsampling in front of it] [+ the residual add behind it].  On channels-last bf16 tensors:
+      * 3 x 3 / padding 1 (stride 1 or 2): the implicit GEMM on the HIP tile kernel (fdm_conv2d_3x3_nhwc_bf16: fp32 accumulation over all
+        9 C_in products, bias added in fp32, ONE rounding).  C_in < 32 (conv_in's 4 latent channels) is zero-padded to 32, C_out that is not a
+        multiple of 8 (conv_out's 4) to 8 -- weights once (cached), activations per call (tiny tensors);
+      * 1 x 1 / stride 1 (the ResNet shortcuts): fdm_gemm_bf16 on the [B*H*W, C] pixel matrix.
+    Everything else -- NCHW activations, FDM_CONV_TORCH=1 (A/B) -- takes the library call the reference makes.  `weight` is the [O, I, kh, kw]
+    tensor in channels_last memory format: its bytes ARE the [O, kh, kw, I] layout the kernels read."""
     import torch.nn.functional as F
     B, C, H, W = x.shape
     O = weight.shape[0]
-    hip = (x.dtype == BF16 and weight.dtype == BF16 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and padding == 1 and stride in (1, 2)
-           and not (upsample and stride != 1) and C % 32 == 0 and O % 8 == 0 and weight.shape[1] == C
-           and x.is_contiguous(memory_format=torch.channels_last) and weight.is_contiguous(memory_format=torch.channels_last)
-           and (bias is None or (bias.dtype == BF16 and bias.is_contiguous()))
-           and (res is None or (res.dtype == BF16 and res.is_contiguous(memory_format=torch.channels_last)))
-           and os.environ.get("FDM_CONV_TORCH", "0") != "1")
-    if not hip:
+    cl = torch.channels_last
+    common = (x.dtype == BF16 and weight.dtype == BF16 and weight.dim() == 4 and weight.shape[1] == C and x.is_contiguous(memory_format=cl)
+              and weight.is_contiguous(memory_format=cl) and (bias is None or (bias.dtype == BF16 and bias.is_contiguous()))
+              and (res is None or (res.dtype == BF16 and res.is_contiguous(memory_format=cl))) and os.environ.get("FDM_CONV_TORCH", "0") != "1")
+    k = tuple(weight.shape[2:])
+    if common and k == (1, 1) and stride == 1 and padding == 0 and not upsample and res is None and C % 8 == 0 and O % 8 == 0:
+        out = torch.empty((B, O, H, W), device=x.device, dtype=BF16, memory_format=cl)
+        M = B * H * W
+        with span("gemm_bf16", 2.0 * M * O * C):
+            N.check(N.lib().fdm_gemm_bf16(N.ptr(out), N.ptr(x), N.ptr(weight), N.ptr(bias), M, O, C, C, C, O, N.EPI_NONE, None, 0, None, 0, N.stream()),
+                    "conv2d_1x1_nhwc")
+        return out
+    if not (common and k == (3, 3) and padding == 1 and stride in (1, 2) and not (upsample and stride != 1)):
         if upsample:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         y = F.conv2d(x, weight, bias, stride, padding)
         return y if res is None else res + y
+    Cp, Op = (C + 31) // 32 * 32, (O + 7) // 8 * 8
+    if Cp != C or Op != O:
+        key = (weight.data_ptr(), None if bias is None else bias.data_ptr(), Cp, Op)
+        pad = _conv_pad.get(key)
+        if pad is None:
+            wp = torch.zeros((Op, Cp, 3, 3), device=x.device, dtype=BF16).contiguous(memory_format=cl)
+            wp[:O, :C] = weight
+            bp = None
+            if bias is not None:
+                bp = torch.zeros(Op, device=x.device, dtype=BF16)
+                bp[:O] = bias
+            pad = _conv_pad[key] = (wp, bp, weight, bias)      # (the originals are kept alive: the key holds their addresses)
+        weight, bias = pad[0], pad[1]
+        if Cp != C:
+            xp = torch.zeros((B, Cp, H, W), device=x.device, dtype=BF16).contiguous(memory_format=cl)
+            xp[:, :C] = x
+            x = xp
+        assert res is None or Op == O
     Ho, Wo = (2 * H, 2 * W) if upsample else ((H - 1) // stride + 1, (W - 1) // stride + 1)
-    out = torch.empty((B, O, Ho, Wo), device=x.device, dtype=BF16, memory_format=torch.channels_last)
+    out = torch.empty((B, Op, Ho, Wo), device=x.device, dtype=BF16, memory_format=cl)
     ones = None
     if res is not None:
         assert res.shape == out.shape
-        ones = _conv_ones.get((x.device, O))
+        ones = _conv_ones.get((x.device, Op))
         if ones is None:
-            ones = _conv_ones[(x.device, O)] = torch.ones(O, device=x.device, dtype=BF16)
+            ones = _conv_ones[(x.device, Op)] = torch.ones(Op, device=x.device, dtype=BF16)
     ws = N.gemm_int8_workspace(x.device)      # the per-(device, stream) split-K scratch of the tile GEMMs (pinned once a capture has seen it)
-    N.check(N.lib().fdm_conv2d_3x3_nhwc_bf16(N.ptr(out), N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(res), N.ptr(ones), B, H, W, C, O, stride,
-                                             1 if upsample else 0, N.ptr(ws), ws.numel(), N.stream()), "conv2d_3x3_nhwc")
-    return out
+    with span("conv3x3_bf16", 2.0 * B * Ho * Wo * Op * 9 * Cp):
+        N.check(N.lib().fdm_conv2d_3x3_nhwc_bf16(N.ptr(out), N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(res), N.ptr(ones), B, H, W, Cp, Op, stride,
+                                                 1 if upsample else 0, N.ptr(ws), ws.numel(), N.stream()), "conv2d_3x3_nhwc")
+    return out if Op == O else out[:, :O]
 
 
+_conv_pad = {}
 _conv_ones = {}
 
 

@@ -34,6 +34,6 @@ class ResnetBlock2D:
     def forward(self, input_tensor, temb):
         h = self._gn_silu_conv3(input_tensor, self.norm1_gamma, self.norm1_beta, self.conv1_weight, self.conv1_bias)
         shift = self.time_emb_proj.forward(F.silu(temb))                   # [B, C_out]: per-channel offset from the time embedding
-        skip = input_tensor if not self.conv_shortcut else F.conv2d(input_tensor, self.convshortcut_weight, self.convshortcut_bias, 1)
+        skip = input_tensor if not self.conv_shortcut else fused.conv2d(input_tensor, self.convshortcut_weight, self.convshortcut_bias, 1)
         # skip + h: the add rides in the convolution's epilogue (channels-last + HIP convolution), same roundings as the separate add
         return self._gn_silu_conv3(h, self.norm2_gamma, self.norm2_beta, self.conv2_weight, self.conv2_bias, addend=shift.contiguous(), res=skip)

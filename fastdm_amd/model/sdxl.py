@@ -141,7 +141,7 @@ class SDXLUNetModelCore(BaseModelCore):
         if self.channels_last:
             sample = sample.contiguous(memory_format=torch.channels_last)
         enc = EncoderStates(encoder_hidden_states)        # quantised once for all 70 cross-attentions
-        sample = F.conv2d(sample, self.conv_in_weight, self.conv_in_bias, 1, 1)
+        sample = fused.conv2d(sample, self.conv_in_weight, self.conv_in_bias, 1, 1)
         s0 = sample
         sample, (s1, s2, s3) = self.down_blocks[0].forward(sample, temb=emb)
         sample, (s4, s5, s6) = self.down_blocks[1].forward(sample, temb=emb, encoder_hidden_states=enc)
@@ -156,5 +156,5 @@ class SDXLUNetModelCore(BaseModelCore):
         sample = self.up_blocks[1].forward(hidden_states=sample, temb=emb, res_hidden_states_tuple=[s3, s4, s5], encoder_hidden_states=enc)
         sample = self.up_blocks[2].forward(hidden_states=sample, temb=emb, res_hidden_states_tuple=[s0, s1, s2])
         sample = fused.group_norm(sample, 32, self.conv_norm_out_gemma, self.conv_norm_out_beta, 1e-05, silu=True)
-        sample = F.conv2d(sample, self.conv_out_weight, self.conv_out_bias, 1, 1)
+        sample = fused.conv2d(sample, self.conv_out_weight, self.conv_out_bias, 1, 1)
         return [sample.contiguous()]

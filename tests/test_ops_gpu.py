@@ -1374,3 +1374,20 @@ def test_group_norm_nhwc_matches_the_nchw_kernel_and_torch(K, B, C, H, W, silu, 
     if (H * W) % 8 == 0:
         nchw = fused.group_norm(x.cuda(), 32, gamma.cuda(), beta.cuda(), 1e-5, addend=None if addend is None else addend.cuda(), silu=silu)
         ulp_close(got, nchw, 0.01, f"group_norm nhwc vs nchw {B}x{C}x{H}x{W}", ulps=2 if silu else 1)
+
+
+@pytest.mark.parametrize("B,C,H,W,O,k", [(2, 4, 64, 64, 320, 3), (2, 320, 64, 64, 4, 3), (2, 320, 32, 32, 640, 1), (1, 960, 9, 7, 640, 1)])
+def test_conv2d_small_channel_and_pointwise_forms(K, B, C, H, W, O, k):
+    """fused.conv2d's other channels-last forms: conv_in (4 input channels zero-padded to 32), conv_out (4 output channels padded to 8 and sliced)
+    and the ResNet blocks' 1 x 1 shortcuts (fdm_gemm_bf16 on the pixel matrix) against the fp32 convolution of the same bf16 operands
+    (reference call sites: model/sdxl.py:417,470, layer/resnetblock.py:44): <= 1 bf16 ulp."""
+    import torch.nn.functional as F
+    from fastdm_amd.kernel import fused
+    g = gen(C * 3 + O + k)
+    x = rbf(g, B, C, H, W).contiguous(memory_format=torch.channels_last)
+    w = rbf(g, O, C, k, k, scale=(k * k * C) ** -0.5).contiguous(memory_format=torch.channels_last)
+    bias = rbf(g, O, scale=0.2)
+    want = F.conv2d(x.float(), w.float(), bias.float(), 1, k // 2).to(BF16)
+    got = fused.conv2d(x.cuda(), w.cuda(), bias.cuda(), 1, k // 2)
+    assert got.shape == want.shape
+    ulp_close(got, want, 0.03, f"conv {k}x{k} {C} -> {O}")
