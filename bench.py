@@ -370,7 +370,8 @@ def main():
                     "whenever it applies: no --cfg-pair, no step cache; bit-identical to two forwards)")
     ap.add_argument("--no-batch-cfg", action="store_true", help="qwen: two batch-1 forwards per step")
     ap.add_argument("--graph", action="store_true", help="sdxl: replay the UNet forward from a HIP graph (the step is launch-bound: ~2000 small kernels)")
-    ap.add_argument("--nhwc", action="store_true", help="sdxl: keep convolution activations channels-last instead of NCHW")
+    ap.add_argument("--nhwc", action="store_true", help="sdxl: channels-last activations + HIP convolutions (the default since round 6; kept for old command lines)")
+    ap.add_argument("--nchw", action="store_true", help="sdxl: NCHW activations, MIOpen convolutions (the round-5 path)")
     ap.add_argument("--cfg-pair", action="store_true", help="qwen / wan / sd35 / sdxl with --gpus 2k: ranks (2i, 2i+1) share image i -- one runs the "
                     "conditional, the other the unconditional forward, one all-gather of the noise predictions per step (strong scaling of a step)")
     ap.add_argument("--images-per-rank", type=int, default=1, help="images each rank (or CFG pair) denoises, one after the other inside every step, as the "
@@ -459,7 +460,7 @@ def main():
     elif args.model == "sdxl":
         from fastdm_amd.synthetic import SyntheticSDXLStateDict, sdxl_step_inputs
         model = create_model("sdxl", ckpt_path=SyntheticSDXLStateDict(seed=0), dtype=torch.bfloat16, quant_type=quant, kernel_backend="hip",
-                             channels_last=args.nhwc).eval()
+                             channels_last=not args.nchw).eval()
         pipe = None
     else:
         from fastdm_amd.pipeline import SyntheticWanPipeline
@@ -643,7 +644,7 @@ def main():
     elif args.model == "sdxl":
         workload = (f"SDXL-base-1.0 UNet {args.quant} {args.height}x{args.width} (latent {args.height // 8}x{args.width // 8}; {n_img} and {n_img // 4} "
                     f"tokens at the two attention levels, {args.max_seq_len} prompt tokens), 30-step schedule, CFG as one batch-2 forward per step{IMG_NOTE}, "
-                    f"70 transformer layers + 52 MIOpen convolutions")
+                    f"70 transformer layers + 52 convolutions ({'MIOpen, NCHW' if args.nchw else 'HIP implicit GEMM, channels-last'})")
     elif args.model == "wan":
         hs = inp["hidden_states"].shape
         nl = len(model.core_model.blocks)

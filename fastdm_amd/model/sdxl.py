@@ -3,8 +3,12 @@
 Same constructor surface, diffusers key names and forward signature as the reference.  The reference hard-codes
 SDXL-base's widths inside the class (sdxl.py:53-113); here they are constructor arguments that default to SDXL-base, so
 the narrow configuration of the parity fixtures goes through the same code.  Transformer blocks run on the fused HIP
-kernels (layer/unetblock.py); convolutions, group-norm and nearest upsampling are MIOpen / PyTorch-ROCm library calls as
-they are cuDNN calls in the reference.  `channels_last=True` keeps the convolution activations in NHWC (the token <-> image
+kernels (layer/unetblock.py).  Round 6: with `channels_last=True` (the DEFAULT now) every convolution is a HIP kernel too -- 3 x 3 as an
+implicit GEMM with fp32 accumulation (kernel/fused.py:conv2d -> fdm_conv2d_3x3_nhwc_bf16; stride-2 downsampling, the nearest upsampling folded
+into the addressing, the ResNet skip added in the epilogue), 1 x 1 shortcuts as GEMMs on the pixel matrix -- and the GroupNorm / SiLU chains use
+the NHWC form of the fused kernel: 30.3 -> 27.3 ms per 1024 x 1024 graph step, and BASELINE configs[0] moves from 1.14-1.47 x the
+two-implementation envelope ONTO it (1.02 1.01 1.03 1.01; MIOpen's bf16 convolutions were the whole excess: profiles/r06g / r06q_sdxl_isolate.txt).
+`channels_last=False` keeps NCHW activations and the library calls the reference makes (MIOpen as cuDNN there).  `channels_last=True` keeps the convolution activations in NHWC (the token <-> image
 permutes become views); measured on MI355X at 1024x1024 the NCHW MIOpen kernels win by 1.5 ms of a 42 ms step, so NCHW is
 the default.  (MIOpen's NCHW solvers answer the first call of a shape differently from later calls -- rounding-level, amplified to
 ~0.06 by the UNet; channels-last was bit-stable run to run in the same experiment, tools/diag_sdxl.py.)
@@ -32,7 +36,7 @@ class SDXLUNetModelCore(BaseModelCore):
                  ip_adapter_scale=0.6, diffu_ipadapter_encoder_hid_proj=None, data_type=BF16, quant_dtype: torch.dtype = torch.float8_e4m3fn,
                  block_out_channels: Tuple[int, int, int] = (320, 640, 1280), transformer_layers: Tuple[int, int] = (2, 10),
                  mid_layers: int = 10, time_proj_dim: int = 320, time_embed_dim: int = 1280, text_embed_dim: int = 1280,
-                 channels_last: bool = False):
+                 channels_last: bool = True):
         super().__init__(type="Unet")
         if is_ip_adapter:
             raise NotImplementedError("the IP-adapter branch of the SDXL UNet is not built (DESIGN.md §8)")

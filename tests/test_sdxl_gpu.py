@@ -134,17 +134,18 @@ def test_baseline_config1_sdxl_512x512_four_steps_against_reference(tag, qt):
     print("\n".join(lines))
 
 # measured (gpurun_out/sdxl_c1_control_<tag>.txt) + 10 %: mean|HIP - ref| / mean|control - ref| per step, where control = the reference's own
-# classes with an fp32-softmax attention (and, fp8, a float64 W8A8 accumulate): the distance between two legitimate implementations
-# measured (profiles/r05_sdxl_c1_control_*.txt): bf16 1.152 1.298 1.447 1.483, fp8 1.072 1.061 1.115 1.180.  What is left above 1.0 is located by
-# the stage taps: down0 -- resnets only: MIOpen convolution / group norm against the CPU's, a difference the control does not contain
-# (its convolutions ARE the reference's) -- already carries mean 0.0073 on mean|ref| 1.01 while control = ref there; from down1 on the
-# stage ratios fall from 1.66 / 1.17 to 1.2 / 1.01-1.05 (bf16 / fp8): no transformer stage sticks out.  In the later, less noisy steps that
-# constant convolution floor weighs more against a shrinking |control - ref| (bf16 ratio 1.15 -> 1.48 while |HIP - ref| falls 0.0083 -> 0.0034).
-SDXL_C1_RATIO_LIMIT = {"bf16": (1.27, 1.43, 1.59, 1.63), "fp8": (1.18, 1.17, 1.23, 1.30)}
+# classes with an fp32-softmax attention (and, fp8, a float64 W8A8 accumulate): the distance between two legitimate implementations.
+# Round 6 (the default model is channels-last with HIP convolutions): bf16 1.023 1.007 1.025 1.010, fp8 1.075 1.011 1.003 1.022 -- ON the envelope.
+# Round 5's NCHW / MIOpen path measured 1.15 1.30 1.45 1.48 (bf16); tools/diag_sdxl_isolate.py showed that fp32 convolutions alone take it to
+# 1.02 1.01 1.03 1.01: MIOpen's bf16 convolutions (every one of them, conv_in and the 1 x 1 shortcuts included) were the whole excess
+# (profiles/r06g_sdxl_isolate.txt, r06q_sdxl_isolate.txt).  The NCHW model keeps the round-5 limits (SDXL_C1_RATIO_LIMIT_NCHW).
+SDXL_C1_RATIO_LIMIT = {"bf16": (1.13, 1.11, 1.13, 1.12), "fp8": (1.19, 1.12, 1.11, 1.13)}
+SDXL_C1_RATIO_LIMIT_NCHW = {"bf16": (1.27, 1.43, 1.59, 1.63), "fp8": (1.18, 1.17, 1.23, 1.30)}
 
 
+@pytest.mark.parametrize("channels_last", [True, False])
 @pytest.mark.parametrize("tag,qt", [("bf16", None), ("fp8", FP8)])
-def test_baseline_config1_sdxl_against_the_two_implementation_control(tag, qt):
+def test_baseline_config1_sdxl_against_the_two_implementation_control(tag, qt, channels_last):
     """BASELINE.json configs[0] with a yardstick.  `python -m oracle.make_golden c1_control` ran the reference's core
     once more per step from the reference's own latents with an fp32-softmax attention (fp8: plus a float64 accumulate) -- `ceps_*`.  The HIP
     path, fed the same latents, must stay within SDXL_C1_RATIO_LIMIT x mean|control - ref| of the reference at every step, and the seven UNet
@@ -159,7 +160,7 @@ def test_baseline_config1_sdxl_against_the_two_implementation_control(tag, qt):
     g, c = load("sdxl_c1_512x512_4steps.npz"), load("sdxl_c1_control.npz")
     seed, steps, hw = int(g["seed"]), int(g["steps"]), int(g["height"])
     assert int(c["seed"]) == seed and int(c["steps"]) == steps
-    model = create_model("sdxl", ckpt_path=SyntheticSDXLStateDict(seed=seed), dtype=BF16, quant_type=qt, kernel_backend="hip").eval()
+    model = create_model("sdxl", ckpt_path=SyntheticSDXLStateDict(seed=seed), dtype=BF16, quant_type=qt, kernel_backend="hip", channels_last=channels_last).eval()
     pipe = SyntheticSDXLPipeline(model, seed=seed)
     ts, sig = pipe.schedule(steps)
     inp = sdxl_step_inputs(2, hw, hw, int(g["n_txt"]), seed=seed)
@@ -183,11 +184,11 @@ def test_baseline_config1_sdxl_against_the_two_implementation_control(tag, qt):
                 th, tc = (taps[name].float() - r).abs().mean().item(), (c[f"tap_{tag}_ctl_{name}"].float() - r).abs().mean().item()
                 lines.append(f"    step 0 stage {name:5s}: mean|HIP - ref| {th:.5f}  mean|control - ref| {tc:.5f}  ratio {(f'{th / tc:.3f}' if tc > 0 else 'n/a (this stage has no attention / W8A8 linear: control = ref)')}  (mean|ref| {r.abs().mean().item():.3f})")
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/sdxl_c1_control_{tag}.txt", "w") as f:
+    with open(f"gpurun_out/sdxl_c1_control_{tag}{'' if channels_last else '_nchw'}.txt", "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
     for i, r in enumerate(ratios):
-        assert r <= SDXL_C1_RATIO_LIMIT[tag][i], lines
+        assert r <= (SDXL_C1_RATIO_LIMIT if channels_last else SDXL_C1_RATIO_LIMIT_NCHW)[tag][i], lines
 
 
 def test_sdxl_blocks_keep_reference_signatures_and_errors():

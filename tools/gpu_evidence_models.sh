@@ -8,6 +8,7 @@ python3 bench.py --model qwen --batch-cfg > "$out/${tag}_qwen_batchcfg_bench.jso
 python3 bench.py --quant bf16 --height 1024 --width 1024 > "$out/${tag}_flux_bf16_1024_bench.json" 2> "$out/${tag}_flux_bf16_1024.err"
 python3 bench.py --quant int8 > "$out/${tag}_flux_int8_bench.json" 2> "$out/${tag}_flux_int8.err"
 python3 bench.py --model sd35 > "$out/${tag}_sd35_bench.json" 2> "$out/${tag}_sd35.err"
+python3 bench.py --model sdxl --nchw --graph > "$out/${tag}_sdxl_nchw_graph_bench.json" 2> "$out/${tag}_sdxl_nchw.err"
 python3 bench.py --model sdxl > "$out/${tag}_sdxl_bench.json" 2> "$out/${tag}_sdxl.err"
 python3 bench.py --model sdxl --graph > "$out/${tag}_sdxl_graph_bench.json" 2> "$out/${tag}_sdxl_graph.err"
 # BASELINE.json configs[0]: SDXL-base UNet 512 x 512, 4 steps (the line carries the CPU baseline of the same layers)
