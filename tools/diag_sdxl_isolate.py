@@ -2,7 +2,7 @@
 """WHY does BASELINE configs[0] (SDXL-base 512 x 512, 4 steps) sit 1.15 -> 1.48 x the two-implementation envelope in bf16?
 Runs the control comparison of tests/test_sdxl_gpu.py::test_baseline_config1_sdxl_against_the_two_implementation_control with the suspected
 stages swapped, one at a time, for arithmetic that is the CPU reference's:
-    default      the shipped path (fdm_group_norm, MIOpen bf16 convolutions)
+    default      the NCHW model (round 5's shipped path: fdm_group_norm, MIOpen bf16 convolutions)
     gn_torch     torch's GroupNorm / SiLU instead of fdm_group_norm (FDM_GN_TORCH=1)
     conv_fp32    every convolution as fp32 F.conv2d on the bf16 operands, rounded to bf16 once (what a CPU bf16 convolution computes)
     both         gn_torch + conv_fp32
@@ -38,7 +38,7 @@ def main():
         return real_conv(x.float(), w.float(), None if b is None else b.float(), stride, padding, *a, **k).to(BF16)
 
     for tag, qt in (("bf16", None), ("fp8", torch.float8_e4m3fn)):
-        model = create_model("sdxl", ckpt_path=SyntheticSDXLStateDict(seed=seed), dtype=BF16, quant_type=qt, kernel_backend="hip").eval()
+        model = create_model("sdxl", ckpt_path=SyntheticSDXLStateDict(seed=seed), dtype=BF16, quant_type=qt, kernel_backend="hip", channels_last=False).eval()
         pipe = SyntheticSDXLPipeline(model, seed=seed)
         ts, sig = pipe.schedule(steps)
         inp = sdxl_step_inputs(2, hw, hw, int(g["n_txt"]), seed=seed)

@@ -47,5 +47,5 @@ for ci, co, hw, st, up, cnt in SHAPES:
     tot[0] += a * cnt
     tot[1] += m1 * cnt
     tot[2] += m2 * cnt
-    print(f"{ci:5d} {co:5d} {hw:4d} {st:2d} {int(up):3d} {cnt:2d} {gf:7.1f} | {a:8.1f} {gf / a / 1e-3 / 2.5e6:6.3f} | {m1:11.1f} | {m2:11.1f}")
+    print(f"{ci:5d} {co:5d} {hw:4d} {st:2d} {int(up):3d} {cnt:2d} {gf:7.1f} | {a:8.1f} {gf / a * 0.4:6.3f} | {m1:11.1f} | {m2:11.1f}")
 print(f"per forward (weighted): HIP {tot[0] / 1e3:.2f} ms, MIOpen channels-last {tot[1] / 1e3:.2f} ms, MIOpen NCHW {tot[2] / 1e3:.2f} ms")
