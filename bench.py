@@ -51,8 +51,10 @@ def span_kernel(span: str, by_kernel=None) -> str:
     res = "true" if span.endswith("_res") else "false"
     if top == "fdm::gemm_p4_kernel":
         return "fdm::gemm_p4_kernel<0>"            # plain epilogue carries most p4 launches (<1> = tanh-GELU, <2> = erf-GELU)
-    if top in ("fdm::gemm_w4_kernel", "fdm::gemm_kernel"):
+    if top == "fdm::gemm_kernel":
         return f"{top}<{dt}, {res}>"
+    if top.startswith("fdm::gemm_w4_kernel"):      # <data type, gate + residual, 16-row blocks per wave: 8 = 256-row tiles, 7 = 224-row tiles>
+        return f"fdm::gemm_w4_kernel<{dt}, {res}, {7 if '224' in top else 8}>"
     return top
 
 

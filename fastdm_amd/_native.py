@@ -38,6 +38,7 @@ SIGNATURES = {
     "fdm_gemm_int8_workspace_bytes": (I64, []),
     "fdm_gemm_last_kernel": (I32, []),
     "fdm_set_gemm_dispatch": (I32, [I32, I32, I32]),
+    "fdm_set_gemm_tile_rows": (I32, [I32]),
     "fdm_gemm_w8a8_int8": (I32, [P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_gemm_bf16": (I32, [P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_conv2d_3x3_nhwc_bf16": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, I32, P, I64, P]),
@@ -71,7 +72,7 @@ SIGNATURES = {
     "fdm_debug_cvt_fp8": (I32, [P, P, I64, I32, P]),
 }
 
-ABI_VERSION = 19         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
+ABI_VERSION = 20         # FDM_ABI_VERSION of include/fastdm_amd.h these SIGNATURES were written against
 EPI_NONE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_GATE_RESIDUAL, EPI_GATE_RESIDUAL_F32 = 0, 1, 2, 3, 4
 
 
@@ -250,6 +251,11 @@ def _apply_env_dispatch(handle):
         rc = handle.fdm_set_gemm_dispatch(k, p4, half)
         if rc != 0:
             raise ValueError(f"FDM_GEMM_KERNEL / FDM_GEMM_P4 / FDM_GEMM_HALF_TILES = {k}, {p4}, {half}: rejected by fdm_set_gemm_dispatch ({rc})")
+    rows = os.environ.get("FDM_GEMM_TILE_ROWS", "")       # 256 | 224: tile height of the 4-wave kernel (A/B); unset = 256
+    if rows != "":
+        rc = handle.fdm_set_gemm_tile_rows(int(rows))
+        if rc != 0:
+            raise ValueError(f"FDM_GEMM_TILE_ROWS = {rows}: 256 | 224")
 
 
 def provenance() -> dict:

@@ -916,8 +916,13 @@ __device__ __forceinline__ void acc_set(const i32x4& v) {
 constexpr int W4_THREADS = 256;
 constexpr int W4_STAGE = (BM + BN) * 128;   // 64 KiB
 
-template <int DT, bool RES>
+// MB = 16-row activation blocks per wave: 8 = 256-row tiles; 7 = 224-row tiles (round 6, opt-in: fdm_set_gemm_tile_rows -- a launch whose tile
+// count sits just above a whole number of rounds takes more, smaller tiles: FLUX's N = 3072 projections 408 -> 468; same MFMAs in the same K
+// order per output element, so the results are bit-identical; what it is worth is measured beside `tile_rows_224` below).
+template <int DT, bool RES, int MB = 8>
 __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup grp) {
+  static_assert(MB == 8 || MB == 7, "gemm_w4_kernel: 256- or 224-row tiles");
+  constexpr int WROWS = 16 * MB, BMW = 2 * WROWS, NIT = WROWS / 4;    // rows of a wave's / the block's tile; 4-row store instructions per wave
   using M = Mma16<DT>;
   using Acc = typename M::Acc;
   using Frag = typename M::Frag;
@@ -938,7 +943,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    if constexpr (DT == DT_INT8) {
+    if constexpr (DT == DT_INT8 && MB == 8) {
       if (grp.mode == 1) {
         t = grp.total_tiles - grp.split_tiles + (bid >> grp.spread_shift);
       } else if (grp.splits > 1) {
@@ -967,7 +972,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     const int first_m = gid * GROUP_M;
     const int gsz = min(pp.tiles_m - first_m, GROUP_M);
     const int rem = t - gid * in_group;
-    m0 = (first_m + rem % gsz) * BM;
+    m0 = (first_m + rem % gsz) * BMW;
     n0 = (rem / gsz) * BN;
   }
   const GemmProblem& p = grp.p[prob];
@@ -980,7 +985,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
 #endif
 
   int64_t Kb = p.Kb, k_off = 0;
-  if constexpr (DT == DT_INT8) {
+  if constexpr (DT == DT_INT8 && MB == 8) {
     if (is_part) {   // K range of this part in 64-byte units (the host's split arithmetic); the last part takes the K tail
       const int nk_all = (int)((p.Kb + BKB - 1) / BKB);
       const int kt0 = (int)((int64_t)part * nk_all / grp.splits), kt1 = (int)((int64_t)(part + 1) * nk_all / grp.splits);
@@ -1004,29 +1009,31 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
   const uint8_t* zero_page = g_zero_page;
   // Stage kt: A rows in smem[(kt & 1) * 64 KiB ..], B rows 32 KiB behind them.  A and B are issued separately: B runs one
   // stage further ahead (its fragments are read a whole step before their MFMAs).
-  auto stage_half = [&](auto inner_c, int kt, const uint8_t* gbase, const uint32_t (&doff)[8], int lds_off) {
+  auto stage_half = [&](auto inner_c, auto nr_c, int kt, const uint8_t* gbase, const uint32_t (&doff)[8], int lds_off) {
+    constexpr int NR = decltype(nr_c)::value;     // rounds of 32 rows: MB for A, 8 for B
     uint8_t* sX = smem + (kt & 1) * W4_STAGE + lds_off + wave * 1024;
     const int64_t koff = (int64_t)kt * 128;
     if constexpr (decltype(inner_c)::value) {
       const uint32_t la = lds_addr_of(sX);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) glds16_sv(gbase + koff, doff[r], la + r * 4096);
+      for (int r = 0; r < NR; ++r) glds16_sv(gbase + koff, doff[r], la + r * 4096);
     } else {
       const bool ok = koff + dchunk * 16 < Kb;   // K % 16 == 0: a chunk lies inside K or outside
       // (the offsets are made opaque so that hipcc does not keep 16 loop-invariant 64-bit lane addresses alive for this path)
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
+      for (int r = 0; r < NR; ++r) {
         uint32_t o = doff[r];
         asm volatile("" : "+v"(o));
         glds16(ok ? gbase + koff + o : zero_page, sX + r * 4096);
       }
     }
   };
-  auto stage_a = [&](auto inner_c, int kt) { stage_half(inner_c, kt, bA, da, 0); };
-  auto stage_b = [&](auto inner_c, int kt) { stage_half(inner_c, kt, bB, db, BM * 128); };
+  auto stage_a = [&](auto inner_c, int kt) { stage_half(inner_c, std::integral_constant<int, MB>{}, kt, bA, da, 0); };
+  auto stage_b = [&](auto inner_c, int kt) { stage_half(inner_c, std::integral_constant<int, 8>{}, kt, bB, db, BM * 128); };
   // DMA j (0..15) of the set issued behind step t's barrier: rounds 0..7 of A(t + 2), then rounds 0..7 of B(t + 3)
   auto dma_one = [&](auto inner_c, auto jc, int t) {
     constexpr int j = decltype(jc)::value, r = j & 7;
+    if constexpr (j < 8 && r >= MB) return;      // (224-row tiles: A has 7 rounds)
     const int kt = j < 8 ? t + 2 : t + 3;
     const uint8_t* gbase = j < 8 ? bA : bB;
     const uint32_t off = j < 8 ? da[r] : db[r];
@@ -1095,7 +1102,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
   // ---- fragment reads: lane (fi = lane % 16, fq = lane / 16) of block b reads row b * 16 + fi
   const int fi = lane & 15, fq = lane >> 4;
   const int fg = ((fi >> 1) & 1) | (((fi >> 3) & 1) << 1);
-  const int a_row = (wm * 128 + fi) * 128, b_row = BM * 128 + (wn * 128 + fi) * 128;
+  const int a_row = (wm * WROWS + fi) * 128, b_row = BM * 128 + (wn * 128 + fi) * 128;
   // fp8: chunk pair fq, odd fq first take the odd chunk (bank spread; same rule for both operands)
 #ifdef FDM_W4_NOSWAP
   const int f8_0 = ((fq ^ fg) << 1) * 16, f8_1 = f8_0 ^ 16;
@@ -1129,7 +1136,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
 
   // int8 split-K tail, merge launch: accumulators = sum of the parts' int32 partials (exact), no K loop
   bool merged = false;
-  if constexpr (DT == DT_INT8) {
+  if constexpr (DT == DT_INT8 && MB == 8) {
     if (grp.mode == 1) {
       merged = true;
       const int32_t* src = grp.ws + ((int64_t)(blockIdx.x >> grp.spread_shift) * grp.splits) * (64 * 256 * 4) + tid * 4;
@@ -1181,7 +1188,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
       stage_a(std::false_type{}, 1);
       stage_b(std::false_type{}, 1);
     }
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // stage 0 (stage 1 lands while its B fragments are read)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MB + 8) : "memory");   // stage 0 (stage 1 lands while its B fragments are read)
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) read_b_blk(fbx, 0, nb);
@@ -1201,12 +1208,14 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     // The block's one barrier per step sits in group 7 behind the wait: every read of stage t has returned and the DMAs issued
     // a step ago (A(t + 1), B(t + 2)) have landed; behind it A(t + 2) goes into A(t)'s buffer and B(t + 3) into B(t + 1)'s
     // (in registers since group 3), and A block 0 of stage t + 1 is read.
-    auto step = [&](auto inner_c, auto first_c, Frag (&bc)[NS][8], Frag (&bn)[NS][8], int t) {
+    // (MB = 7: an odd number of A blocks per step, so the two A fragment registers swap roles every step: PAR = t & 1 as a constant)
+    auto step = [&](auto inner_c, auto first_c, auto par_c, Frag (&bc)[NS][8], Frag (&bn)[NS][8], int t) {
+      constexpr int PAR = (MB & 1) ? decltype(par_c)::value : 0;
       const int cur = t & 1, nxt = cur ^ 1;
       const uint8_t* sa_cur = smem + cur * W4_STAGE + a_row;
-      static_for<8>([&](auto gc) {
+      static_for<MB>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
-        if constexpr (g == 7) {
+        if constexpr (g == MB - 1) {
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifndef FDM_W4_NOBAR      // (timing ablation only)
           __builtin_amdgcn_s_barrier();
@@ -1215,13 +1224,13 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
           touch_retired();
           __builtin_amdgcn_sched_barrier(0);
           touch(t + 3 + TOUCH_AHEAD);               // (B(t + 3)'s DMAs follow in the next step)
-          read_frag(fa[0], smem + nxt * W4_STAGE + a_row, 0);
+          read_frag(fa[(MB + PAR) & 1], smem + nxt * W4_STAGE + a_row, 0);
         } else {
           constexpr int cnt = (g >= 1 && g <= 4) ? 4 : 0;
           __builtin_amdgcn_s_waitcnt(0xC07F | (cnt << 8));    // lgkmcnt(cnt) only
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (!SPREAD_READS) {
-            read_frag(fa[(g + 1) & 1], sa_cur, g + 1);
+            read_frag(fa[(g + 1 + PAR) & 1], sa_cur, g + 1);
             if constexpr (g < 4) {
               read_b_blk(bn, nxt, 2 * g);
               read_b_blk(bn, nxt, 2 * g + 1);
@@ -1231,13 +1240,13 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
         __builtin_amdgcn_sched_barrier(0);
         static_for<NS * 8>([&](auto jc) {
           constexpr int s = decltype(jc)::value / 8, nb = decltype(jc)::value % 8;
-          M::template run<g * 8 + nb, decltype(first_c)::value && s == 0>(bc[s][nb], fa[g & 1][s]);   // swapped operands: MFMA rows = n, columns = m
-          if constexpr (SPREAD_READS && g < 7) {
+          M::template run<g * 8 + nb, decltype(first_c)::value && s == 0>(bc[s][nb], fa[(g + PAR) & 1][s]);   // swapped operands: MFMA rows = n, columns = m
+          if constexpr (SPREAD_READS && g < MB - 1) {
             // int8 / bf16: an MFMA lasts 16 cycles, the group's 2 + 4 fragment reads in one burst in front of it are 28 cycles of issue
             // with the matrix core idle for half of them.  One read behind each of the group's first MFMAs instead, in the same order
             // (A block g + 1 first, then the B blocks of step t + 1), so the counted lgkmcnt waits above still mean what they say.
             constexpr int q = decltype(jc)::value;
-            if constexpr (q < NS) fa[(g + 1) & 1][q] = read_frag_slice(sa_cur, g + 1, q);
+            if constexpr (q < NS) fa[(g + 1 + PAR) & 1][q] = read_frag_slice(sa_cur, g + 1, q);
             else if constexpr (g < 4 && q < NS + 2 * NS) {
               constexpr int k = q - NS, blk = 2 * g + k / NS, sl = k % NS;
               bn[sl][blk] = read_frag_slice(smem + nxt * W4_STAGE + b_row, blk, sl);
@@ -1250,7 +1259,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
           constexpr int q = decltype(jc)::value, every = NS * 2;      // one DMA slot after every 2nd (NS = 1) / 4th MFMA
           if constexpr (q % every == every - 1) {
             constexpr int slot = q / every;                            // 0..3
-            if constexpr (g == 7) dma_one(inner_c, std::integral_constant<int, slot>{}, t);
+            if constexpr (g == MB - 1) dma_one(inner_c, std::integral_constant<int, slot>{}, t);
             if constexpr (g < 4 && slot < 3 && !decltype(first_c)::value) dma_one(inner_c, std::integral_constant<int, 4 + 3 * g + slot>{}, t - 1);
           }
         });
@@ -1259,21 +1268,23 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     };
     const int nk2 = (nk + 1) & ~1;
     // step 0 has no DMAs left over from a previous step (the prologue issued A(1), B(2) whole)
-    step(std::false_type{}, std::true_type{}, fbx, fby, 0);
-    step(std::false_type{}, std::false_type{}, fby, fbx, 1);
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    step(std::false_type{}, std::true_type{}, P0{}, fbx, fby, 0);
+    step(std::false_type{}, std::false_type{}, P1{}, fby, fbx, 1);
     int t = 2;
     for (; t + 4 < nk_full; t += 2) {            // issues stages up to t + 4: all complete
-      step(std::true_type{}, std::false_type{}, fbx, fby, t);
-      step(std::true_type{}, std::false_type{}, fby, fbx, t + 1);
+      step(std::true_type{}, std::false_type{}, P0{}, fbx, fby, t);
+      step(std::true_type{}, std::false_type{}, P1{}, fby, fbx, t + 1);
     }
     for (; t < nk2; t += 2) {                     // K tail and (odd nk) one zero-filled padding step
-      step(std::false_type{}, std::false_type{}, fbx, fby, t);
-      step(std::false_type{}, std::false_type{}, fby, fbx, t + 1);
+      step(std::false_type{}, std::false_type{}, P0{}, fbx, fby, t);
+      step(std::false_type{}, std::false_type{}, P1{}, fby, fbx, t + 1);
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15" ::: "memory");  // retire the padding DMAs and the dead fragment reads; MFMA -> v_accvgpr_read distance
   __builtin_amdgcn_s_barrier();                                  // every wave is done with the ring: reuse it below
-  if constexpr (DT == DT_INT8) {
+  if constexpr (DT == DT_INT8 && MB == 8) {
     if (grp.mode == 1 && (wave >> (2 - grp.spread_shift)) != (int)(blockIdx.x & ((1 << grp.spread_shift) - 1))) return;
     if (is_part) {   // int32 partial sums of this K range -> workspace ([tile * splits + part][64 blocks][256 threads] x 16 B)
       int32_t* dst = grp.ws + ((int64_t)part_slot) * (64 * 256 * 4) + tid * 4;
@@ -1290,14 +1301,14 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
 
   // ---- epilogue.  Wave-private LDS tile: 128 rows x 256 B; 16-byte chunk c of row r stored at chunk c ^ (r & 15).
   uint8_t* wt = smem + wave * 32768;
-  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  const bool full = (m0 + BMW <= p.M) && (n0 + BN <= p.N);
   auto epilogue = [&](auto epi_c) {
     constexpr int EPI = decltype(epi_c)::value;
     float sam[8];
     int azpm[8];
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-      const int mc = min(m0 + wm * 128 + mb * 16 + fi, p.M - 1);
+    for (int mb = 0; mb < MB; ++mb) {
+      const int mc = min(m0 + wm * WROWS + mb * 16 + fi, p.M - 1);
       sam[mb] = 1.0f;
       azpm[mb] = 0;
       if constexpr (DT != DT_BF16) sam[mb] = p.sa[mc];
@@ -1342,9 +1353,10 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
       static_for<2>([&](auto hc) {
         constexpr int h = decltype(hc)::value;
         if constexpr (HALF == -1 || HALF == h) {
-        float y[16];   // [mm][c]
+        float y[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // [mm][c]
         static_for<4>([&](auto mmc) {
           constexpr int mm = decltype(mmc)::value, mb = h * 4 + mm;
+          if constexpr (mb < MB) {
           const i32x4 av = acc_get<mb * 8 + nb>();
           const int aw[4] = {av[0], av[1], av[2], av[3]};   // (a bit_cast applied to `av[c]` directly read element 0 for every c)
 #pragma unroll
@@ -1361,10 +1373,11 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
             }
             y[4 * mm + c] = (EPI == FDM_EPI_GELU_TANH || EPI == FDM_EPI_GELU_ERF) ? rbf(yy) : yy;
           }
+          }
         });
         gelu16<EPI>(y);
 #pragma unroll
-        for (int mm = 0; mm < 4; ++mm) {
+        for (int mm = 0; mm < (h * 4 + 4 <= MB ? 4 : MB - h * 4); ++mm) {
           i32x2 o;
           o[0] = (int)pack2bf(y[4 * mm], y[4 * mm + 1]);
           o[1] = (int)pack2bf(y[4 * mm + 2], y[4 * mm + 3]);
@@ -1400,7 +1413,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
         // whole tile, no residual: the two 64-row halves go out one after the other -- the row stores of the first half (queued,
         // asynchronous) drain through the CU's store path while the VALU scales and packs the second half (epilogue of a K = 3072
         // tile 12.6 k -> 11.8 k cycles)
-        bf16_t* cptr = p.C + (int64_t)(m0 + wm * 128 + rsub) * p.ldc + ccol;
+        bf16_t* cptr = p.C + (int64_t)(m0 + wm * WROWS + rsub) * p.ldc + ccol;
         const int64_t step4 = 4 * p.ldc;
         static_for<2>([&](auto hfc) {
           constexpr int hf = decltype(hfc)::value;
@@ -1408,11 +1421,12 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
 #ifdef FDM_GEMM_STAMPS
           if (hf == 1 && tid == 0) stamp[4] = __builtin_readcyclecounter();
 #endif
-          i32x4 v[16];
+          constexpr int NH = hf == 0 ? 16 : NIT - 16;
+          i32x4 v[NH];
 #pragma unroll
-          for (int it = 0; it < 16; ++it) v[it] = lds_row(hf * 16 + it);
+          for (int it = 0; it < NH; ++it) v[it] = lds_row(hf * 16 + it);
 #pragma unroll
-          for (int it = 0; it < 16; ++it) *reinterpret_cast<i32x4*>(cptr + (hf * 16 + it) * step4) = v[it];
+          for (int it = 0; it < NH; ++it) *reinterpret_cast<i32x4*>(cptr + (hf * 16 + it) * step4) = v[it];
         });
         return;
       }
@@ -1422,7 +1436,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
     if (tid == 0) stamp[4] = __builtin_readcyclecounter();
 #endif
     auto store_row = [&](int it, const i32x4& v) {
-      const int m = m0 + wm * 128 + it * 4 + rsub;
+      const int m = m0 + wm * WROWS + it * 4 + rsub;
       if (n_ok && (full || m < p.M)) *reinterpret_cast<i32x4*>(p.C + (int64_t)m * p.ldc + ccol) = v;
     };
     auto combine = [&](auto f32_c, const i32x4& yv, const float (&g8)[8], const i32x4& rv) -> i32x4 {
@@ -1442,11 +1456,11 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
       return o;
     };
     if constexpr (EPI == FDM_EPI_GATE_RESIDUAL) {
-      const int m_first = m0 + wm * 128, m_last = min(m0 + wm * 128 + 128, p.M) - 1;
+      const int m_first = m0 + wm * WROWS, m_last = min(m0 + wm * WROWS + WROWS, p.M) - 1;
       const bool one_batch = (m_first / p.rows_per_batch) == (m_last / p.rows_per_batch);
       const bool n_ok_all = n0 + BN <= p.N;     // (this kernel only takes problems of whole N tiles: always true)
       auto res_row = [&](int it) -> i32x4 {
-        const int mc = min(m0 + wm * 128 + it * 4 + rsub, p.M - 1);
+        const int mc = min(m0 + wm * WROWS + it * 4 + rsub, p.M - 1);
         return *reinterpret_cast<const i32x4*>(p.res + (int64_t)mc * p.ldc + ncc);
       };
       auto load_gate = [&](int64_t batch, float (&g8)[8]) {
@@ -1467,7 +1481,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
           }
         }
       };
-      bf16_t* cptr = p.C + (int64_t)(m0 + wm * 128 + rsub) * p.ldc + ccol;
+      bf16_t* cptr = p.C + (int64_t)(m0 + wm * WROWS + rsub) * p.ldc + ccol;
       const int64_t step4 = 4 * p.ldc;
       auto pipelined = [&](auto f32_c, auto fast_c) {
         // groups of 8 row-instructions: loads(g) run one group ahead of combine(g - 1) + stores(g - 1); every load of a
@@ -1477,29 +1491,30 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
         // count per store.  (The row-at-a-time edge path below is one exposed gate + residual round trip per row-instruction:
         // +12 ... 19 us on a launch whose last tiles are ragged, Qwen-Image's M = 6889: profiles/r04_experiments.md.)
         constexpr bool FAST = decltype(fast_c)::value;
-        int it_max = 32;
+        constexpr int GS = NIT / 4;     // row-instructions per group: 8 (7 for 224-row tiles)
+        int it_max = NIT;
         if constexpr (!FAST) {
-          const int rows_valid = p.M - (m0 + wm * 128) - rsub;    // rows 4 it + rsub < M - tile row 0
+          const int rows_valid = p.M - (m0 + wm * WROWS) - rsub;    // rows 4 it + rsub < M - tile row 0
           it_max = rows_valid <= 0 ? 0 : (rows_valid + 3) >> 2;
         }
         float g8[8];
         load_gate(m_first / p.rows_per_batch, g8);
         i32x4 rr[2][8], oo[8];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) rr[0][it] = res_row(it);
+        for (int it = 0; it < GS; ++it) rr[0][it] = res_row(it);
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
           if (gi < 3) {
 #pragma unroll
-            for (int it = 0; it < 8; ++it) rr[(gi + 1) & 1][it] = res_row((gi + 1) * 8 + it);
+            for (int it = 0; it < GS; ++it) rr[(gi + 1) & 1][it] = res_row((gi + 1) * GS + it);
           }
 #pragma unroll
-          for (int it = 0; it < 8; ++it) oo[it] = combine(f32_c, lds_row(gi * 8 + it), g8, rr[gi & 1][it]);
+          for (int it = 0; it < GS; ++it) oo[it] = combine(f32_c, lds_row(gi * GS + it), g8, rr[gi & 1][it]);
           asm volatile("" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int it = 0; it < 8; ++it) {
-            if (FAST || gi * 8 + it < it_max) *reinterpret_cast<i32x4*>(cptr + (gi * 8 + it) * step4) = oo[it];
+          for (int it = 0; it < GS; ++it) {
+            if (FAST || gi * GS + it < it_max) *reinterpret_cast<i32x4*>(cptr + (gi * GS + it) * step4) = oo[it];
           }
         }
       };
@@ -1512,8 +1527,8 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
       } else {
         // edge tiles and waves whose rows straddle a batch boundary (rare): per-row gate vector, guarded stores, unpipelined
         // (the double-buffered form with guarded stores ran out of registers: hipcc parked three of them in a0..a2)
-        for (int it = 0; it < 32; ++it) {
-          const int mc = min(m0 + wm * 128 + it * 4 + rsub, p.M - 1);
+        for (int it = 0; it < NIT; ++it) {
+          const int mc = min(m0 + wm * WROWS + it * 4 + rsub, p.M - 1);
           float g8[8];
           load_gate(mc / p.rows_per_batch, g8);
           const i32x4 rv = res_row(it);
@@ -1522,7 +1537,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) gemm_w4_kernel(const GemmGroup 
       }
     } else {
 #pragma unroll
-      for (int it = 0; it < 32; ++it) store_row(it, lds_row(it));
+      for (int it = 0; it < NIT; ++it) store_row(it, lds_row(it));
     }
   };
   if constexpr (RES) {
@@ -1621,7 +1636,7 @@ int g_gemm_use_w4 = 1;   // micro-benchmark builds only: both kernels in one pro
 // Dispatch policy knobs (A/B runs, parity tests): process-wide atomics set through fdm_set_gemm_dispatch() -- the library reads NO environment
 // variable; fastdm_amd/_native.py translates FDM_GEMM_KERNEL / FDM_GEMM_P4 / FDM_GEMM_HALF_TILES on the host side when it loads
 // the library.  kernel: 2 auto (default) | 1 the 4-wave kernel everywhere it runs | 0 the 8-wave kernel everywhere.
-static std::atomic<int> g_dispatch_kernel{2}, g_dispatch_p4{1}, g_dispatch_half{-1};
+static std::atomic<int> g_dispatch_kernel{2}, g_dispatch_p4{1}, g_dispatch_half{-1}, g_dispatch_rows{-1};
 static int gemm_kernel_mode() { return g_dispatch_kernel.load(std::memory_order_relaxed); }
 template <int DT>
 static bool use_w4(const GemmGroup& grp) {
@@ -1735,6 +1750,25 @@ static bool half_tiles_pay(const GemmGroup& grp) {
   return t_half < t_full - 0.05f;
 }
 
+// 224-row tiles for a launch of the 4-wave kernel (gemm_w4_kernel<.., 7>): OPT-IN through fdm_set_gemm_tile_rows(224), never the default.
+// Round 6 measurement (profiles/r06_experiments.md "224-row tiles"): FLUX's N = 3072 projections are 34 x 12 = 408 tiles of 256 rows = 2 rounds,
+// the second 59 % full; 39 x 12 = 468 tiles of 224 rows are still 2 rounds, each 7/8 as long.  Back to back on random operands that is worth
+// 9-14 % (370 -> 319 us, 259 -> 236); INSIDE the step it is worth nothing (312 -> 304, 263 -> 262, 93 -> 99 us; step 100.64 vs 100.66 ms on one
+// box; Qwen-Image +2.3 ms because it displaces the int8 split-K tail): the package sits at its power limit there, and the CUs a partial round
+// leaves idle hand their share of it to the busy ones as clock.  Kept for the A/B and because the results are bit-identical either way.
+constexpr int BM7 = 224;
+static GemmGroup with_tile_rows_224(const GemmGroup& grp) {
+  GemmGroup g = grp;
+  g.total_tiles = 0;
+  for (int i = 0; i < g.n; ++i) {
+    g.p[i].tiles_m = (g.p[i].M + BM7 - 1) / BM7;
+    g.total_tiles += g.p[i].tiles_m * g.p[i].tiles_n;
+  }
+  g.n_blocks = g.total_tiles;
+  return g;
+}
+static bool tile_rows_224(const GemmGroup& grp) { return g_dispatch_rows.load(std::memory_order_relaxed) == BM7 && grp.splits <= 1 && grp.mode == 0; }
+
 constexpr int64_t SPLIT_PART_BYTES = (int64_t)BM * BN * 4;   // one K part of one tile: 256 x 256 int32
 static thread_local int g_last_gemm_kernel = -1;              // fdm_gemm_last_kernel()
 
@@ -1774,6 +1808,7 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, 
       // only for long K loops: >= 160 steps of 64 bytes (a tile of >= ~120 us).  K = 3072 tiles (46 us) are never split.
       if (nk_min < 160) S = 1;
     }
+    if (S > 1 && use_w4<DT>(grp) && tile_rows_224(grp)) S = 1;     // (A/B: the forced 224-row form has no split-K tail)
     if (S > 1) {
       GemmGroup g2 = grp;
       g2.split_tiles = rem;
@@ -1815,9 +1850,16 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, 
     }
   }
   if (use_w4<DT>(grp)) {
-    if (res) gemm_w4_kernel<DT, true><<<grid, W4_THREADS, 0, s>>>(grp);
-    else gemm_w4_kernel<DT, false><<<grid, W4_THREADS, 0, s>>>(grp);
-    g_last_gemm_kernel = FDM_GEMM_KERNEL_W4;
+    if (tile_rows_224(grp)) {
+      const GemmGroup g7 = with_tile_rows_224(grp);
+      if (res) gemm_w4_kernel<DT, true, 7><<<g7.total_tiles, W4_THREADS, 0, s>>>(g7);
+      else gemm_w4_kernel<DT, false, 7><<<g7.total_tiles, W4_THREADS, 0, s>>>(g7);
+      g_last_gemm_kernel = FDM_GEMM_KERNEL_W4_224;
+    } else {
+      if (res) gemm_w4_kernel<DT, true><<<grid, W4_THREADS, 0, s>>>(grp);
+      else gemm_w4_kernel<DT, false><<<grid, W4_THREADS, 0, s>>>(grp);
+      g_last_gemm_kernel = FDM_GEMM_KERNEL_W4;
+    }
   } else if (half_tiles_pay(grp)) {
     // 256 x 128 half tiles, two 4-wave blocks per CU (gemm_kernel<.., 2>): same wave code, twice the work items
     GemmGroup g2 = grp;
@@ -2014,6 +2056,12 @@ static int launch_gemv(void* out, const void* a, const void* b, const void* bias
 extern "C" {
 
 int fdm_gemm_last_kernel(void) { return g_last_gemm_kernel; }
+
+int fdm_set_gemm_tile_rows(int rows) {
+  if (rows != -1 && rows != 256 && rows != 224) return FDM_ERR_INVALID;     // -1 = the default = 256
+  fdm::g_dispatch_rows.store(rows, std::memory_order_relaxed);
+  return FDM_OK;
+}
 
 int fdm_set_gemm_dispatch(int kernel, int p4, int half_tiles) {
   if (kernel < -1 || kernel > 2 || p4 < -1 || p4 > 2 || half_tiles < -1 || half_tiles > 1) return FDM_ERR_INVALID;

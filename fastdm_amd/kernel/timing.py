@@ -16,7 +16,7 @@ def log_gemm(dtype: str, problems):
     if shape_log is not None:
         shape_log.append({"dtype": dtype, "problems": [list(map(int, p)) for p in problems if p[0] > 0]})
 GEMM_KERNEL_NAMES = {0: "fdm::gemm_kernel", 1: "fdm::gemm_w4_kernel", 2: "fdm::gemm_p4_kernel", 3: "fdm::gemv_bf16_kernel",
-                     4: "fdm::gemm_kernel<.., 2> (half tiles)"}   # fdm_gemm_last_kernel()
+                     4: "fdm::gemm_kernel<.., 2> (half tiles)", 5: "fdm::gemm_w4_kernel<.., 7> (224-row tiles)"}   # fdm_gemm_last_kernel()
 
 
 class Recorder:

@@ -44,7 +44,7 @@ const char* fdm_last_hip_error_string(void);
 
 /* Bumped whenever an entry point changes its argument list: a binding built against another revision of this header must
  * refuse to run instead of passing arguments at the wrong positions. */
-#define FDM_ABI_VERSION 19
+#define FDM_ABI_VERSION 20
 int fdm_abi_version(void);
 
 /* Provenance the binary carries itself (no stamp file beside it): the content digest (64 hex digits) of every source the
@@ -191,6 +191,7 @@ int fdm_gemm_w8a8_int8_x2_ws(const fdm_gemm_int8_desc* d0, const fdm_gemm_int8_d
 #define FDM_GEMM_KERNEL_P4 2
 #define FDM_GEMM_KERNEL_GEMV 3
 #define FDM_GEMM_KERNEL_W8_HALF 4    /* fdm::gemm_kernel<.., 2>: the 8-wave kernel's wave code on 256 x 128 half tiles (ABI 19) */
+#define FDM_GEMM_KERNEL_W4_224 5     /* fdm::gemm_w4_kernel<.., 7>: the 4-wave kernel on 224-row tiles (ABI 20) */
 int fdm_gemm_last_kernel(void);
 
 /* A/B and parity-test control of the GEMM dispatch policy (process-wide, atomic; default = auto everywhere).  The library reads no environment
@@ -200,6 +201,11 @@ int fdm_gemm_last_kernel(void);
  *   p4         -1 default (plain / tanh-GELU launches) | 0 never | 1 default | 2 every epilogue it implements      (ignored when kernel is 0 / 1)
  *   half_tiles -1 the cost model | 0 never | 1 always (8-wave kernel only)                                                               */
 int fdm_set_gemm_dispatch(int kernel, int p4, int half_tiles);
+/* Tile height of the 4-wave kernel (ABI 20): -1 / 256 the default | 224 (A/B only: launches whose 256-row tile count sits just above a whole number
+ * of rounds -- 408 tiles on 256 CUs -- are 9-14 % faster back to back and NOT faster inside a denoise step, where the package is at its power limit;
+ * DESIGN.md 4.1).  Both forms run the same MFMAs in the same K order per output element: results are bit-identical.  _native.py translates
+ * FDM_GEMM_TILE_ROWS.  No reference counterpart.                                                                                              */
+int fdm_set_gemm_tile_rows(int rows);
 
 /* ---- 3 x 3 convolution, NHWC bf16, as an implicit GEMM on the 8-wave tile kernel (ABI 19) ----------------------------------------
  * The UNet's convolutions (/root/reference/fastdm/layer/resnetblock.py:29-47 conv1 / conv2, fastdm/layer/unetblock.py:203-218 downsample

@@ -423,8 +423,9 @@ def test_bench_names_the_gemm_kernel_from_the_recorded_launches():
     import bench
     by = {"fdm::gemm_p4_kernel": {"launches": 76, "total_ms": 17.0, "work": 1.0}, "fdm::gemm_w4_kernel": {"launches": 38, "total_ms": 11.6, "work": 1.0}}
     assert bench.span_kernel("gemm_w8a8_fp8", by) == "fdm::gemm_p4_kernel<0>"
-    assert bench.span_kernel("gemm_w8a8_fp8_res", {"fdm::gemm_w4_kernel": by["fdm::gemm_w4_kernel"]}) == "fdm::gemm_w4_kernel<0, true>"
-    assert bench.span_kernel("gemm_w8a8_int8", {"fdm::gemm_w4_kernel": by["fdm::gemm_w4_kernel"]}) == "fdm::gemm_w4_kernel<1, false>"
+    assert bench.span_kernel("gemm_w8a8_fp8_res", {"fdm::gemm_w4_kernel": by["fdm::gemm_w4_kernel"]}) == "fdm::gemm_w4_kernel<0, true, 8>"
+    assert bench.span_kernel("gemm_w8a8_int8", {"fdm::gemm_w4_kernel": by["fdm::gemm_w4_kernel"]}) == "fdm::gemm_w4_kernel<1, false, 8>"
+    assert bench.span_kernel("gemm_w8a8_fp8_res", {"fdm::gemm_w4_kernel<.., 7> (224-row tiles)": by["fdm::gemm_w4_kernel"]}) == "fdm::gemm_w4_kernel<0, true, 7>"
     assert bench.span_kernel("gemm_bf16_res", {"fdm::gemm_kernel": by["fdm::gemm_w4_kernel"]}) == "fdm::gemm_kernel<2, true>"
     assert bench.span_kernel("attn_fwd_bf16") == "fdm::attn_fwd64_kernel<128, false>"
     assert bench.span_kernel("attn_fwd_bf16_hd64") == "fdm::attn_fwd_kernel<64, 512, 64>"      # SD3.5 / SDXL: the round-1 kernel

@@ -491,6 +491,7 @@ def test_gemm_p4_persistent_assembly_is_bit_identical_to_gemm_w4():
         env.pop("FDM_GEMM_KERNEL", None)
         if tag == "w4":
             env["FDM_GEMM_KERNEL"] = "w4"        # (the auto policy sends K < 2048 bytes to the 8-wave kernel, whose fp32 summation order differs)
+            env["FDM_GEMM_TILE_ROWS"] = "256"    # (its 224-row form has a test of its own)
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "gemm_policy_worker.py")], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         out[tag] = json.loads(r.stdout.strip().splitlines()[-1])
@@ -1391,3 +1392,102 @@ def test_conv2d_small_channel_and_pointwise_forms(K, B, C, H, W, O, k):
     got = fused.conv2d(x.cuda(), w.cuda(), bias.cuda(), 1, k // 2)
     assert got.shape == want.shape
     ulp_close(got, want, 0.03, f"conv {k}x{k} {C} -> {O}")
+
+
+def test_gemm_224_row_tiles_are_bit_identical_to_256_row_tiles():
+    """gemm_w4_kernel<.., 7> (224-row tiles, opt-in through fdm_set_gemm_tile_rows: launches whose 256-row tile count sits just above a whole
+    number of rounds -- FLUX's N = 3072 projections, 408 tiles on 256 CUs; faster back to back, not inside the power-limited step) runs the same MFMAs in the same K order per output element and the same epilogue arithmetic as the 256-row
+    form, so every output bit must agree: fp8 / int8 (+ zero points) / bf16; plain, GELU and gate + residual epilogues; M ragged against both tile
+    heights; a wave tile that straddles a batch boundary; fp32 gates; an image + text pair with plane outputs.  fdm_set_gemm_tile_rows() forces
+    the form (process-wide atomic), fdm_gemm_last_kernel() proves which one ran."""
+    import ctypes
+    import hashlib
+    from fastdm_amd import _native as N
+    L = N.lib()
+    s = N.stream()
+
+    def sha(t):
+        torch.cuda.synchronize()
+        return hashlib.sha256(t.cpu().view(torch.int16).numpy().tobytes()).hexdigest()
+
+    def run(rows):
+        g = torch.Generator().manual_seed(977)
+        want = {256: 1, 224: 5}[rows]
+        res = {}
+        for name, (m, k, n, epi, rpb) in {
+            "fp8_res_ragged": (2500, 3072, 3072, N.EPI_GATE_RESIDUAL, 1250), "fp8_res_f32_gate": (1792, 2048, 768, N.EPI_GATE_RESIDUAL_F32, 1792),
+            "fp8_plain_whole": (1792, 2048, 768, N.EPI_NONE, 0), "fp8_tanh": (4096 + 37, 2048, 1024, N.EPI_GELU_TANH, 0),
+            "fp8_res_batches_of_100": (900, 2304, 512, N.EPI_GATE_RESIDUAL, 100), "fp8_one_row": (1, 2048, 256, N.EPI_NONE, 0),
+        }.items():
+            a = (torch.randn(m, k, generator=g) * 1.5).to(FP8).cuda()
+            b = (torch.randn(n, k, generator=g) * 1.5).to(FP8).cuda()
+            sa, sb = (torch.rand(m, 1, generator=g) * 0.02 + 0.002).cuda(), (torch.rand(n, 1, generator=g) * 0.02 + 0.002).cuda()
+            bias = (torch.randn(n, generator=g) * 0.5).to(BF16).cuda()
+            nb = (m + rpb - 1) // rpb if rpb else 1
+            gate = torch.randn(nb, n, generator=g)
+            gate = (gate if epi == N.EPI_GATE_RESIDUAL_F32 else gate.to(BF16)).cuda()
+            r = torch.randn(m, n + 8, generator=g).to(BF16).cuda()
+            out = torch.full((m, n + 8), 3.0, dtype=BF16, device="cuda")
+            gr = epi in (N.EPI_GATE_RESIDUAL, N.EPI_GATE_RESIDUAL_F32)
+            rc = L.fdm_gemm_w8a8_fp8(N.ptr(out), N.ptr(a), N.ptr(b), N.ptr(sa), N.ptr(sb), N.ptr(bias), m, n, k, k, k, n + 8, epi,
+                                     N.ptr(gate) if gr else None, n, N.ptr(r) if gr else None, rpb, s)
+            assert rc == 0 and L.fdm_gemm_last_kernel() == want, (name, rc, L.fdm_gemm_last_kernel())
+            assert (out[:, n:] == 3.0).all(), name
+            res[name] = sha(out)
+        for name, (m, k, n, epi) in {"i8_ragged": (1500, 2304, 1280, N.EPI_NONE), "i8_res": (2240, 2048, 512, N.EPI_GATE_RESIDUAL)}.items():
+            a = torch.randint(-128, 128, (m, k), generator=g, dtype=torch.int8).cuda()
+            b = torch.randint(-128, 128, (n, k), generator=g, dtype=torch.int8).cuda()
+            sa, sb = (torch.rand(m, 1, generator=g) * 0.01).cuda(), (torch.rand(n, 1, generator=g) * 0.01).cuda()
+            azp = torch.randint(-20, 20, (m, 1), generator=g, dtype=torch.int32).cuda()
+            adj = b.to(torch.int32).sum(dim=1, dtype=torch.int32).reshape(1, n).contiguous()
+            bias = (torch.randn(n, generator=g) * 0.5).to(BF16).cuda()
+            gate, r = torch.randn(1, n, generator=g).to(BF16).cuda(), torch.randn(m, n, generator=g).to(BF16).cuda()
+            out = torch.empty((m, n), dtype=BF16, device="cuda")
+            gr = epi == N.EPI_GATE_RESIDUAL
+            rc = L.fdm_gemm_w8a8_int8(N.ptr(out), N.ptr(a), N.ptr(b), N.ptr(sa), N.ptr(sb), N.ptr(adj), N.ptr(azp), N.ptr(bias), m, n, k, k, k, n, epi,
+                                      N.ptr(gate) if gr else None, n, N.ptr(r) if gr else None, m, s)
+            assert rc == 0 and L.fdm_gemm_last_kernel() == want, (name, rc, L.fdm_gemm_last_kernel())
+            res[name] = sha(out)
+        for name, (m, k, n, epi) in {"bf16_erf": (1000, 1024, 512, N.EPI_GELU_ERF), "bf16_plain": (2016, 1152, 768, N.EPI_NONE)}.items():
+            a, w = torch.randn(m, k, generator=g).to(BF16).cuda(), (torch.randn(n, k, generator=g) * k ** -0.5).to(BF16).cuda()
+            bias = (torch.randn(n, generator=g) * 0.1).to(BF16).cuda()
+            out = torch.empty((m, n), dtype=BF16, device="cuda")
+            rc = L.fdm_gemm_bf16(N.ptr(out), N.ptr(a), N.ptr(w), N.ptr(bias), m, n, k, k, k, n, epi, None, 0, None, 0, s)
+            assert rc == 0 and L.fdm_gemm_last_kernel() == want, (name, rc, L.fdm_gemm_last_kernel())
+            res[name] = sha(out)
+        # image + text pair, three output planes of 256 columns
+        C, kk, m_img, m_txt = 256, 2048, 700, 77
+        planes = torch.full((3, m_img + m_txt, C), 5.0, dtype=BF16, device="cuda")
+        ds, keep = [], []
+        for m, off in ((m_img, m_txt), (m_txt, 0)):
+            a = (torch.randn(m, kk, generator=g) * 1.5).to(FP8).cuda()
+            b = (torch.randn(3 * C, kk, generator=g) * 1.5).to(FP8).cuda()
+            sa, sb = (torch.rand(m, 1, generator=g) * 0.02 + 0.002).cuda(), (torch.rand(3 * C, 1, generator=g) * 0.02 + 0.002).cuda()
+            bias = (torch.randn(3 * C, generator=g) * 0.5).to(BF16).cuda()
+            keep += [a, b, sa, sb, bias]
+            d = N.GemmFp8Desc()
+            d.out, d.a, d.b, d.scale_a, d.scale_b, d.bias = N.ptr(planes[0, off:]), N.ptr(a), N.ptr(b), N.ptr(sa), N.ptr(sb), N.ptr(bias)
+            d.M, d.N, d.K, d.lda, d.ldb, d.ldc = m, 3 * C, kk, kk, kk, C
+            d.epilogue = N.EPI_NONE
+            d.epi_gate, d.epi_gate_stride, d.epi_res, d.epi_rows_per_batch = None, 0, None, 0
+            d.out_plane_cols, d.out_plane_stride = C, (m_img + m_txt) * C
+            ds.append(d)
+        rc = L.fdm_gemm_w8a8_fp8_x2(ctypes.byref(ds[0]), ctypes.byref(ds[1]), s)
+        assert rc == 0 and L.fdm_gemm_last_kernel() == want, rc
+        res["pair_planes"] = sha(planes)
+        return res
+
+    assert L.fdm_set_gemm_tile_rows(100) != 0
+    try:
+        assert L.fdm_set_gemm_dispatch(1, -1, -1) == 0        # the 4-wave kernel for every launch
+        out = {}
+        for rows in (256, 224):
+            assert L.fdm_set_gemm_tile_rows(rows) == 0
+            out[rows] = run(rows)
+    finally:
+        k, p4, half = N.gemm_dispatch_from_env()
+        L.fdm_set_gemm_dispatch(k, p4, half)
+        L.fdm_set_gemm_tile_rows(int(os.environ.get("FDM_GEMM_TILE_ROWS", "-1")))
+    assert len(out[256]) == 11
+    for name in out[256]:
+        assert out[256][name] == out[224][name], f"{name}: 224-row tiles differ from 256-row tiles"
