@@ -251,7 +251,7 @@ def _apply_env_dispatch(handle):
         rc = handle.fdm_set_gemm_dispatch(k, p4, half)
         if rc != 0:
             raise ValueError(f"FDM_GEMM_KERNEL / FDM_GEMM_P4 / FDM_GEMM_HALF_TILES = {k}, {p4}, {half}: rejected by fdm_set_gemm_dispatch ({rc})")
-    rows = os.environ.get("FDM_GEMM_TILE_ROWS", "")       # 256 | 224: tile height of the 4-wave kernel (A/B); unset = 256
+    rows = os.environ.get("FDM_GEMM_TILE_ROWS", "")       # 256 | 224: tile height of the 4-wave kernel (A/B); unset = the policy of gemm.hip tile_rows_224
     if rows != "":
         rc = handle.fdm_set_gemm_tile_rows(int(rows))
         if rc != 0:

@@ -1661,7 +1661,11 @@ static bool use_w4(const GemmGroup& grp) {
     const GemmProblem& q = grp.p[i];
     if (q.Kb < 2048) return false;
     if (!many_rounds && (q.M % BM)) return false;
-    if ((q.N % BN) || (q.Kb % 256)) return false;
+    // ragged N (a last column tile with masked stores) and an odd number of 128-byte K steps (one zero-filled padding step): SD3.5-large's
+    // N = K = 2432.  Neutral in round 3 (56.9 -> 56.6 ms); with the cooperative weight touch of round 6 it pays: 55.05 / 55.12 -> 53.74 / 53.77 ms
+    // per step on one box (profiles/r06af_*), so whole launches of >= 1 round take the 4-wave kernel whatever N and K are
+    if (!many_rounds && ((q.N % BN) || (q.Kb % 256))) return false;
+    if ((q.N % 8) || (q.Kb % 16)) return false;
   }
   return true;
 #endif
@@ -1750,12 +1754,13 @@ static bool half_tiles_pay(const GemmGroup& grp) {
   return t_half < t_full - 0.05f;
 }
 
-// 224-row tiles for a launch of the 4-wave kernel (gemm_w4_kernel<.., 7>): OPT-IN through fdm_set_gemm_tile_rows(224), never the default.
-// Round 6 measurement (profiles/r06_experiments.md "224-row tiles"): FLUX's N = 3072 projections are 34 x 12 = 408 tiles of 256 rows = 2 rounds,
-// the second 59 % full; 39 x 12 = 468 tiles of 224 rows are still 2 rounds, each 7/8 as long.  Back to back on random operands that is worth
-// 9-14 % (370 -> 319 us, 259 -> 236); INSIDE the step it is worth nothing (312 -> 304, 263 -> 262, 93 -> 99 us; step 100.64 vs 100.66 ms on one
-// box; Qwen-Image +2.3 ms because it displaces the int8 split-K tail): the package sits at its power limit there, and the CUs a partial round
-// leaves idle hand their share of it to the busy ones as clock.  Kept for the A/B and because the results are bit-identical either way.
+// 224-row tiles for a launch of the 4-wave kernel (gemm_w4_kernel<.., 7>).  Unit = one 16-row block column of a tile: a launch costs rounds x rows / 16.
+// FLUX's N = 3072 projections are 34 x 12 = 408 tiles of 256 rows = 2 rounds x 8, the second 59 % full; 39 x 12 = 468 tiles of 224 rows are 2 rounds x 7.
+// Round 6 measurements (profiles/r06_experiments.md "224-row tiles"): back to back on random operands that is worth 9-14 % (370 -> 319 us, 259 -> 236);
+// INSIDE the power-limited FLUX step it is worth nothing either way (312 -> 304, 263 -> 262, 93 -> 99 us; step 100.64 vs 100.66 ms on one box: the CUs a
+// partial round leaves idle hand their share of the package power to the busy ones as clock); where the step is NOT at the power limit it pays
+// (SD3.5-large with its N = K = 2432 launches on this kernel: 53.75 -> 52.68 ms).  Policy: 224 rows where the rounds arithmetic promises >= 10 %, never
+// in place of the int8 split-K tail (Qwen-Image: the split gets closer to the ideal than 7/8).  fdm_set_gemm_tile_rows(256 | 224) forces the answer.
 constexpr int BM7 = 224;
 static GemmGroup with_tile_rows_224(const GemmGroup& grp) {
   GemmGroup g = grp;
@@ -1767,7 +1772,16 @@ static GemmGroup with_tile_rows_224(const GemmGroup& grp) {
   g.n_blocks = g.total_tiles;
   return g;
 }
-static bool tile_rows_224(const GemmGroup& grp) { return g_dispatch_rows.load(std::memory_order_relaxed) == BM7 && grp.splits <= 1 && grp.mode == 0; }
+static bool tile_rows_224(const GemmGroup& grp, bool forced_only = false) {
+  if (grp.splits > 1 || grp.mode != 0) return false;
+  const int forced = g_dispatch_rows.load(std::memory_order_relaxed);
+  if (forced > 0 || forced_only) return forced == BM7;
+  const int cu = device_cu_count();
+  int t7 = 0;
+  for (int i = 0; i < grp.n; ++i) t7 += ((grp.p[i].M + BM7 - 1) / BM7) * grp.p[i].tiles_n;
+  const int c8 = 8 * ((grp.total_tiles + cu - 1) / cu), c7 = 7 * ((t7 + cu - 1) / cu);
+  return 10 * c7 <= 9 * c8;
+}
 
 constexpr int64_t SPLIT_PART_BYTES = (int64_t)BM * BN * 4;   // one K part of one tile: 256 x 256 int32
 static thread_local int g_last_gemm_kernel = -1;              // fdm_gemm_last_kernel()
@@ -1808,7 +1822,7 @@ static int launch_gemm(const GemmGroup& grp, hipStream_t s, void* ws = nullptr, 
       // only for long K loops: >= 160 steps of 64 bytes (a tile of >= ~120 us).  K = 3072 tiles (46 us) are never split.
       if (nk_min < 160) S = 1;
     }
-    if (S > 1 && use_w4<DT>(grp) && tile_rows_224(grp)) S = 1;     // (A/B: the forced 224-row form has no split-K tail)
+    if (S > 1 && use_w4<DT>(grp) && tile_rows_224(grp, true)) S = 1;     // (A/B: the FORCED 224-row form has no split-K tail; the policy prefers the split)
     if (S > 1) {
       GemmGroup g2 = grp;
       g2.split_tiles = rem;
@@ -2058,7 +2072,7 @@ extern "C" {
 int fdm_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 
 int fdm_set_gemm_tile_rows(int rows) {
-  if (rows != -1 && rows != 256 && rows != 224) return FDM_ERR_INVALID;     // -1 = the default = 256
+  if (rows != -1 && rows != 256 && rows != 224) return FDM_ERR_INVALID;     // -1 = the policy (tile_rows_224)
   fdm::g_dispatch_rows.store(rows, std::memory_order_relaxed);
   return FDM_OK;
 }

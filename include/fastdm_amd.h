@@ -201,10 +201,10 @@ int fdm_gemm_last_kernel(void);
  *   p4         -1 default (plain / tanh-GELU launches) | 0 never | 1 default | 2 every epilogue it implements      (ignored when kernel is 0 / 1)
  *   half_tiles -1 the cost model | 0 never | 1 always (8-wave kernel only)                                                               */
 int fdm_set_gemm_dispatch(int kernel, int p4, int half_tiles);
-/* Tile height of the 4-wave kernel (ABI 20): -1 / 256 the default | 224 (A/B only: launches whose 256-row tile count sits just above a whole number
- * of rounds -- 408 tiles on 256 CUs -- are 9-14 % faster back to back and NOT faster inside a denoise step, where the package is at its power limit;
- * DESIGN.md 4.1).  Both forms run the same MFMAs in the same K order per output element: results are bit-identical.  _native.py translates
- * FDM_GEMM_TILE_ROWS.  No reference counterpart.                                                                                              */
+/* Tile height of the 4-wave kernel (ABI 20): -1 the policy (default: 224-row tiles where rounds x rows promises >= 10 % -- a launch whose 256-row tile
+ * count sits just above a whole number of rounds, 408 tiles on 256 CUs -- and never in place of the int8 split-K tail) | 256 | 224.  Both forms run the
+ * same MFMAs in the same K order per output element: results are bit-identical.  Measured: 9-14 % per launch back to back, neutral inside
+ * the power-limited FLUX step, -2 % on the SD3.5-large step.  _native.py translates FDM_GEMM_TILE_ROWS.  No reference counterpart.                    */
 int fdm_set_gemm_tile_rows(int rows);
 
 /* ---- 3 x 3 convolution, NHWC bf16, as an implicit GEMM on the 8-wave tile kernel (ABI 19) ----------------------------------------

@@ -275,9 +275,11 @@ def sample_rows(M, n=48):
 
 # Qwen-Image's ragged token counts (one forward: 7017 rows, batch-2 forward: 14034): edge tiles of gemm_w4_kernel in launches of >= 1 round
 RAGGED_M_SHAPES = [[7017, 3072, 9216], [14034, 3072, 3072], [7017, 12288, 3072]]
+# SD3.5-large with a CFG batch of 2 (hidden 2432 = 9.5 tiles of 256, 19 K steps of 128 bytes): ragged M, N and K on the 4-wave kernel (round 6)
+RAGGED_NK_SHAPES = [[8858, 2432, 2432], [8858, 2432, 7296], [8858, 9728, 2432], [4429, 2432, 9728]]
 
 
-@pytest.mark.parametrize("M,Kd,Nn", MM_SHAPES + RAGGED_M_SHAPES)
+@pytest.mark.parametrize("M,Kd,Nn", MM_SHAPES + RAGGED_M_SHAPES + RAGGED_NK_SHAPES)
 def test_fp8_matmul_reference_shapes(K, M, Kd, Nn):
     g = gen(M * 31 + Kd * 7 + Nn)
     a = torch.randn(M, Kd, generator=g).to(FP8)
@@ -348,7 +350,7 @@ def test_fp8_gemm_fused_epilogues_full_matrix(K, M, Kd, Nn, epi):
     N.check(N.lib().fdm_gemm_w8a8_fp8(N.ptr(out), N.ptr(ad), N.ptr(bd), N.ptr(sad), N.ptr(sbd), N.ptr(biasd), M, Nn, Kd, Kd, Kd, Nn, e,
                                       N.ptr(gd), Nn, N.ptr(rd), M, N.stream()), "fp8 gemm + epilogue")
     kern = int(N.lib().fdm_gemm_last_kernel())
-    assert kern == (2 if epi == "tanh" else 1), kern                   # persistent assembly for tanh-GELU, gemm_w4_kernel for the others
+    assert kern == {"tanh": 2, "erf": 1, "res": 5}[epi], kern         # persistent assembly for tanh-GELU, gemm_w4_kernel for erf, its 224-row form (408 / 384 tiles -> 468 / 444: 2 rounds either way) for gate + residual
     got = out.cpu()
     for r0 in range(0, M, 2176):                                       # the oracle in row chunks (memory)
         y = O.fp8_matmul(a[r0:r0 + 2176], b.t(), sa[r0:r0 + 2176], sb, BF16, bias)
@@ -369,7 +371,7 @@ def test_fp8_gemm_fused_epilogues_full_matrix(K, M, Kd, Nn, epi):
         ulp_close(got[r0:r0 + 2176], want, 0.05, f"fp8 {M}x{Kd}x{Nn} + {epi} rows {r0}..", ulps=2)
 
 
-@pytest.mark.parametrize("M,Kd,Nn", MM_SHAPES[::3] + [[130, 16, 16], [257, 48, 272]] + RAGGED_M_SHAPES)
+@pytest.mark.parametrize("M,Kd,Nn", MM_SHAPES[::3] + [[130, 16, 16], [257, 48, 272]] + RAGGED_M_SHAPES + RAGGED_NK_SHAPES[:2])
 def test_int8_matmul_reference_shapes(K, M, Kd, Nn):
     g = gen(M * 13 + Kd * 5 + Nn)
     a = torch.randint(-128, 128, (M, Kd), generator=g).to(torch.int8)
@@ -1418,6 +1420,7 @@ def test_gemm_224_row_tiles_are_bit_identical_to_256_row_tiles():
             "fp8_res_ragged": (2500, 3072, 3072, N.EPI_GATE_RESIDUAL, 1250), "fp8_res_f32_gate": (1792, 2048, 768, N.EPI_GATE_RESIDUAL_F32, 1792),
             "fp8_plain_whole": (1792, 2048, 768, N.EPI_NONE, 0), "fp8_tanh": (4096 + 37, 2048, 1024, N.EPI_GELU_TANH, 0),
             "fp8_res_batches_of_100": (900, 2304, 512, N.EPI_GATE_RESIDUAL, 100), "fp8_one_row": (1, 2048, 256, N.EPI_NONE, 0),
+            "fp8_res_sd35_ragged_n_k": (3000, 2432, 2432, N.EPI_GATE_RESIDUAL, 1500), "fp8_erf_ragged_n": (700, 2432, 392, N.EPI_GELU_ERF, 0),
         }.items():
             a = (torch.randn(m, k, generator=g) * 1.5).to(FP8).cuda()
             b = (torch.randn(n, k, generator=g) * 1.5).to(FP8).cuda()
@@ -1488,6 +1491,6 @@ def test_gemm_224_row_tiles_are_bit_identical_to_256_row_tiles():
         k, p4, half = N.gemm_dispatch_from_env()
         L.fdm_set_gemm_dispatch(k, p4, half)
         L.fdm_set_gemm_tile_rows(int(os.environ.get("FDM_GEMM_TILE_ROWS", "-1")))
-    assert len(out[256]) == 11
+    assert len(out[256]) == 13
     for name in out[256]:
         assert out[256][name] == out[224][name], f"{name}: 224-row tiles differ from 256-row tiles"
