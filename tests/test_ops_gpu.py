@@ -542,6 +542,40 @@ def test_bf16_gemm_and_epilogues():
         ulp_close(out, want, 0.03, f"bf16 gemm epi {epi}", ulps=2)
 
 
+@pytest.mark.parametrize("M,Kd,Nn,epi", [(8858, 2432, 2432, "res"), (8858, 2432, 7296, "none"), (8858, 9728, 2432, "res"), (7017, 1288, 3080, "tanh")])
+def test_bf16_gemm_ragged_n_and_k_on_the_4_wave_kernel(M, Kd, Nn, epi):
+    """Launches of >= 1 round take gemm_w4_kernel whatever N and K are (round 6: SD3.5-large's N = K = 2432 -- a masked last column tile, K steps
+    of 128 bytes with a zero-filled tail): bf16 form against the fp32-accumulate product, every row of a sample, with the strided output untouched
+    past N.  fdm_gemm_last_kernel() proves the 4-wave kernel (256- or 224-row tiles) ran."""
+    from fastdm_amd import _native as N
+    g = gen(M + 3 * Kd + Nn)
+    a, w, bias = rbf(g, M, Kd), rbf(g, Nn, Kd, scale=Kd ** -0.5), rbf(g, Nn, scale=0.1)
+    res, gate = rbf(g, M, Nn), rbf(g, 1, Nn)
+    ad, wd, bd, rd, gd = a.cuda(), w.cuda(), bias.cuda(), res.cuda(), gate.cuda()
+    e = {"none": N.EPI_NONE, "tanh": N.EPI_GELU_TANH, "res": N.EPI_GATE_RESIDUAL}[epi]
+    ldc = Nn + 8
+    out = torch.full((M, ldc), 7.0, dtype=BF16, device="cuda")
+    rr = torch.zeros((M, ldc), dtype=BF16, device="cuda")
+    rr[:, :Nn] = rd
+    N.check(N.lib().fdm_gemm_bf16(N.ptr(out), N.ptr(ad), N.ptr(wd), N.ptr(bd), M, Nn, Kd, Kd, Kd, ldc, e, N.ptr(gd) if epi == "res" else None, Nn,
+                                  N.ptr(rr) if epi == "res" else None, M, N.stream()), "gemm_bf16 ragged")
+    assert int(N.lib().fdm_gemm_last_kernel()) in (1, 5)
+    assert (out[:, Nn:] == 7.0).all()
+    rows = sample_rows(M)
+    y = torch.addmm(bias.float(), a[rows].float(), w.float().t()).to(BF16)
+    got = out[:, :Nn].cpu()[rows]
+    if epi == "tanh":
+        ulp_close(got, torch.nn.functional.gelu(y.float(), approximate="tanh").to(BF16), 0.05, f"bf16 {M}x{Kd}x{Nn} tanh", ulps=2)
+    elif epi == "res":
+        gy = (gate.float() * y.float()).to(BF16).float()
+        want = (res[rows].float() + gy).to(BF16)
+        d = (got.float() - want.float()).abs()
+        tol = 2.1 * 2.0 ** -7 * gy.abs() + 1.05 * 2.0 ** -7 * want.float().abs() + 2.0 ** -9 * gy.abs().mean()
+        assert (d <= tol).all(), f"bf16 {M}x{Kd}x{Nn} + res: {int((d > tol).sum())} elements beyond 2 ulp of the product + 1 of the sum, max {d.max().item()}"
+    else:
+        ulp_close(got, y, 0.03, f"bf16 {M}x{Kd}x{Nn}")
+
+
 @pytest.mark.parametrize("M,Kd,Nn", [(1, 256, 3072), (2, 3072, 18432), (3, 3072, 1001), (8, 3072, 9216 + 4), (5, 8192, 64)])
 def test_bf16_skinny_rows_gemv_path(M, Kd, Nn):
     """M <= 8 (the AdaLN modulation / timestep-embedding linears) takes the HBM-streaming GEMV kernel; it must agree
