@@ -1666,6 +1666,7 @@ static bool use_w4(const GemmGroup& grp) {
     // per step on one box (profiles/r06af_*), so whole launches of >= 1 round take the 4-wave kernel whatever N and K are
     if (!many_rounds && ((q.N % BN) || (q.Kb % 256))) return false;
     if ((q.N % 8) || (q.Kb % 16)) return false;
+    if ((q.N % BN) && (q.N % BN) < BN / 2) return false;     // a last column tile less than half full (Wan's N = 64 output projection) stays with the 8-wave kernel's half tiles
   }
   return true;
 #endif

@@ -542,7 +542,7 @@ def test_bf16_gemm_and_epilogues():
         ulp_close(out, want, 0.03, f"bf16 gemm epi {epi}", ulps=2)
 
 
-@pytest.mark.parametrize("M,Kd,Nn,epi", [(8858, 2432, 2432, "res"), (8858, 2432, 7296, "none"), (8858, 9728, 2432, "res"), (7017, 1288, 3080, "tanh")])
+@pytest.mark.parametrize("M,Kd,Nn,epi", [(8858, 2432, 2432, "res"), (8858, 2432, 7296, "none"), (8858, 9728, 2432, "res"), (7017, 1288, 3208, "tanh")])
 def test_bf16_gemm_ragged_n_and_k_on_the_4_wave_kernel(M, Kd, Nn, epi):
     """Launches of >= 1 round take gemm_w4_kernel whatever N and K are (round 6: SD3.5-large's N = K = 2432 -- a masked last column tile, K steps
     of 128 bytes with a zero-filled tail): bf16 form against the fp32-accumulate product, every row of a sample, with the strided output untouched
