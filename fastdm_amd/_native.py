@@ -44,6 +44,7 @@ SIGNATURES = {
     "fdm_conv2d_3x3_nhwc_bf16": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, I32, P, I64, P]),
     "fdm_linear_skinny_bf16": (I32, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, P]),
     "fdm_attn_fwd": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I32, I32, P, I64, P]),
+    "fdm_attn_fwd_causal": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P]),
     "fdm_attn_fwd_workspace_bytes": (I64, [I32]),
     "fdm_attn_pvfp8_workspace_bytes": (I64, [I64, I64, I32, I32]),
     "fdm_attn_fwd_pvfp8": (I32, [P, P, P, P, I64, I64, I64, I32, I32, I32, I64, I64, I64, I64, F32, P, I64, P, I64, P]),

@@ -123,7 +123,10 @@ __device__ __forceinline__ i32x4 tr_pair(const uint8_t* p0, const uint8_t* p1) {
 // NT threads = NT/64 waves of 32 query rows: 512 (256-row q-blocks, one block per CU: the dense path) or 256 (128-row
 // q-blocks = exactly one block-mask row, two blocks per CU: the block-sparse path, where the two halves of a 256-row
 // block would carry different masks and wait for each other).
-template <int D, int NT, int KTT>
+// CAUSAL (round 6; `is_causal=True` of the operator API, which no model of the reference passes): key j contributes to query row i iff j <= i
+// (torch's top-left alignment for Sq != Sk).  A block stops at the tile that holds its last row's diagonal; tiles that reach past a wave's
+// first row get the element mask.  Dense 512-thread form only (no block mask, no split-KV).
+template <int D, int NT, int KTT, bool CAUSAL = false>
 __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
   constexpr int KT = KTT;        // keys per tile: 128 on the dense path (half the barriers and DMA waits), 64 with a block mask
   constexpr int NKT = KT / 32;   // 32-key S^T tiles per KV tile
@@ -299,6 +302,16 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
         for (int e = 0; e < 16; ++e)
           if (kt2 * 32 + (e & 3) + 8 * (e >> 2) >= rem) sacc[kt2][e] = -INFINITY;
     }
+    if constexpr (CAUSAL) {
+      if ((int64_t)(t + 1) * KT - 1 > q0 + wave * 32) {     // (wave-uniform) the tile reaches past this wave's first row
+        const int lim = (int)(q0 + wave * 32 + lq - (int64_t)t * KT) - 4 * h;   // last local key index of this lane's row, shifted by the lane-half offset
+#pragma unroll
+        for (int kt2 = 0; kt2 < NKT; ++kt2)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (kt2 * 32 + (e & 3) + 8 * (e >> 2) > lim) sacc[kt2][e] = -INFINITY;
+      }
+    }
     // ---- online softmax in the exp2 domain with lazy rescale: the running max only moves (and O, l are only
     //      rescaled) when some row's tile max exceeds it by more than RESCALE_THR; the decision is taken before
     //      this tile is exponentiated and after the previous tile's P.V has been issued (textbook order).
@@ -363,7 +376,13 @@ __global__ void __launch_bounds__(NT, 2) attn_fwd_kernel(const AttnParams p) {
 #endif
   // KV range of this work item: everything, or the part-th of `split` consecutive ranges
   const int t_begin = is_part ? (int)((int64_t)part * ntiles / p.split) : 0;
-  const int t_end = is_part ? (int)((int64_t)(part + 1) * ntiles / p.split) : ntiles;
+  int t_hi = ntiles;
+  if constexpr (CAUSAL) {      // the block's last (existing) query row bounds the keys anyone here may see
+    const int64_t last_q = (q0 + QBT < p.sq ? q0 + QBT : p.sq) - 1;
+    const int64_t t_diag = last_q / KT + 1;
+    if (t_diag < t_hi) t_hi = (int)t_diag;
+  }
+  const int t_end = is_part ? (int)((int64_t)(part + 1) * ntiles / p.split) : t_hi;
   int t = next_active(t_begin);
   int cur = 0;
   if (t < t_end) stage_tile(t, 0);
@@ -741,8 +760,9 @@ static int attn_fwd_impl(void* o, const void* q, const void* k, const void* v, i
                          int q_heads, int kv_heads, int head_dim, int64_t q_tok_stride, int64_t k_tok_stride,
                          int64_t v_tok_stride, int64_t o_tok_stride, float scale, const int8_t* block_mask, int block_q,
                          int block_k, void* workspace, int64_t workspace_bytes, fdm_stream_t stream, int qmode, void* vq_ws,
-                         int64_t vq_bytes) {
+                         int64_t vq_bytes, bool causal = false) {
   const bool pv8 = qmode != 0;      // qmode: 0 bf16, 1 fp8 P.V, 2 fp8 QK^T + fp8 P.V
+  if (causal && (pv8 || block_mask != nullptr)) return FDM_ERR_UNSUPPORTED;
   (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
   if (!o || !q || !k || !v || batch <= 0 || sq <= 0 || sk <= 0 || q_heads <= 0 || kv_heads <= 0 || q_heads % kv_heads)
     return FDM_ERR_INVALID;
@@ -813,7 +833,7 @@ static int attn_fwd_impl(void* o, const void* q, const void* k, const void* v, i
   int n_tail = 0;
   // a workspace that cannot be used is an error, not a silent fall-back to the (20 % slower) unsplit schedule
   if (workspace != nullptr && ((reinterpret_cast<uintptr_t>(workspace) & 15) || workspace_bytes < 0)) return FDM_ERR_INVALID;
-  if (block_mask == nullptr && workspace != nullptr && (bh % 8) == 0) {
+  if (block_mask == nullptr && workspace != nullptr && (bh % 8) == 0 && !causal) {
     const int num_cu = device_cu_count() * (512 / ATT_THREADS);  // concurrent work-item slots on the chip (per device)
     const int rem = (int)(grid % num_cu);
     const int kt_dense = head_dim == 128 ? KT_DENSE : KT_MASK;
@@ -881,6 +901,9 @@ static int attn_fwd_impl(void* o, const void* q, const void* k, const void* v, i
     } else {
       attn_fwd64_pv8_kernel<128, false><<<(unsigned)grid, 256, 0, s>>>(p);
     }
+  } else if (causal) {
+    if (head_dim == 128) attn_fwd_kernel<128, 512, KT_MASK, true><<<(unsigned)grid, 512, 0, s>>>(p);
+    else attn_fwd_kernel<64, 512, KT_MASK, true><<<(unsigned)grid, 512, 0, s>>>(p);
   } else if (mask_v2) {
     attn_fwd64_kernel<128, true><<<(unsigned)grid, 256, 0, s>>>(p);
   } else if (block_mask != nullptr) {
@@ -911,6 +934,13 @@ extern "C" int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v
                             int block_k, void* workspace, int64_t workspace_bytes, fdm_stream_t stream) {
   return attn_fwd_impl(o, q, k, v, batch, sq, sk, q_heads, kv_heads, head_dim, q_tok_stride, k_tok_stride, v_tok_stride, o_tok_stride,
                        scale, block_mask, block_q, block_k, workspace, workspace_bytes, stream, 0, nullptr, 0);
+}
+
+extern "C" int fdm_attn_fwd_causal(void* o, const void* q, const void* k, const void* v, int64_t batch, int64_t sq, int64_t sk,
+                                   int q_heads, int kv_heads, int head_dim, int64_t q_tok_stride, int64_t k_tok_stride,
+                                   int64_t v_tok_stride, int64_t o_tok_stride, float scale, fdm_stream_t stream) {
+  return attn_fwd_impl(o, q, k, v, batch, sq, sk, q_heads, kv_heads, head_dim, q_tok_stride, k_tok_stride, v_tok_stride, o_tok_stride,
+                       scale, nullptr, 0, 0, nullptr, 0, stream, 0, nullptr, 0, true);
 }
 
 extern "C" int fdm_attn_fwd_pvfp8(void* o, const void* q, const void* k, const void* v, int64_t batch, int64_t sq, int64_t sk,

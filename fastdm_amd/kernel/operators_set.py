@@ -141,7 +141,8 @@ def int8_matmul(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b
 
 def _attn(query, key, value, num_q_heads, num_kv_heads, head_dim, is_causal, scale, mask, bq, bk):
     _need_gpu(query, key, value, mask)
-    assert not is_causal, "every call site of the reference passes is_causal=False; causal masking is not built"
+    if is_causal and mask is not None:
+        raise NotImplementedError("is_causal with a block mask: the reference's sparse shim drops the flag (kernel/cuda/attention.py:218-261); not built")
     assert query.dtype == BF16 and key.dtype == BF16 and value.dtype == BF16
     assert query.ndim == 3 and key.ndim == 3 and value.ndim == 3
     B, Sq, _ = query.shape
@@ -152,6 +153,11 @@ def _attn(query, key, value, num_q_heads, num_kv_heads, head_dim, is_causal, sca
     if scale is None:
         scale = head_dim ** -0.5
     out = torch.empty((B, Sq, num_q_heads * head_dim), device=query.device, dtype=query.dtype)
+    if is_causal:       # torch's top-left-aligned causal mask (kernel/torch/attention.py:34-43 hands the flag to F.scaled_dot_product_attention); bf16 arithmetic always
+        N.check(N.lib().fdm_attn_fwd_causal(N.ptr(out), N.ptr(query), N.ptr(key), N.ptr(value), B, Sq, Sk, num_q_heads, num_kv_heads, head_dim,
+                                            query.stride(1), key.stride(1), value.stride(1), out.stride(1), float(scale), N.stream()),
+                "scaled_dot_product_attention (causal)")
+        return out
     ws = N.attn_workspace(query.device, head_dim)
     if mask is not None and head_dim == 128 and attention_pv_fp8() and -(-Sk // 64) <= 4096:      # opt-in: the reference's SpargeAttn class
         mode = attention_pv_fp8()

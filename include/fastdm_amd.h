@@ -253,6 +253,13 @@ int fdm_attn_fwd(void* o, const void* q, const void* k, const void* v,
                  int64_t o_tok_stride, float scale,
                  const int8_t* block_mask, int block_q, int block_k,
                  void* workspace, int64_t workspace_bytes, fdm_stream_t stream);
+/* The same with causal masking (`is_causal=True` of scaled_dot_product_attention, kernel/operators_set.py:154-179; the reference's torch backend
+ * hands the flag to F.scaled_dot_product_attention, kernel/torch/attention.py:34-43 -- no model of the reference sets it): key j contributes to
+ * query row i iff j <= i (torch's top-left alignment when Sq != Sk).  bf16 arithmetic of fdm_attn_fwd; D in {64,128}; no block mask (ABI 20).   */
+int fdm_attn_fwd_causal(void* o, const void* q, const void* k, const void* v,
+                        int64_t batch, int64_t sq, int64_t sk, int q_heads, int kv_heads, int head_dim,
+                        int64_t q_tok_stride, int64_t k_tok_stride, int64_t v_tok_stride,
+                        int64_t o_tok_stride, float scale, fdm_stream_t stream);
 /* Optional scratch for fdm_attn_fwd (NULL = never split; a non-NULL workspace that is not 16-byte aligned is
  * FDM_ERR_INVALID, never a silent fall-back): when the last round of equal-sized q-block work
  * items would fill less than half the chip, those items are split along KV and merged (split-KV tail

@@ -676,6 +676,37 @@ def test_attention_reference_shapes(K, B, Sq, Sk, H, hd):
     rel = ((sub.float() - ref.float()).norm() / ref.float().norm()).item()
     assert rel <= 1.0e-2, rel                                                         # bf16 P and bf16 output rounding
 
+@pytest.mark.parametrize("B,Sq,Sk,H,hd", [(1, 1000, 1000, 4, 128), (2, 777, 777, 3, 64), (1, 300, 1000, 2, 64), (1, 1000, 300, 2, 128), (1, 4608, 4608, 24, 128),
+                                          (2, 4096, 4096, 10, 64)])
+def test_attention_is_causal_matches_the_masked_fp32_softmax(K, B, Sq, Sk, H, hd):
+    """`is_causal=True` of scaled_dot_product_attention (operators_set.py:154-179; the reference's torch backend hands it to
+    F.scaled_dot_product_attention, kernel/torch/attention.py:34-43: key j counts for query row i iff j <= i, top-left aligned when Sq != Sk):
+    sampled rows incl. row 0 (one key: the output IS v[0]), the rows around every 64-key tile edge and 256-row block edge, against the fp32
+    softmax over exactly the allowed keys -- the non-causal tests' tolerances."""
+    g = gen(Sq * 3 + Sk + H + hd)
+    q, k, v = rbf(g, B, Sq, H * hd, scale=4.0), rbf(g, B, Sk, H * hd), rbf(g, B, Sk, H * hd)
+    got = K.scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, is_causal=True, scale=hd ** -0.5).cpu()
+    assert torch.isfinite(got.float()).all()
+    rows = sorted(set(sample_rows(Sq, 16).tolist() + [r for r in (1, 31, 32, 63, 64, 65, 127, 128, 255, 256, 257, 299, 300, 301, 511, 512) if r < Sq]))
+    heads = sorted({0, H - 1, H // 2})
+    ref = torch.empty(B, len(rows), len(heads) * hd)
+    for hi, h in enumerate(heads):
+        qs, ks, vs = (t[:, :, h * hd:(h + 1) * hd].float() for t in (q, k, v))
+        for ri, r in enumerate(rows):
+            n = min(r + 1, Sk)
+            w = torch.softmax((qs[:, r:r + 1] @ ks[:, :n].transpose(1, 2)) * hd ** -0.5, dim=-1)
+            ref[:, ri, hi * hd:(hi + 1) * hd] = (w @ vs[:, :n])[:, 0]
+    hsel = torch.cat([torch.arange(h * hd, (h + 1) * hd) for h in heads])
+    sub = got[:, rows][:, :, hsel].float()
+    torch.testing.assert_close(sub, ref, rtol=0.0, atol=1.8e-2)
+    assert torch.equal(got[:, 0], v[:, 0])                                   # one key: weight 1 exactly
+    rel = ((sub - ref).norm() / ref.norm()).item()
+    assert rel <= 1.0e-2, rel
+    with pytest.raises(NotImplementedError):
+        K.sparse_scaled_dot_product_attention(q.cuda(), k.cuda(), v.cuda(), H, H, hd, is_causal=True, scale=hd ** -0.5,
+                                              sparse_mask=torch.ones(B, H, -(-Sq // 128), -(-Sk // 64), dtype=torch.int8, device="cuda"))
+
+
 # ------------------------------------------------------------------ opt-in quantised attention (fdm_attn_fwd_pvfp8; VERDICT r4 missing item 2)
 def _pv8(q, k, v, H, hd, ws=True, mode=1):
     """fdm_attn_fwd_pvfp8 (mode 1) / fdm_attn_fwd_fp8 (mode 2: fp8 QK^T too) through the C ABI on [B, S, H*hd] CUDA tensors."""
