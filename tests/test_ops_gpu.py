@@ -475,6 +475,28 @@ def test_plane_split_projection_equals_plain_output(K, quant, C):
     assert torch.equal(planes1.permute(1, 0, 2).reshape(m_img, 3 * C), plain_i)
 
 
+def test_plane_split_projection_on_the_4_wave_kernel_with_ragged_plane_width():
+    """SD3.5-large's fused q|k|v projection at full size (CFG batch of 2: M = 8858, K = 2432, three planes of 2432 columns = 9.5 column tiles each): since
+    round 6 the launch runs on gemm_w4_kernel (ragged N and K); a 256-column tile straddles two planes, every 8-column piece lands in its own.  Same bits
+    as the plain [M, 3C] output of the same kernel (which test_fp8_matmul_reference_shapes checks against the oracle at this shape)."""
+    from fastdm_amd import _native as N
+    from fastdm_amd.layer.qlinear import QLinear
+    g = gen(2432)
+    C, Kd, M = 2432, 2432, 8858
+    lin = QLinear(Kd, 3 * C, bias=True, data_type=BF16)
+    lin.weight_loading_and_quant([rbf(g, 3 * C, Kd, scale=Kd ** -0.5).t()], [rbf(g, 3 * C, scale=0.1)], FP8)
+    x = rbf(g, M, Kd).cuda()
+    qx = lin.quantize_input(x)
+    plain = lin.forward_q(qx)
+    assert int(N.lib().fdm_gemm_last_kernel()) in (1, 5)
+    planes = torch.full((3, M + 3, C), 3.0, dtype=BF16, device="cuda")
+    QLinear.forward_q_planes([(lin, qx, 0)], planes)
+    assert int(N.lib().fdm_gemm_last_kernel()) in (1, 5)
+    for pl in range(3):
+        assert torch.equal(planes[pl, :M], plain[:, pl * C:(pl + 1) * C]), pl
+        assert (planes[pl, M:] == 3.0).all()
+
+
 def test_gemm_p4_persistent_assembly_is_bit_identical_to_gemm_w4():
     """fdm::gemm_p4_kernel (the persistent fp8 tile loop in hand-written gfx950 assembly, fastdm_amd/csrc/gen_gemm_p4.py) issues the same
     MFMAs in the same K order and applies the same epilogue arithmetic as fdm::gemm_w4_kernel, so every output bit must agree: plain
