@@ -1442,6 +1442,61 @@ def test_conv2d_3x3_nhwc_against_fp32_convolution(K, B, C, H, W, O, stride, up, 
         assert (d > 0).float().mean().item() <= 0.03, what
 
 
+def test_conv2d_3x3_nhwc_random_shapes():
+    """24 seeded random shapes of fdm_conv2d_3x3_nhwc_bf16 (odd image sizes down to 3 x 3, 1-3 images, C_in 32 .. 352, C_out 8 .. 392, stride 2, the folded
+    upsampling, the residual epilogue; tile, half-tile and split-K launches as the dispatch rule decides) against the fp32 convolution: the bounds of
+    test_conv2d_3x3_nhwc_against_fp32_convolution."""
+    import random
+    import torch.nn.functional as F
+    from fastdm_amd.kernel import fused
+    rnd = random.Random(20260)
+    for case in range(24):
+        B, C, O = rnd.choice([1, 1, 2, 3]), 32 * rnd.randint(1, 11), 8 * rnd.randint(1, 49)
+        H, W = rnd.randint(3, 41), rnd.randint(3, 41)
+        stride = rnd.choice([1, 1, 2])
+        up = stride == 1 and rnd.random() < 0.25
+        res = rnd.random() < 0.5
+        g = gen(1000 + case)
+        x = rbf(g, B, C, H, W).contiguous(memory_format=torch.channels_last)
+        w = rbf(g, O, C, 3, 3, scale=(9 * C) ** -0.5).contiguous(memory_format=torch.channels_last)
+        bias = rbf(g, O, scale=0.2)
+        xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+        y = F.conv2d(xin, w.float(), bias.float(), stride, 1).to(BF16)
+        r = rbf(g, *y.shape).contiguous(memory_format=torch.channels_last) if res else None
+        want = y if r is None else (r.float() + y.float()).to(BF16)
+        got = fused.conv2d(x.cuda(), w.cuda(), bias.cuda(), stride, 1, upsample=up, res=None if r is None else r.cuda())
+        what = f"case {case}: conv {B}x{C}x{H}x{W} -> {O} stride {stride} up {up} res {res}"
+        assert got.shape == want.shape, what
+        d = (got.float().cpu() - want.float()).abs()
+        tol = 1.05 * 2.0 ** -7 * (y.float().abs() + want.float().abs()) + 2.0 ** -9 * y.float().abs().mean()
+        assert (d <= tol).all(), f"{what}: {int((d > tol).sum())} elements out of bounds, max {d.max().item()}"
+        assert (d > 0).float().mean().item() <= 0.04, what
+
+
+def test_group_norm_nhwc_random_shapes():
+    """16 seeded random shapes of fdm_group_norm_nhwc (1-3 images, 32 groups of 2 .. 40 channels, 2 .. 1500 pixels incl. primes, with and without the
+    per-image addend and the SiLU) against torch's fp32 chain: <= 1 bf16 ulp (2 behind the SiLU)."""
+    import random
+    import torch.nn.functional as F
+    from fastdm_amd.kernel import fused
+    rnd = random.Random(777)
+    for case in range(16):
+        B, C = rnd.choice([1, 2, 3]), 64 * rnd.randint(1, 20)
+        H, W = rnd.choice([(2, 1), (1, 7), (3, 3), (5, 13), (16, 16), (31, 37), (30, 50), (17, 1)])      # (a 1 x 1 image is NCHW-contiguous as well: torch's path)
+        silu, add = rnd.random() < 0.5, rnd.random() < 0.5
+        g = gen(5000 + case)
+        x = (rbf(g, B, C, H, W, scale=1.3) + 0.25).to(BF16)
+        gamma, beta = (1.0 + 0.1 * torch.randn(C, generator=g)).to(BF16), (0.1 * torch.randn(C, generator=g)).to(BF16)
+        addend = rbf(g, B, C, scale=0.5) if add else None
+        v = x if addend is None else (x.float() + addend.float()[:, :, None, None]).to(BF16)
+        y = F.group_norm(v.float(), 32, gamma.float(), beta.float(), 1e-5).to(BF16)
+        want = F.silu(y.float()).to(BF16) if silu else y
+        xd = x.cuda().contiguous(memory_format=torch.channels_last)
+        assert not xd.is_contiguous()
+        got = fused.group_norm(xd, 32, gamma.cuda(), beta.cuda(), 1e-5, addend=None if addend is None else addend.cuda(), silu=silu)
+        ulp_close(got, want, 0.03, f"case {case}: group_norm nhwc {B}x{C}x{H}x{W} silu {silu} add {add}", ulps=2 if silu else 1)
+
+
 @pytest.mark.parametrize("B,C,H,W,silu,add", [(2, 320, 64, 64, True, False), (2, 640, 32, 32, True, True), (2, 1280, 16, 16, False, False),
                                               (2, 2560, 16, 16, True, True), (1, 960, 9, 5, True, True), (3, 64, 7, 3, False, True)])
 def test_group_norm_nhwc_matches_the_nchw_kernel_and_torch(K, B, C, H, W, silu, add):
