@@ -497,6 +497,85 @@ def test_plane_split_projection_on_the_4_wave_kernel_with_ragged_plane_width():
         assert (planes[pl, M:] == 3.0).all()
 
 
+def test_gemm_random_shapes_through_the_dispatch_policy():
+    """36 seeded random launches through the C ABI with the DEFAULT dispatch policy (persistent assembly / 4-wave kernel with 256- or 224-row tiles /
+    8-wave kernel with whole or half tiles / GEMV; round 6 moved several borders): fp8, int8 (+ zero points) and bf16; M 1 .. 15000, N and K multiples
+    of 16 incl. the ragged ones; plain, GELU and gate + residual epilogues; bias or none; a strided output.  Sampled rows against the oracle
+    (oracle/ops.py fp8_matmul / int8_matmul, the fp32 product for bf16) with the bounds of the full-matrix tests; the kernel that ran is printed per
+    case (pytest -s) and the set of kernels exercised is asserted to be wide."""
+    import random
+    from fastdm_amd import _native as N
+    rnd = random.Random(606)
+    L, st = N.lib(), N.stream()
+    seen = set()
+    for case in range(36):
+        dt = ("fp8", "int8", "bf16")[case % 3]
+        M = rnd.choice([1, 7, 154, 300, 666, 1000, 2048, 3000, 4429, 4608, 7017, 8192, 8704, 8858, 14034, rnd.randint(1, 15000)])
+        Nn = 16 * rnd.choice([4, 20, 40, 80, 152, 192, 200, 320, 456, 576, 608, 768, rnd.randint(1, 800)])
+        Kd = 16 * rnd.choice([8, 40, 80, 128, 152, 192, 200, 320, 608, 768, 960, rnd.randint(2, 1000)])
+        if M * Nn * Kd > 9.0e11:
+            Kd = max(128, 16 * int(9.0e11 / (M * Nn) / 16))
+        epi = rnd.choice(["none", "none", "tanh", "erf", "res", "res"])
+        has_bias = rnd.random() < 0.7
+        g = gen(9000 + case)
+        e = {"none": N.EPI_NONE, "tanh": N.EPI_GELU_TANH, "erf": N.EPI_GELU_ERF, "res": N.EPI_GATE_RESIDUAL}[epi]
+        rpb = rnd.choice([M, (M + 1) // 2]) if epi == "res" else 0
+        nb = (M + rpb - 1) // rpb if rpb else 1
+        bias = rbf(g, Nn, scale=0.3) if has_bias else None
+        gate, res = rbf(g, nb, Nn), rbf(g, M, Nn)
+        ldc = Nn + rnd.choice([0, 8, 64])
+        out = torch.full((M, ldc), 7.0, dtype=BF16, device="cuda")
+        rr = torch.zeros((M, ldc), dtype=BF16, device="cuda")
+        rr[:, :Nn] = res.cuda()
+        gd = gate.cuda()
+        gp, rp = (N.ptr(gd), N.ptr(rr)) if epi == "res" else (None, None)
+        bd = bias.cuda() if has_bias else None
+        rows = sample_rows(M, 20)
+        if dt == "fp8":
+            a, b = torch.randn(M, Kd, generator=g).to(FP8), torch.randn(Nn, Kd, generator=g).to(FP8)
+            sa, sb = torch.rand(M, 1, generator=g) * 0.02 + 0.01, torch.rand(Nn, 1, generator=g) * 0.02 + 0.01
+            ad, wd, sad, sbd = a.cuda(), b.cuda(), sa.cuda(), sb.cuda()
+            rc = L.fdm_gemm_w8a8_fp8(N.ptr(out), N.ptr(ad), N.ptr(wd), N.ptr(sad), N.ptr(sbd), N.ptr(bd), M, Nn, Kd, Kd, Kd, ldc, e, gp, Nn, rp, rpb, st)
+            y = O.fp8_matmul(a[rows], b.t(), sa[rows], sb, BF16, bias)
+        elif dt == "int8":
+            a = torch.randint(-128, 128, (M, Kd), generator=g, dtype=torch.int8)
+            b = torch.randint(-128, 128, (Nn, Kd), generator=g, dtype=torch.int8)
+            sa, sb = torch.rand(M, 1, generator=g) * 0.001 + 0.0005, torch.rand(Nn, 1, generator=g) * 0.001 + 0.0005
+            azp = torch.randint(-128, 127, (M, 1), generator=g).to(torch.int32)
+            adj = b.to(torch.int32).sum(dim=1, dtype=torch.int32).reshape(1, Nn).contiguous()
+            ad, wd, sad, sbd, azd, ajd = a.cuda(), b.cuda(), sa.cuda(), sb.cuda(), azp.cuda(), adj.cuda()
+            rc = L.fdm_gemm_w8a8_int8(N.ptr(out), N.ptr(ad), N.ptr(wd), N.ptr(sad), N.ptr(sbd), N.ptr(ajd), N.ptr(azd), N.ptr(bd), M, Nn, Kd, Kd, Kd, ldc, e,
+                                      gp, Nn, rp, rpb, st)
+            y = O.int8_matmul(a[rows], b.t(), sa[rows], sb, BF16, adj, azp[rows], bias)
+        else:
+            a, b = rbf(g, M, Kd), rbf(g, Nn, Kd, scale=Kd ** -0.5)
+            ad, wd = a.cuda(), b.cuda()
+            rc = L.fdm_gemm_bf16(N.ptr(out), N.ptr(ad), N.ptr(wd), N.ptr(bd), M, Nn, Kd, Kd, Kd, ldc, e, gp, Nn, rp, rpb, st)
+            acc = a[rows].float() @ b.float().t()
+            y = (acc + bias.float() if has_bias else acc).to(BF16)
+        kern = int(L.fdm_gemm_last_kernel())
+        what = f"case {case}: {dt} {M}x{Nn}x{Kd} {epi} bias {has_bias} ldc {ldc} -> kernel {kern}"
+        print(what)
+        assert rc == 0, what
+        seen.add(kern)
+        assert (out[:, Nn:] == 7.0).all(), what
+        got = out[:, :Nn].cpu()[rows]
+        if epi == "tanh":
+            ulp_close(got, torch.nn.functional.gelu(y.float(), approximate="tanh").to(BF16), 0.06, what, ulps=2)
+        elif epi == "erf":
+            ulp_close(got, torch.nn.functional.gelu(y.float()).to(BF16), 0.06, what, ulps=2)
+        elif epi == "res":
+            gsel = gate[(rows // rpb).clamp(max=nb - 1)]
+            gy = (gsel.float() * y.float()).to(BF16).float()
+            want = (res[rows].float() + gy).to(BF16)
+            d = (got.float() - want.float()).abs()
+            tol = 2.1 * 2.0 ** -7 * gy.abs() + 1.05 * 2.0 ** -7 * want.float().abs() + 2.0 ** -9 * gy.abs().mean()
+            assert (d <= tol).all(), f"{what}: {int((d > tol).sum())} elements beyond 2 ulp of the product + 1 of the sum, max {d.max().item()}"
+        else:
+            ulp_close(got, y, 0.04, what)
+    assert len(seen) >= 4, seen
+
+
 def test_gemm_p4_persistent_assembly_is_bit_identical_to_gemm_w4():
     """fdm::gemm_p4_kernel (the persistent fp8 tile loop in hand-written gfx950 assembly, fastdm_amd/csrc/gen_gemm_p4.py) issues the same
     MFMAs in the same K order and applies the same epilogue arithmetic as fdm::gemm_w4_kernel, so every output bit must agree: plain
