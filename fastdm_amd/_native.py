@@ -33,6 +33,7 @@ SIGNATURES = {
     "fdm_gelu_and_mul": (I32, [P, P, I64, I32, P]),
     "fdm_gemm_w8a8_fp8": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I32, P, I64, P, I64, P]),
     "fdm_gemm_w8a8_fp8_x2": (I32, [P, P, P]),
+    "fdm_gemm_bf16_x2": (I32, [P, P, P]),
     "fdm_gemm_w8a8_int8_x2": (I32, [P, P, P]),
     "fdm_gemm_w8a8_int8_x2_ws": (I32, [P, P, P, I64, P]),
     "fdm_gemm_int8_workspace_bytes": (I64, []),
@@ -84,6 +85,14 @@ class GemmFp8Desc(C.Structure):
                 ("epilogue", I64), ("epi_gate", P), ("epi_gate_stride", I64), ("epi_res", P), ("epi_rows_per_batch", I64),
                 ("out_plane_cols", I64), ("out_plane_stride", I64)]
 
+
+
+class GemmBf16Desc(C.Structure):
+    """struct fdm_gemm_bf16_desc (include/fastdm_amd.h)."""
+    _fields_ = [("out", P), ("a", P), ("b", P), ("bias", P),
+                ("M", I64), ("N", I64), ("K", I64), ("lda", I64), ("ldb", I64), ("ldc", I64),
+                ("epilogue", I64), ("epi_gate", P), ("epi_gate_stride", I64), ("epi_res", P), ("epi_rows_per_batch", I64),
+                ("out_plane_cols", I64), ("out_plane_stride", I64)]
 
 
 class GemmInt8Desc(C.Structure):

@@ -2222,6 +2222,28 @@ int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias, int
   return launch_gemm<DT_BF16>(g, to_stream(stream));
 }
 
+int fdm_gemm_bf16_x2(const fdm_gemm_bf16_desc* d0, const fdm_gemm_bf16_desc* d1, fdm_stream_t stream) {
+  (void)hipGetLastError();  // drop any stale error of an earlier, unrelated runtime call: FDM_CHECK_LAUNCH must see only ours
+  if (!d0 || !d1) return FDM_ERR_INVALID;
+  const bool swap = d1->M > 0 && d0->M > d1->M;       // the smaller problem first in the tile list (as fdm_gemm_w8a8_fp8_x2)
+  const fdm_gemm_bf16_desc* ds[2] = {swap ? d1 : d0, swap ? d0 : d1};
+  GemmGroup g;
+  int n = 0;
+  for (int i = 0; i < 2; ++i) {
+    const fdm_gemm_bf16_desc* d = ds[i];
+    if (d->M == 0 && d->N > 0 && d->K > 0) continue;
+    int rc = fill_problem(g.p[n], d->out, d->a, d->b, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, 2, (int)d->epilogue, d->epi_gate,
+                          d->epi_gate_stride, d->epi_res, d->epi_rows_per_batch, d->out_plane_cols);
+    if (rc == FDM_OK) rc = set_planes(g.p[n], d->out_plane_cols, d->out_plane_stride);
+    if (rc != FDM_OK) return rc;
+    g.p[n].bias = (const bf16_t*)d->bias;
+    ++n;
+  }
+  if (n == 0) return FDM_OK;
+  finish_group(g, n);
+  return launch_gemm<DT_BF16>(g, to_stream(stream));
+}
+
 int fdm_conv2d_3x3_nhwc_bf16(void* out, const void* x, const void* w, const void* bias, const void* res, const void* res_gate,
                              int64_t batch, int64_t h_in, int64_t w_in, int64_t c_in, int64_t c_out, int stride, int upsample2x,
                              void* workspace, int64_t workspace_bytes, fdm_stream_t stream) {

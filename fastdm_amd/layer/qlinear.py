@@ -140,6 +140,19 @@ class QLinear:
     def _desc(self, x, epilogue, gate, res, rows_per_batch, out):
         wt = self.weight
         K, Nn = wt.shape
+        if self.quant_type is None:      # bf16 layer: x is the [M, K] activation matrix itself (fdm_gemm_bf16_desc has no scales)
+            a = x
+            assert a.dtype == self.dtype and a.stride(1) == 1
+            M = a.shape[0]
+            if out is None:
+                out = torch.empty((M, Nn), device=a.device, dtype=self.dtype)
+            d = N.GemmBf16Desc()
+            d.out, d.a, d.b, d.bias = N.ptr(out), N.ptr(a), N.ptr(wt), N.ptr(self.bias)
+            d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, Nn, K, a.stride(0), wt.stride(1), out.stride(0)
+            d.epilogue = epilogue
+            d.epi_gate, d.epi_gate_stride = (N.ptr(gate), gate.stride(0)) if gate is not None else (None, 0)
+            d.epi_res, d.epi_rows_per_batch = N.ptr(res), rows_per_batch
+            return d, out, 2.0 * M * Nn * K
         a = x.q
         M = a.shape[0]
         if out is None:
@@ -180,31 +193,27 @@ class QLinear:
                 ws = N.gemm_int8_workspace(x0.q.device)
                 N.check(N.lib().fdm_gemm_w8a8_int8_x2_ws(ctypes.byref(d0), ctypes.byref(d1), N.ptr(ws), ws.numel(), N.stream()), "int8 linear pair")
             return o0, o1
+        if lin0.quant_type is None and lin1.quant_type is None and lin0.dtype == BF16 and lin1.dtype == BF16 and min(x0.shape[0], x1.shape[0]) > 8:
+            import ctypes                     # (M <= 8 keeps the GEMV kernel of fdm_gemm_bf16)
+            d0, o0, f0 = lin0._desc(x0, epilogue, gate0, res0, rpb0, out0)
+            d1, o1, f1 = lin1._desc(x1, epilogue, gate1, res1, rpb1, out1)
+            timing.log_gemm("bf16", [(d0.M, d0.N, d0.K, epilogue), (d1.M, d1.N, d1.K, epilogue)])
+            with span("gemm_bf16_res" if epilogue >= N.EPI_GATE_RESIDUAL else "gemm_bf16", f0 + f1):
+                N.check(N.lib().fdm_gemm_bf16_x2(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "bf16 linear pair")
+            return o0, o1
         return (lin0.forward_q(x0, epilogue, gate0, res0, rpb0, out0), lin1.forward_q(x1, epilogue, gate1, res1, rpb1, out1))
 
     @staticmethod
     def forward_q_planes(items, planes: torch.Tensor):
         """Fused projections whose N = P*C output columns are split into P compact planes (q|k|v): `planes` is a
         contiguous [P, rows, C] buffer and `items` = [(linear, x, first_row)], each linear writing its M rows at
-        first_row of every plane.  W8A8 linears go two per launch through the GEMM's plane-split output; bf16 linears
-        run one GEMM per plane on a column slice of the weight."""
+        first_row of every plane.  Two linears of one kind (fp8 / int8 / bf16) per launch through the GEMM's plane-split output."""
         import ctypes
         P_, rows, Cc = planes.shape
         assert planes.is_contiguous() and all(lin.weight.shape[1] == P_ * Cc for lin, _, _ in items)
         pending = []
         for lin, x, r0 in items:
-            if lin.quant_type is None:
-                wt = lin.weight
-                K = wt.shape[0]
-                a = x
-                assert a.dtype == lin.dtype and a.stride(1) == 1
-                for pl in range(P_):
-                    timing.log_gemm("bf16", [(a.shape[0], Cc, K, N.EPI_NONE)])
-                    with span("gemm_bf16", 2.0 * a.shape[0] * Cc * K):
-                        N.check(N.lib().fdm_gemm_bf16(N.ptr(planes[pl, r0:]), N.ptr(a), N.ptr(wt[:, pl * Cc:]),
-                                                      N.ptr(lin.bias[pl * Cc:]) if lin.bias is not None else None, a.shape[0], Cc, K,
-                                                      a.stride(0), wt.stride(1), Cc, N.EPI_NONE, None, 0, None, 0, N.stream()), "bf16 linear")
-                continue
+            # (bf16 linears too since round 6: one plane-split launch for both streams instead of one launch per plane and stream)
             d, _, f = lin._desc(x, N.EPI_NONE, None, None, 0, planes[0, r0:])
             d.out_plane_cols, d.out_plane_stride = Cc, rows * Cc
             pending.append((lin.quant_type, d, f))
@@ -216,9 +225,11 @@ class QLinear:
             else:
                 d1, f1 = type(d0)(), 0.0
                 d1.M, d1.N, d1.K = 0, 1, 1          # an empty problem: skipped by the library
-            timing.log_gemm("fp8" if qt == FP8 else "int8", [(d0.M, d0.N, d0.K, N.EPI_NONE), (d1.M, d1.N, d1.K, N.EPI_NONE)])
-            with span("gemm_w8a8_fp8" if qt == FP8 else "gemm_w8a8_int8", f0 + f1):
-                if qt == FP8:
+            timing.log_gemm("fp8" if qt == FP8 else "int8" if qt == torch.int8 else "bf16", [(d0.M, d0.N, d0.K, N.EPI_NONE), (d1.M, d1.N, d1.K, N.EPI_NONE)])
+            with span("gemm_w8a8_fp8" if qt == FP8 else "gemm_w8a8_int8" if qt == torch.int8 else "gemm_bf16", f0 + f1):
+                if qt is None:
+                    N.check(N.lib().fdm_gemm_bf16_x2(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "plane-split linear")
+                elif qt == FP8:
                     N.check(N.lib().fdm_gemm_w8a8_fp8_x2(ctypes.byref(d0), ctypes.byref(d1), N.stream()), "plane-split linear")
                 else:
                     ws = N.gemm_int8_workspace(planes.device)

@@ -232,6 +232,26 @@ int fdm_gemm_bf16(void* out, const void* a, const void* b, const void* bias,
                   int epilogue, const void* epi_gate, int64_t epi_gate_stride,
                   const void* epi_res, int64_t epi_rows_per_batch, fdm_stream_t stream);
 
+/* Two independent bf16 GEMMs in ONE launch (ABI 20; as fdm_gemm_w8a8_fp8_x2: the image- and text-stream projection of a double block, or one problem
+ * with an empty second one), with the plane-split output for fused q|k|v projections.  Fields as in fdm_gemm_bf16 / fdm_gemm_fp8_desc.  Until round 6
+ * the unquantised model ran the text stream's launches on their own (M = 512: 24 tiles on 256 CUs, 0.07 of peak: 9 of the 54 ms of GEMM time of a
+ * FLUX bf16 1024 x 1024 step) and a fused q|k|v projection as one launch per plane.  Same kernels, same arithmetic as fdm_gemm_bf16.            */
+typedef struct fdm_gemm_bf16_desc {
+  void* out;
+  const void* a;
+  const void* b;
+  const void* bias;
+  int64_t M, N, K, lda, ldb, ldc;
+  int64_t epilogue;
+  const void* epi_gate;
+  int64_t epi_gate_stride;
+  const void* epi_res;
+  int64_t epi_rows_per_batch;
+  int64_t out_plane_cols;   /* as in fdm_gemm_fp8_desc */
+  int64_t out_plane_stride;
+} fdm_gemm_bf16_desc;
+int fdm_gemm_bf16_x2(const fdm_gemm_bf16_desc* d0, const fdm_gemm_bf16_desc* d1, fdm_stream_t stream);
+
 /* The same linear for M <= 8 rows (AdaLN modulation / embedder projections: one weight-streaming GEMV launch, the kernel
  * fdm_gemm_bf16 itself picks for such shapes), with an optional second addend applied AFTER the output rounding:
  * out[m,n] = bf16(acc + bias[n]); where post_add != NULL and post_add[n] != 0: out[m,n] = bf16(out[m,n] + post_add[n]).

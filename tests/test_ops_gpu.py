@@ -475,6 +475,42 @@ def test_plane_split_projection_equals_plain_output(K, quant, C):
     assert torch.equal(planes1.permute(1, 0, 2).reshape(m_img, 3 * C), plain_i)
 
 
+@pytest.mark.parametrize("m_img,m_txt,Kd,Nn,epi", [(4096, 512, 3072, 3072, "res"), (4096, 512, 1024, 4096, "tanh"), (300, 37, 192, 528, "none"), (1000, 9, 2048, 512, "res")])
+def test_bf16_linear_pair_in_one_launch_equals_two_launches(m_img, m_txt, Kd, Nn, epi):
+    """fdm_gemm_bf16_x2 (round 6: the unquantised model's image- and text-stream projections in ONE launch, as the W8A8 path always did): every output
+    bit equals the two fdm_gemm_bf16 launches when the same tile kernel takes both forms (asserted through fdm_gemm_last_kernel; the 8-wave kernel's
+    half tiles are bit-identical to its whole tiles), and both agree with the fp32 product to the bf16 GEMM tests' bounds."""
+    from fastdm_amd import _native as N
+    from fastdm_amd.layer.qlinear import QLinear
+    g = gen(m_img + Kd + Nn)
+    e = {"none": N.EPI_NONE, "tanh": N.EPI_GELU_TANH, "res": N.EPI_GATE_RESIDUAL}[epi]
+    lins, xs, gates, ress = [], [], [], []
+    for m in (m_img, m_txt):
+        lin = QLinear(Kd, Nn, bias=True, data_type=BF16)
+        lin.weight_loading_and_quant([rbf(g, Nn, Kd, scale=Kd ** -0.5).t()], [rbf(g, Nn, scale=0.1)], None)
+        lins.append(lin)
+        xs.append(rbf(g, m, Kd).cuda())
+        gates.append(rbf(g, 1, Nn).cuda() if epi == "res" else None)
+        ress.append(rbf(g, m, Nn).cuda() if epi == "res" else None)
+    single, kern1 = [], []
+    for i in range(2):
+        single.append(lins[i].forward_q(xs[i], e, gates[i], ress[i], xs[i].shape[0] if epi == "res" else 0))
+        kern1.append(int(N.lib().fdm_gemm_last_kernel()))
+    o0, o1 = QLinear.forward_q_pair(lins[0], xs[0], lins[1], xs[1], e, gates[0], ress[0], m_img if epi == "res" else 0, None,
+                                    gates[1], ress[1], m_txt if epi == "res" else 0, None)
+    kern2 = int(N.lib().fdm_gemm_last_kernel())
+    fam = lambda k: "w4" if k in (1, 5) else "w8" if k in (0, 4) else str(k)      # noqa: E731
+    for i, (got, ref) in enumerate(((o0, single[0]), (o1, single[1]))):
+        if fam(kern1[i]) == fam(kern2):
+            assert torch.equal(got, ref), (i, kern1, kern2)
+        else:
+            ulp_close(got, ref, 0.05, f"pair vs single launch, problem {i} (kernels {kern1[i]} / {kern2})", ulps=2)
+    lin, x = lins[1], xs[1]
+    y = torch.addmm(lin.bias.float().cpu(), x.float().cpu(), lin.weight.float().cpu()).to(BF16)
+    if epi == "none":
+        ulp_close(o1, y, 0.03, "text problem of the pair vs fp32 product")
+
+
 def test_plane_split_projection_on_the_4_wave_kernel_with_ragged_plane_width():
     """SD3.5-large's fused q|k|v projection at full size (CFG batch of 2: M = 8858, K = 2432, three planes of 2432 columns = 9.5 column tiles each): since
     round 6 the launch runs on gemm_w4_kernel (ragged N and K); a 256-column tile straddles two planes, every 8-column piece lands in its own.  Same bits
