@@ -259,11 +259,15 @@ def qk_norm_rope_inplace(q_rows: torch.Tensor, k_rows: torch.Tensor, wq: torch.T
                                              q_rows.stride(-2), k_off, pos_offset, heads, head_dim, eps, N.stream()), "qk_norm_rope_inplace")
 
 
-def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, head_dim: int, scale: float) -> torch.Tensor:
-    """Dense attention on [B*S, H*D] buffers (same kernel as operators_set.scaled_dot_product_attention)."""
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, head_dim: int, scale: float,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Dense attention on [B*S, H*D] buffers (same kernel as operators_set.scaled_dot_product_attention).
+    out: a [B*S, H*D] view whose rows may be strided (the left columns of the [attention | mlp] operand of FLUX's single-block proj_out: no torch.cat)."""
     S = q.shape[0] // batch
     Sk = k.shape[0] // batch
-    out = torch.empty((q.shape[0], heads * head_dim), device=q.device, dtype=q.dtype)  # q/k/v may be strided views
+    if out is None:
+        out = torch.empty((q.shape[0], heads * head_dim), device=q.device, dtype=q.dtype)  # q/k/v may be strided views
+    assert out.shape == (q.shape[0], heads * head_dim) and out.stride(1) == 1 and out.dtype == q.dtype
     ws = N.attn_workspace(q.device, head_dim)
     from fastdm_amd.kernel.utils import attention_pv_fp8
     if head_dim == 128 and attention_pv_fp8():       # opt-in quantised attention (kernel/utils.py); its own timing span

@@ -115,7 +115,8 @@ class Attention:
             self.to_add_out = QLinear(self.inner_dim, query_dim, bias=True, data_type=data_type)
 
     # ---- fused path: inputs are [B*S, D] matrices (quantised or bf16), output = attention result [B*S_tot, D]
-    def attend(self, xq, batch: int, s_img: int, rope: Optional[torch.Tensor], enc_q=None, s_txt: int = 0) -> torch.Tensor:
+    def attend(self, xq, batch: int, s_img: int, rope: Optional[torch.Tensor], enc_q=None, s_txt: int = 0,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Both fused-qkv GEMMs write straight into three joint planes q|k|v [B*(S_txt+S_img), inner] (text rows first,
         as the reference concatenates them, transformer.py:288-296) through the GEMM's plane-split output; q/k are
         normalised + rotated in place and the attention kernel reads the planes -- no chunk, no cat, no copy of v."""
@@ -135,7 +136,7 @@ class Attention:
         if enc_q is not None:
             fused.qk_norm_rope_inplace(q, k, self.norm_added_q_weight, self.norm_added_k_weight, rope, batch * s_txt, s_txt, s_tot, 0,
                                        self.heads, self.head_dim, self.eps)
-        return fused.attention(q, k, v, batch, self.heads, self.head_dim, self.scale)
+        return fused.attention(q, k, v, batch, self.heads, self.head_dim, self.scale, out=out)
 
     # ---- reference signature
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None, attention_mask=None,

@@ -52,12 +52,16 @@ class FluxSingleTransformerBlock:
         # act_mlp (erf-GELU, flux.py:61): W8A8 -> deferred into the [attn | mlp] quantisation pass (layer/transformer.py FeedForward note),
         # bf16 -> the GEMM's epilogue
         deferred = self.proj_out.quant_type is not None
-        mlp = self.proj_mlp.forward_q(xin, epilogue=N.EPI_NONE if deferred else N.EPI_GELU_ERF)
-        attn = self.attn.attend(xin, B, S, image_rotary_emb)
         if deferred:
+            mlp = self.proj_mlp.forward_q(xin, epilogue=N.EPI_NONE)
+            attn = self.attn.attend(xin, B, S, image_rotary_emb)
             cat = fused.quantize_rows(attn, mlp, self.proj_out.quant_type, act1=N.EPI_GELU_ERF)
         else:
-            cat = torch.cat([attn, mlp], dim=1)
+            # bf16: the GEMM and the attention kernel write the two column ranges of proj_out's [attention | gelu(mlp)] operand directly
+            # (row stride D + mlp_hidden_dim): the torch.cat of flux.py:69 never runs
+            cat = torch.empty((B * S, D + self.mlp_hidden_dim), device=x.device, dtype=x.dtype)
+            self.proj_mlp.forward_q(xin, epilogue=N.EPI_GELU_ERF, out=cat[:, D:])
+            self.attn.attend(xin, B, S, image_rotary_emb, out=cat[:, :D])
         out = torch.empty_like(x)
         self.proj_out.forward_q(cat, epilogue=N.EPI_GATE_RESIDUAL, gate=gate, res=x, rows_per_batch=S, out=out)
         return out.view(B, S, D)
