@@ -388,6 +388,7 @@ def main():
                     "sharding / CFG-pair exchange / final gather with real HIP forwards); the line says so and is not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event spans")
+    ap.add_argument("--kernel-timing-every", type=int, default=0, help="HIP-event spans on every N-th timed step (default: 5 when --steps >= 10, else 1)")
     ap.add_argument("--no-device-state", action="store_true", help="skip the MFMA clock probe / rocm-smi readings taken around (never inside) the timed steps")
     ap.add_argument("--allow-build-flags", action="store_true", help="A/B only: accept a library built with extra hipcc flags (FDM_LIB_DIR=tools/micro/_ab/<name>); "
                     "the line then carries lib_flags and \"experimental\": true and is not a headline number")
@@ -605,11 +606,15 @@ def main():
         torch.cuda.synchronize()
         D.barrier()
         torch.cuda.synchronize()
-        rec = timing.Recorder() if not args.no_kernel_timing else None
+        # HIP-event spans on every 5th timed step (every step for short runs and step-cache runs, whose steps differ): see timing.Recorder
+        every = args.kernel_timing_every or (5 if (args.steps >= 10 and cache is None) else 1)
+        rec = timing.Recorder(every) if not args.no_kernel_timing else None
         t0 = time.perf_counter()
         if rec:
             rec.__enter__()
-        for _ in range(args.steps):
+        for step_i in range(args.steps):
+            if rec:
+                rec.begin_step(step_i)
             one_step()
         if rec:
             rec.__exit__(None, None, None)
@@ -704,14 +709,15 @@ def main():
         out["config"]["transport"] = "gloo, every rank on cuda:0 (--same-device)"
     if rec:
         summ = rec.summary()
+        n_timed = max(1, rec.sampled_steps)     # the steps whose launches carry HIP events
         kernels = {}
         for name, s in summ.items():
             dt = "bf16qk+fp8pv" if "pvfp8" in name else ("bf16" if "bf16" in name else ("int8" if "int8" in name else "fp8"))      # attn_fwd_fp8 -> "fp8"
             tf = s["work"] / (s["total_ms"] * 1e-3) / 1e12
-            kernels[name] = {"launches_per_step": s["launches"] / args.steps, "avg_ms": s["avg_ms"], "ms_per_step": s["total_ms"] / args.steps,
+            kernels[name] = {"launches_per_step": s["launches"] / n_timed, "avg_ms": s["avg_ms"], "ms_per_step": s["total_ms"] / n_timed,
                              "achieved_TFLOPs": tf, "peak_TFLOPs": PEAK_TFLOPS[dt], "frac": tf / PEAK_TFLOPS[dt]}
             if "by_kernel" in s:      # the tile kernel each launch of the span actually ran (fdm_gemm_last_kernel; one span can mix kernels)
-                kernels[name]["hip_kernels"] = {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["total_ms"] / args.steps,
+                kernels[name]["hip_kernels"] = {k: {"launches_per_step": v["launches"] / n_timed, "ms_per_step": v["total_ms"] / n_timed,
                                                     "achieved_TFLOPs": v["work"] / (v["total_ms"] * 1e-3) / 1e12} for k, v in s["by_kernel"].items()}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         default_workload = (args.model, args.height, args.width, args.max_seq_len, args.quant, args.cache_config) == ("flux", 1024, 2048, 512, "fp8", None)
@@ -719,7 +725,9 @@ def main():
         traffic, traffic_src = pmc_traffic(dom_kernel) if default_workload else (None, "not the default workload")
         out["roofline"] = {"kernel": dom_kernel, "span": dom, "bound": "mfma", "achieved": kernels[dom]["achieved_TFLOPs"],
                            "peak": kernels[dom]["peak_TFLOPs"], "unit": "TFLOP/s", "frac": kernels[dom]["frac"],
-                           "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": kernels[dom]["avg_ms"]}
+                           "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": kernels[dom]["avg_ms"],
+                           "timed_launches": summ[dom]["launches"],
+                           "event_sampling": f"HIP-event pairs around every launch of {n_timed} of the {args.steps} timed steps (every {rec.every}-th)"}
         out["kernels"] = kernels
         # the W8A8 GEMM family as ONE entry (its instantiations are separate spans above, so the family never shows up as the
         # "dominant kernel" although it is the largest share of the step)
@@ -731,8 +739,8 @@ def main():
             ran = sorted({k for f in fam for k in summ[f].get("by_kernel", {})})
             out["roofline_family"] = {"family": f"W8A8 {fdt} GEMM, all epilogues; kernels launched: {', '.join(ran) if ran else 'n/a'}", "spans": fam, "bound": "mfma",
                                       "achieved": f_tf, "peak": PEAK_TFLOPS[fdt], "unit": "TFLOP/s", "frac": f_tf / PEAK_TFLOPS[fdt],
-                                      "ms_per_step": f_ms / args.steps, "share_of_step": f_ms / args.steps / ms_per_step}
-        flops_step = sum(s["work"] for s in summ.values()) / args.steps
+                                      "ms_per_step": f_ms / n_timed, "share_of_step": f_ms / n_timed / ms_per_step}
+        flops_step = sum(s["work"] for s in summ.values()) / n_timed
         out["step_TFLOP"] = flops_step / 1e12
         out["step_achieved_TFLOPs"] = flops_step / (ms_per_step * 1e-3) / 1e12
     if world == 1 and not args.no_cpu_baseline and args.model in ("flux", "qwen", "sdxl"):

@@ -292,7 +292,7 @@ def test_bench_device_state_parses_rocm_smi_and_stays_off_under_a_profiler(monke
     assert not bench.DeviceState.smi_usable()
     # the timed region of main() forks nothing: no subprocess / rocm-smi call between the two perf_counter() reads
     src = open(os.path.join(root, "bench.py")).read()
-    timed = src[src.index("rec = timing.Recorder()"):src.index("elapsed = time.perf_counter() - t0")]
+    timed = src[src.index("rec = timing.Recorder("):src.index("elapsed = time.perf_counter() - t0")]
     assert "t0 = time.perf_counter()" in timed and "one_step()" in timed
     assert "subprocess" not in timed and "smi" not in timed and "probe" not in timed
 
